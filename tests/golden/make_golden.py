@@ -1,0 +1,429 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ from THE REFERENCE ITSELF.
+
+Runs only in the build container (needs /root/reference).  It recreates the py3-importable copy
+of the reference under /tmp/oracle_probe (mechanical lib2to3 conversion,
+the numpy-2 dtype-alias patch of utils/nms.pyx, stub modules for cv2/matlab/easydict), imports it
+from there, runs the hot-path functions on seeded inputs (tests/synth.py) and records their
+OUTPUTS.  Nothing of the reference (source, bytecode, .so) is written into the repository: the
+fixtures are data -- seeds/parameters + expected outputs.
+
+    python tests/golden/make_golden.py            # rebuild /tmp/oracle_probe if missing, write fixtures
+"""
+import copy
+import gzip
+import hashlib
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import synth  # noqa: E402
+
+O = '/tmp/oracle_probe'
+
+RECIPE = r'''
+set -e
+O=/tmp/oracle_probe; rm -rf $O; mkdir -p $O/py3 $O/stubs/matlab
+cp -r /root/reference $O/py3/vdetlib && chmod -R u+w $O/py3
+sed -i -e 's/np\.int_t/np.intp_t/g' -e 's/dtype=np\.int)/dtype=np.intp)/g' $O/py3/vdetlib/utils/nms.pyx
+cat > $O/py3/setup_probe.py <<'PY'
+import numpy as np
+from setuptools import setup, Extension
+from Cython.Build import cythonize
+setup(ext_modules=cythonize([Extension("vdetlib.utils.cython_nms", ["vdetlib/utils/nms.pyx"],
+      extra_compile_args=["-Wno-cpp","-Wno-unused-function"], include_dirs=[np.get_include()])],
+      language_level=2))
+PY
+(cd $O/py3 && python3 setup_probe.py build_ext --inplace >/dev/null 2>&1)
+python3 -m lib2to3 -w -n $O/py3/vdetlib/utils $O/py3/vdetlib/vdet $O/py3/vdetlib/tools >/dev/null 2>&1
+sed -i 's|half_window_size = window_size / 2|half_window_size = window_size // 2|' $O/py3/vdetlib/vdet/tubelet_cls.py
+cat > $O/stubs/cv2.py <<'PY'
+IMREAD_COLOR = 1
+INTER_LINEAR = 1
+FONT_HERSHEY_SIMPLEX = 0
+BORDER_CONSTANT = 0
+def _raise(*a, **k): raise RuntimeError("cv2 stub")
+imread = resize = rectangle = putText = copyMakeBorder = _raise
+PY
+echo 'double = lambda x: x' > $O/stubs/matlab/__init__.py
+cat > $O/stubs/matlab/engine.py <<'PY'
+class EngineError(Exception): pass
+def start_matlab(*a, **k): raise EngineError("no matlab")
+PY
+cat > $O/stubs/easydict.py <<'PY'
+class EasyDict(dict):
+    def __init__(self, d=None, **kw):
+        super().__init__()
+        d = dict(d or {}); d.update(kw)
+        for k, v in d.items(): self[k] = v
+    def __getattr__(self, k):
+        try: return self[k]
+        except KeyError: raise AttributeError(k)
+    def __setattr__(self, k, v): self[k] = v
+PY
+'''
+
+
+def load_reference():
+    if not os.path.isfile(os.path.join(O, 'py3/vdetlib/utils/protocol.py')) or \
+            not any(f.startswith('cython_nms') and f.endswith('.so')
+                    for f in os.listdir(os.path.join(O, 'py3/vdetlib/utils'))):
+        subprocess.check_call(['bash', '-c', RECIPE])
+    sys.path[:0] = [O + '/stubs', O + '/py3']
+    import scipy.misc
+    scipy.misc.imresize = None
+    import warnings
+    warnings.simplefilter('ignore')
+    from vdetlib.utils import cython_nms, protocol, common
+    from vdetlib.vdet import tubelet_cls, track, video_det, image_det, dataset
+    # py3: md5 needs bytes (utils/protocol.py:372-375)
+    protocol.bbox_hash = lambda v, f, b: hashlib.md5('{}_{}_{}_{}_{}_{}'.format(
+        v, f, b[0], b[1], b[2], b[3]).encode()).hexdigest()
+    video_det.bbox_hash = protocol.bbox_hash
+    tubelet_cls.bbox_hash = protocol.bbox_hash
+    return dict(nms=cython_nms, P=protocol, Cm=common, T=tubelet_cls, K=track, V=video_det,
+                I=image_det, D=dataset)
+
+
+def jdump(obj, name):
+    with open(os.path.join(HERE, name), 'w') as f:
+        json.dump(obj, f, separators=(',', ':'), sort_keys=True)
+
+
+def to_py(o):
+    """numpy scalars/arrays -> plain python for json."""
+    if isinstance(o, dict):
+        return {k: to_py(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [to_py(v) for v in o]
+    if isinstance(o, np.ndarray):
+        return o.tolist()
+    if isinstance(o, (np.floating,)):
+        return float(o)
+    if isinstance(o, (np.integer,)):
+        return int(o)
+    return o
+
+
+# ---------------------------------------------------------------------------------------------
+def g1_nms(R, npz, index):
+    cases = []
+    n_list = [0, 1, 2, 3, 63, 64, 65, 127, 128, 129, 300, 1000, 2500]
+    for n in n_list:
+        for thresh in (0.3, 0.5, 0.7):
+            for frac in (False, True):
+                cases.append(dict(seed=100 + n, n=n, thresh=thresh, frac=frac, degenerate=0,
+                                  kind='perm'))
+    # clustered duplicates, randn scores, odd thresholds (1/3 is not f32-exact; 0.0 / 1.0 / >1 edges)
+    for n, dg in ((300, 200), (1000, 900), (2000, 1500)):
+        for thresh in (0.3, 1.0 / 3.0, 0.5):
+            cases.append(dict(seed=7000 + n, n=n, thresh=thresh, frac=False, degenerate=dg,
+                              kind='randn'))
+    for thresh in (0.0, 1.0, 1.5, 1e-9, 0.9999999):
+        cases.append(dict(seed=4242, n=400, thresh=thresh, frac=False, degenerate=300, kind='perm'))
+    # the full-size config-2 problem shape (SURVEY appendix A sanity row lives in test code too)
+    for n in (10000,):
+        for thresh in (0.3, 0.5):
+            cases.append(dict(seed=n, n=n, thresh=thresh, frac=False, degenerate=0, kind='perm'))
+    cases.append(dict(seed=10001, n=10000, thresh=0.3, frac=True, degenerate=5000, kind='randn'))
+    for i, c in enumerate(cases):
+        d = synth.dets5(c['seed'], c['n'], c['frac'], c['degenerate'], c['kind'])
+        if c['n'] == 0:
+            d = np.zeros((0, 5), np.float32)
+        k = R['nms'].nms(d, c['thresh'])
+        npz['nms_%d' % i] = np.asarray(k, dtype=np.int32)
+    index['nms'] = cases
+
+
+def g2_vid_nms(R, npz, index):
+    cases = []
+    for n, nf in ((0, 1), (1, 1), (50, 1), (200, 3), (1000, 7), (3000, 30), (9000, 30)):
+        for thresh in (0.3, 0.5):
+            cases.append(dict(seed=200 + n, n=n, n_frames=nf, thresh=thresh, frac=(n % 3 == 0)))
+    for i, c in enumerate(cases):
+        d = synth.dets6(c['seed'], c['n'], c['n_frames'], c['frac'])
+        if c['n'] == 0:
+            d = np.zeros((0, 6), np.float32)
+        k = R['nms'].vid_nms(d, c['thresh'])
+        npz['vid_nms_%d' % i] = np.asarray(k, dtype=np.int32)
+        # equivalence used by the build: per-frame nms merged by global score order
+    index['vid_nms'] = cases
+
+
+def g3_track_det_nms(R, npz, index):
+    cases = []
+    for m, t, nf in ((0, 1, 1), (1, 1, 1), (40, 1, 1), (300, 1, 1), (300, 3, 2), (1000, 5, 4),
+                     (2000, 1, 1), (500, 0, 2)):
+        for thresh in (0.3, 0.5):
+            cases.append(dict(seed=300 + m + t, m=m, t=t, n_frames=nf, thresh=thresh))
+    for i, c in enumerate(cases):
+        d = synth.dets6(c['seed'], c['m'], c['n_frames'])
+        if c['m'] == 0:
+            d = np.zeros((0, 6), np.float32)
+        rng = np.random.RandomState(c['seed'] + 1)
+        tb = synth.boxes_1(rng, c['t'])
+        tf = rng.randint(1, c['n_frames'] + 1, c['t']).astype(np.float32)
+        tr = np.hstack([tf[:, None], tb]).astype(np.float32).reshape(-1, 5)
+        k = R['nms'].track_det_nms(tr, d, c['thresh'])
+        npz['tdn_%d' % i] = np.asarray(k, dtype=np.int32)
+    index['track_det_nms'] = cases
+
+
+def g4_iou(R, npz, index):
+    cases = []
+    for n1, n2, frac in ((1, 1, False), (1, 50, False), (3, 7, True), (20, 30, True), (1, 300, False)):
+        cases.append(dict(seed=400 + n1 + n2, n1=n1, n2=n2, frac=frac))
+    for i, c in enumerate(cases):
+        rng = np.random.RandomState(c['seed'])
+        b1 = synth.boxes_1(rng, c['n1'], c['frac']).astype(np.float64)
+        b2 = synth.boxes_1(rng, c['n2'], c['frac']).astype(np.float64)
+        if i == 1:
+            b2[:5] = b1[0]                 # exact duplicates -> iou 1.0
+        npz['iou_%d' % i] = R['Cm'].iou(b1, b2)
+    index['iou'] = cases
+
+
+def g13_ties(R, npz, index):
+    """Tie cases: numpy's default argsort is unstable, so record the order the reference actually
+    used on this machine next to its keep list; tests inject it through the C-ABI's `order`."""
+    cases = []
+    for n, levels in ((200, 5), (1000, 17), (3000, 64)):
+        cases.append(dict(seed=1300 + n, n=n, levels=levels, thresh=0.3))
+    for i, c in enumerate(cases):
+        rng = np.random.RandomState(c['seed'])
+        b = synth.boxes_1(rng, c['n'])
+        s = (rng.randint(0, c['levels'], c['n']) / float(c['levels'])).astype(np.float32)
+        d = np.hstack([b, s[:, None]]).astype(np.float32)
+        npz['ties_order_%d' % i] = d[:, 4].argsort()[::-1].astype(np.int32)
+        npz['ties_keep_%d' % i] = np.asarray(R['nms'].nms(d, c['thresh']), dtype=np.int32)
+    index['ties'] = cases
+
+
+# ---------------------------------------------------------------------------------------------
+CLS5 = ['__background__', 'airplane', 'antelope', 'bear', 'bicycle']
+
+
+def stub_tracker_factory(R, nan_at=None, span=3):
+    def stub_tracker(vid_proto, anchor_frame_id, anchor_bbox, opts):
+        rows, start = synth.stub_track_rows(len(vid_proto['frames']), anchor_frame_id,
+                                            list(anchor_bbox), span=span, nan_at=nan_at)
+        return R['P'].tracks_proto_from_boxes(rows, vid_proto['video'], anchor_frame_id, start, 1)
+    return stub_tracker
+
+
+def g5_to_g12_protos(R, out):
+    P, V, I, T, K, Cm = R['P'], R['V'], R['I'], R['T'], R['K'], R['Cm']
+    name = 'synth_vid_a'
+    F, B = 6, 40
+    vid = synth.make_vid_proto(name, F)
+    det = synth.make_det_proto(501, name, F, B, CLS5)
+
+    # G5 apply_image_nms / apply_vid_nms (incl. ignored `thres`, -inf for a missing class)
+    rng = np.random.RandomState(502)
+    bx = synth.boxes_1(rng, 120).astype(np.float64)
+    sc = synth.tie_free_scores(rng, 120).astype(np.float64)
+    out['apply_image_nms'] = dict(seed=502, n=120, thres=0.4, keep=to_py(I.apply_image_nms(bx, sc, 0.4)))
+    g5 = {}
+    for ci in (1, 3):
+        g5[str(ci)] = V.apply_vid_nms(copy.deepcopy(det), ci, thres=0.9)      # thres is ignored (:57)
+    g5['missing_class_7'] = V.apply_vid_nms(copy.deepcopy(det), 7)
+    out['apply_vid_nms'] = to_py({k: [d['hash'] for d in v['detections']] for k, v in g5.items()})
+
+    # G6 fast_rcnn_det_vid with stub det_fun / imread
+    Fv, Bv, Cv = 4, 150, 4
+    vid6 = synth.make_vid_proto('synth_vid_b', Fv)
+    box6 = synth.make_box_proto(601, 'synth_vid_b', Fv, Bv)
+    V.imread = lambda p: None
+
+    def det_fun(net, im, orig_boxes):
+        # deterministic per-frame stand-in for the CNN: keyed on the first box
+        seed = 600 + int(orig_boxes[0][0]) + 7 * int(orig_boxes[0][1])
+        r = np.random.RandomState(seed)
+        scores = r.rand(len(orig_boxes), Cv + 1)
+        deltas = r.uniform(-5, 5, (len(orig_boxes), 4 * (Cv + 1)))
+        boxes = np.tile(orig_boxes.astype(np.float64), (1, Cv + 1)) + deltas
+        return scores, boxes
+    import io
+    import contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        all_boxes = V.fast_rcnn_det_vid(None, vid6, box6, det_fun, class_names=CLS5[:Cv + 1],
+                                        max_per_image=100, thresh=0.05)
+        all_boxes_k = V.fast_rcnn_det_vid(None, vid6, box6, det_fun, class_names=CLS5[:Cv + 1],
+                                          max_per_image=20, thresh=0.5)
+    out['fast_rcnn_det_vid'] = dict(F=Fv, B=Bv, C=Cv, box_seed=601,
+                                    full=to_py([[np.asarray(a).tolist() for a in cls] for cls in all_boxes]),
+                                    top20=to_py([[np.asarray(a).tolist() for a in cls] for cls in all_boxes_k]))
+
+    # G7 greedy tracking with the stub tracker
+    g7 = {}
+    for tag, kw in (('plain', {}), ('nan_split', {'nan_at': 1})):
+        trk = stub_tracker_factory(R, **kw)
+        for ci in (1, 2):
+            opts = Cm.options({'max_tracks': 5, 'thres': 0.2, 'nms_thres': 0.3})
+            g7['%s_det_c%d' % (tag, ci)] = K.greedily_track_from_det(
+                vid, copy.deepcopy(det), trk, lambda d, ci=ci: P.det_score(d, ci), opts)
+        # raw-det twin: det_info [F*B, 5+C] f64 rows (frame, x1,y1,x2,y2, scores of classes 1..C-1)
+        det_info = np.asarray([[d['frame']] + d['bbox'] + [s['score'] for s in d['scores'][1:]]
+                               for d in det['detections']], dtype=np.float64)
+        for ci in (1, 4):
+            opts = Cm.options({'max_tracks': 4, 'thres': 0.5})       # nms_thres default 0.3 (:190-193)
+            g7['%s_raw_c%d' % (tag, ci)] = K.greedily_track_from_raw_dets(vid, det_info, trk, ci, opts)
+    out['greedy_track'] = to_py(g7)
+
+    # G8 spatial max-pooling (+ completion) on the tracks above
+    track_proto = g7['plain_det_c1']
+    g8 = {}
+    g8['dets_c1_0.7'] = T.dets_spatial_max_pooling(vid, copy.deepcopy(track_proto), det, 1, 0.7)
+    g8['dets_c2_0.3'] = T.dets_spatial_max_pooling(vid, copy.deepcopy(track_proto), det, 2, 0.3)
+    frame_to_det = {}
+    for f in range(1, F + 1):
+        ds = [d for d in det['detections'] if d['frame'] == f]
+        if f == 4:
+            continue                                            # a frame without det file (:511)
+        frame_to_det[f] = (np.asarray([d['bbox'] for d in ds], dtype=np.float64) + 0.25,
+                           np.asarray([[s['score'] for s in d['scores'][1:]] for d in ds],
+                                      dtype=np.float32))
+    frame_to_det[5] = (np.zeros((0, 4)), np.zeros((0, 4), np.float32))    # empty frame (:513)
+    g8['raw_c1_0.5'] = T.raw_dets_spatial_max_pooling(vid, copy.deepcopy(track_proto), frame_to_det, 1, 0.5)
+    g8['raw_c3_0.7'] = T.raw_dets_spatial_max_pooling(vid, copy.deepcopy(track_proto), frame_to_det, 3, 0.7)
+    out['spatial_maxpool'] = to_py(g8)
+    # completion on hand-made gap patterns
+    comp = {}
+    pats = {'lead': [-1e5, -1e5, 0.3, 0.5], 'trail': [0.2, 0.7, -1e5, -1e5, -1e5],
+            'inner': [0.1, -1e5, -1e5, -1e5, 0.9, -20.0, 0.4], 'none': [0.1, 0.2],
+            'edge_m10': [-10.0, 0.5, -9.99, -10.0, 1.5]}
+    for k, pat in pats.items():
+        sp = {'video': 'x', 'method': 'm', 'tubelets': [{'gt': 0, 'boxes': [{'det_score': v} for v in pat]}]}
+        T.do_score_completion(sp)
+        comp[k] = dict(inp=pat, out=[b['det_score'] for b in sp['tubelets'][0]['boxes']])
+    out['completion'] = to_py(comp)
+
+    # G9 temporal max-pool
+    g9 = {}
+    base = g8['dets_c1_0.7']
+    for w in (1, 3, 5, 7):
+        g9['w%d' % w] = T.score_proto_temporal_maxpool(copy.deepcopy(base), w)
+    out['temporal_maxpool'] = to_py(g9)
+    rng = np.random.RandomState(901)
+    series = rng.randn(23).tolist()
+    sp = {'video': 'x', 'method': 'm', 'tubelets': [{'gt': 0, 'boxes': [{'det_score': v} for v in series]}]}
+    out['temporal_maxpool_series'] = to_py(dict(
+        inp=series, **{'w%d' % w: [b['det_score'] for b in T.score_proto_temporal_maxpool(
+            copy.deepcopy(sp), w)['tubelets'][0]['boxes']] for w in (3, 5, 9)}))
+
+    # G10 interpolation incl. the min==2 / max==F-1 extrapolation rule (:472-475)
+    g10 = {}
+    vid10 = synth.make_vid_proto('synth_vid_c', 12)
+    rng = np.random.RandomState(1001)
+    for tag, frames in (('sparse', [3, 5, 9]), ('min2_maxF1', [2, 4, 7, 11]), ('single', [5]),
+                        ('dense', [1, 2, 3, 4])):
+        boxes = []
+        for f in frames:
+            bb = synth.boxes_1(rng, 1)[0]
+            boxes.append({'frame': f, 'bbox': [int(v) for v in bb], 'det_score': float(rng.randn()),
+                          'anchor': f - frames[0], 'track_score': 0.5, 'hash': 'h'})
+        sp = {'video': 'synth_vid_c', 'method': 'm',
+              'tubelets': [{'gt': 0, 'class': 'airplane', 'class_index': 1, 'boxes': boxes}]}
+        g10[tag] = dict(inp=sp, out=T.score_proto_interpolation(copy.deepcopy(sp), vid10))
+    out['interpolation'] = to_py(g10)
+
+    # G11 misc protocol helpers
+    g11 = {}
+    annot = {'video': name, 'annotations': [
+        {'id': 0, 'track': [{'frame': f, 'bbox': [10 + f, 20, 110 + f, 140], 'class': 'airplane',
+                             'class_index': 1, 'name': 'n', 'occluded': 0, 'generated': 0}
+                            for f in range(1, 5)]},
+        {'id': 1, 'track': [{'frame': f, 'bbox': [300, 200 + f, 420, 330 + f], 'class': 'bear',
+                             'class_index': 3, 'name': 'n', 'occluded': 0, 'generated': 0}
+                            for f in range(2, 7)]}]}
+    g11['annot'] = annot
+    g11['track_proto_from_annot_proto'] = P.track_proto_from_annot_proto(copy.deepcopy(annot))
+    tubs = P.tubelets_proto_from_tracks_proto(copy.deepcopy(track_proto['tracks']), 1)
+    g11['tubelets_proto_from_tracks_proto'] = copy.deepcopy(tubs)
+    g11['tubelets_overlap'] = P.tubelets_overlap(copy.deepcopy(tubs), annot, 1)
+    gt_tubs = P.tubelets_proto_from_tracks_proto(g11['track_proto_from_annot_proto']['tracks'][:1], 1)
+    g11['tubelets_overlap_gt'] = P.tubelets_overlap(copy.deepcopy(gt_tubs), annot, 1)
+    a = copy.deepcopy(g8['dets_c1_0.7'])
+    b = copy.deepcopy(g9['w3'])
+    g11['merge_max'] = P.merge_score_protos(copy.deepcopy(a), copy.deepcopy(b), 'max')
+    g11['merge_combine'] = P.merge_score_protos(copy.deepcopy(a), copy.deepcopy(b), 'combine')
+    g11['anchor_propagate'] = T.anchor_propagate(vid, copy.deepcopy(track_proto), det, 2)
+    g11['top_detections'] = [d['hash'] for d in P.top_detections(det, 7, 2)['detections']]
+    g11['frame_top_detections'] = sorted(d['hash'] for d in P.frame_top_detections(det, 3, 1)['detections'])
+    rows = np.asarray([[1, 2, 30.7, 40.2, 0.9], [2, 3, 31, 41, 0.8], [np.nan] * 5, [4, 5, 33, 43, 0.6],
+                       [np.nan] * 5, [np.nan] * 5, [7, 8, 36, 46, 0.3]])
+    g11['tracks_proto_from_boxes'] = P.tracks_proto_from_boxes(rows, 'vv', 5, 3, 2)
+    g11['boxes_proto_from_boxes'] = P.boxes_proto_from_boxes([1, 2], [[[1, 2, 3, 4], [5, 6, 7, 8]], [[9, 9, 20, 20]]], 'vv')
+    g11['score_proto'] = P.score_proto(CLS5, np.asarray([0.1, 0.2, 0.3, 0.4, 0.5]))
+    g11['sample_vid_proto'] = P.sample_vid_proto(synth.make_vid_proto('s', 25), 10)
+    g11['empty_det_from_box'] = P.empty_det_from_box(synth.make_box_proto(1101, 'e', 2, 3))
+    g11['frame_paths'] = dict(at=P.frame_path_at(vid, 3), before=P.frame_path_before(vid, 3),
+                              after=P.frame_path_after(vid, 5))
+    g11['det_score_missing'] = repr(P.det_score(det['detections'][0], 99))
+    out['protocol_misc'] = to_py(g11)
+
+    # G12 proto_dump / proto_load round trip (parsed-object equality; .gz preference)
+    with tempfile.TemporaryDirectory() as td:
+        p1 = os.path.join(td, 'a.det')
+        P.proto_dump(g5['1'], p1)
+        raw = open(p1).read()
+        p2 = os.path.join(td, 'b.det.gz')
+        # py3: GzipFile.write needs bytes; the reference writes a str (py2) -> emulate by dumping
+        # through the same json.dumps(indent=2) text
+        with gzip.GzipFile(p2, 'w', 1) as f:
+            f.write(json.dumps(g5['1'], indent=2).encode())
+        out['proto_io'] = dict(obj=to_py(g5['1']), text_sha=hashlib.md5(raw.encode()).hexdigest(),
+                               text_head=raw[:160],
+                               load_plain_eq=bool(P.proto_load(p1) == g5['1']),
+                               load_gz_pref_eq=bool(P.proto_load(os.path.join(td, 'b.det')) == g5['1']))
+
+    # score_conv_cls blob-assembly contract, pinned with a recording fake net (:19-46)
+    class Blob(object):
+        def __init__(self, c): self.shape = (1, c, 1, 1); self.data = np.zeros(self.shape, np.float32)
+        def reshape(self, *s): self.shape = tuple(s); self.data = np.zeros(s, np.float32)
+
+    class FakeNet(object):
+        def __init__(self):
+            self.blobs = {k: Blob(1) for k in ('det_scores', 'track_scores', 'anchors', 'abs_anchors',
+                                              'gt_overlaps', 'labels')}
+            self.calls = []
+        def forward(self):
+            L = self.blobs['det_scores'].shape[3]
+            self.calls.append({k: np.array(b.data).ravel().tolist() for k, b in self.blobs.items()})
+            z = self.blobs['det_scores'].data.reshape(L)
+            p1 = 1.0 / (1.0 + np.exp(-z))
+            return {'probs': np.stack([1 - p1, p1])[None].astype(np.float32)}
+    sp = P.tubelets_overlap(copy.deepcopy(g8['dets_c1_0.7']['tubelets']), annot, 1)
+    spr = dict(g8['dets_c1_0.7'], tubelets=sp)
+    net = FakeNet()
+    with contextlib.redirect_stdout(io.StringIO()):
+        res = T.score_conv_cls(copy.deepcopy(spr), net)
+    out['score_conv_cls'] = to_py(dict(inp=spr, blobs=net.calls, out=res))
+
+
+def main():
+    R = load_reference()
+    npz, index = {}, {}
+    g1_nms(R, npz, index)
+    g2_vid_nms(R, npz, index)
+    g3_track_det_nms(R, npz, index)
+    g4_iou(R, npz, index)
+    g13_ties(R, npz, index)
+    np.savez_compressed(os.path.join(HERE, 'nms_golden.npz'), **npz)
+    jdump(index, 'nms_golden_index.json')
+    out = {}
+    g5_to_g12_protos(R, out)
+    with gzip.open(os.path.join(HERE, 'proto_golden.json.gz'), 'wt') as f:
+        json.dump(out, f, separators=(',', ':'), sort_keys=True)
+    for fn in sorted(os.listdir(HERE)):
+        print('%8d  %s' % (os.path.getsize(os.path.join(HERE, fn)), fn))
+
+
+if __name__ == '__main__':
+    main()

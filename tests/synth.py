@@ -1,0 +1,147 @@
+"""Deterministic synthetic inputs shared by the golden generator, the tests and bench.py.
+
+All generators use ``np.random.RandomState(seed)`` (the legacy stream is frozen across numpy
+versions) so inputs can be regenerated from seeds on the GPU box; only seeds + reference outputs
+are committed under tests/golden/.
+"""
+import numpy as np
+
+W, H = 1280, 720
+
+
+def boxes_1(rng, n, frac=False, degenerate=0):
+    """n boxes in a 1280x720 image, SURVEY appendix A recipe (x1,y1,w,h drawn in that order)."""
+    x1 = rng.uniform(0, W - 50, n)
+    y1 = rng.uniform(0, H - 50, n)
+    w = rng.uniform(10, 300, n)
+    h = rng.uniform(10, 300, n)
+    b = np.stack([x1, y1, np.minimum(x1 + w, W - 1), np.minimum(y1 + h, H - 1)], 1)
+    if not frac:
+        b = np.round(b)
+    b = b.astype(np.float32)
+    if degenerate:
+        # clustered near-duplicates: high IoU neighbourhoods (dense suppression chains)
+        k = min(degenerate, n)
+        src = rng.randint(0, n, k)
+        dst = rng.randint(0, n, k)
+        jit = rng.randint(-3, 4, (k, 4)).astype(np.float32)
+        b[dst] = b[src] + jit
+        b[:, 2] = np.maximum(b[:, 2], b[:, 0])
+        b[:, 3] = np.maximum(b[:, 3], b[:, 1])
+    return b
+
+
+def tie_free_scores(rng, n, kind="perm"):
+    """n distinct float32 scores."""
+    if kind == "perm":
+        return ((rng.permutation(n) + 0.5) / max(n, 1)).astype(np.float32)
+    s = rng.randn(n).astype(np.float32)
+    # de-duplicate by rank jitter, then verify
+    order = np.argsort(s, kind="stable")
+    s2 = s.copy()
+    for _ in range(8):
+        if len(np.unique(s2)) == n:
+            break
+        s2 = s + (np.argsort(order).astype(np.float32) * np.float32(2.0 ** -18))
+    assert len(np.unique(s2)) == n
+    return s2
+
+
+def dets5(seed, n, frac=False, degenerate=0, kind="perm"):
+    rng = np.random.RandomState(seed)
+    b = boxes_1(rng, n, frac, degenerate)
+    s = tie_free_scores(rng, n, kind)
+    return np.hstack([b, s[:, None]]).astype(np.float32)
+
+
+def dets6(seed, n, n_frames, frac=False, kind="perm"):
+    """(frame,x1,y1,x2,y2,score) rows, frames 1..n_frames assigned at random, scores distinct
+    over the whole array."""
+    rng = np.random.RandomState(seed)
+    b = boxes_1(rng, n, frac)
+    s = tie_free_scores(rng, n, kind)
+    f = rng.randint(1, n_frames + 1, n).astype(np.float32)
+    return np.hstack([f[:, None], b, s[:, None]]).astype(np.float32)
+
+
+def video(seed, F, B, C, frac=False, kind="perm"):
+    """boxes [F,B,4] f32, scores [F,B,C] f32 tie-free per (frame, class)."""
+    rng = np.random.RandomState(seed)
+    boxes = np.stack([boxes_1(rng, B, frac) for _ in range(F)], 0)
+    if kind == "perm":
+        # one argsort of uniform noise per (f, c) column = a random permutation per column
+        r = rng.rand(F, B, C)
+        ranks = np.argsort(np.argsort(r, axis=1), axis=1)
+        scores = ((ranks + 0.5) / B).astype(np.float32)
+    else:
+        scores = rng.randn(F, B, C).astype(np.float32)
+    return boxes, scores
+
+
+# ---------------------------------------------------------------------------------------------
+# protocol-dict inputs (small), built with plain python so that the golden generator (reference
+# side) and the tests (product side) start from byte-identical dicts
+# ---------------------------------------------------------------------------------------------
+import hashlib
+
+
+def _hash(video, frame, bbox):
+    return hashlib.md5('{}_{}_{}_{}_{}_{}'.format(
+        video, frame, bbox[0], bbox[1], bbox[2], bbox[3]).encode()).hexdigest()
+
+
+def make_vid_proto(name, F):
+    return {'video': name, 'root_path': '/synthetic/' + name,
+            'frames': [{'frame': i + 1, 'path': '%06d.JPEG' % i} for i in range(F)]}
+
+
+def make_box_proto(seed, name, F, B):
+    rng = np.random.RandomState(seed)
+    boxes = []
+    for f in range(1, F + 1):
+        for b in boxes_1(rng, B):
+            bb = [int(v) for v in b]
+            boxes.append({'frame': f, 'bbox': bb, 'hash': _hash(name, f, bb)})
+    return {'video': name, 'boxes': boxes}
+
+
+def make_det_proto(seed, name, F, B, class_names, kind="perm"):
+    """det_proto with one score dict per class (class_index = position, utils/protocol.py:307-320).
+    Scores are distinct over the whole video per class."""
+    rng = np.random.RandomState(seed)
+    C = len(class_names)
+    dets = []
+    # temporally coherent proposals: frame f = frame 1 drifting by (4,2) px/frame + jitter, so
+    # that stub_track_rows' drifting boxes overlap detections in neighbouring frames
+    base = boxes_1(rng, B)
+    all_boxes = []
+    for f in range(F):
+        jit = rng.randint(-2, 3, (B, 4)).astype(np.float32)
+        all_boxes.append(base + np.float32(f) * np.array([4, 2, 4, 2], np.float32) + jit)
+    cols = [tie_free_scores(rng, F * B, kind) for _ in range(C)]
+    n = 0
+    for f in range(1, F + 1):
+        for b in all_boxes[f - 1]:
+            bb = [int(v) for v in b]
+            dets.append({'frame': f, 'bbox': bb, 'hash': _hash(name, f, bb),
+                         'scores': [{'class': class_names[c], 'class_index': c,
+                                     'score': float(cols[c][n])} for c in range(C)]})
+            n += 1
+    return {'video': name, 'detections': dets}
+
+
+def stub_track_rows(n_frames, anchor_frame, bbox, span=3, drift=(4, 2), nan_at=None):
+    """Deterministic stand-in for the external MATLAB tracker (vdet/track.py:52-106): the anchor
+    box drifting linearly over [anchor-span, anchor+span], score 1/(1+|d|).  Returns
+    (rows [L,5] float64, start_frame)."""
+    start = max(1, anchor_frame - span)
+    end = min(n_frames, anchor_frame + span)
+    rows = []
+    for f in range(start, end + 1):
+        d = f - anchor_frame
+        if nan_at is not None and d == nan_at:
+            rows.append([float('nan')] * 5)
+            continue
+        rows.append([bbox[0] + drift[0] * d, bbox[1] + drift[1] * d,
+                     bbox[2] + drift[0] * d, bbox[3] + drift[1] * d, 1.0 / (1 + abs(d))])
+    return np.asarray(rows, dtype=np.float64), start
