@@ -1,0 +1,142 @@
+/*
+ * vdet_hip.h -- C-ABI of libvdet_hip.so: the MI355X (gfx950) implementation of vdetlib's
+ * per-frame scoring / tubelet post-processing hot path.
+ *
+ * This is the drop-in boundary.  The reference's only native component is the Cython module
+ * utils/cython_nms (built from utils/nms.pyx by setup.py:8-14); its three entry points are what
+ * vdet_nms_f32 / vdet_track_det_nms_f32 replace.  The remaining entry points are the array forms
+ * of the numeric cores of vdet/video_det.py, vdet/track.py, vdet/tubelet_cls.py and
+ * utils/common.py:iou, so that T-CNN style host code (vdetlib_amd/, a py3 mirror of the reference's
+ * python API) never computes on the CPU.  Reference citations are file:line in /root/reference.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++/torch types, no exceptions across the boundary.
+ *   - The caller owns every buffer.  "h_" parameters are host pointers, "d_" parameters are device
+ *     pointers on the context's GPU.  The library never frees caller memory; device scratch is
+ *     owned by the vdet_ctx.
+ *   - Every function returns VDET_OK (0) or a negative vdet_status.  vdet_last_error() gives text.
+ *   - h_* entry points are synchronous.  d_* entry points enqueue on the context's stream and
+ *     return; data-dependent failures (capacity overflow, zero union) are latched on the device
+ *     and reported by vdet_sync().
+ *   - A context is not thread-safe: one per thread / per GPU (reference is single-threaded, GIL
+ *     held throughout).  Results are deterministic (no float atomics on any result path).
+ *   - Boxes are (x1,y1,x2,y2), inclusive pixel coordinates, +1 convention (utils/nms.pyx:24,61-62).
+ *   - Sort order wherever the reference says scores.argsort()[::-1] (utils/nms.pyx:25,80 -- numpy's
+ *     default UNSTABLE sort): descending score, ties by DESCENDING original index
+ *     (= argsort(kind='stable')[::-1]); -0.0 == +0.0; NaN scores sort first.  A caller-supplied
+ *     `order` reproduces any other tie order exactly.
+ */
+#ifndef VDET_HIP_H
+#define VDET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vdet_ctx vdet_ctx;
+
+typedef enum vdet_status {
+    VDET_OK = 0,
+    VDET_EINVAL = -1,    /* bad shape / argument  (python: ValueError) */
+    VDET_ECAP = -2,      /* output capacity too small; nothing written past capacity (ValueError) */
+    VDET_EHIP = -3,      /* HIP runtime failure (RuntimeError) */
+    VDET_EDIVZERO = -4,  /* zero union where the reference raises ZeroDivisionError
+                            (Cython cdivision=False, utils/nms.pyx:64,122,180) */
+    VDET_ENOMEM = -5
+} vdet_status;
+
+/* ---- context ------------------------------------------------------------------------------- */
+
+/* device < 0: use the calling thread's current HIP device. */
+int vdet_create(vdet_ctx **out, int device);
+int vdet_destroy(vdet_ctx *ctx);
+/* Enqueue on an existing hipStream_t (e.g. torch's current stream); NULL = the context's own. */
+int vdet_set_stream(vdet_ctx *ctx, void *hip_stream);
+/* Wait for the context's stream; return (and clear) the first latched device-side failure. */
+int vdet_sync(vdet_ctx *ctx);
+const char *vdet_last_error(vdet_ctx *ctx);
+/* "vdet_hip <version> gfx950" */
+const char *vdet_version(void);
+/* Wall-clock (ms, HIP events on the context's stream) of the kernels enqueued by the most recent
+ * d_* call, by stage; used by bench.py for the roofline object.  out[8]: 0 iou_bits (K1), 1 adj_build
+ * (K2), 2 mis (K3), 3 temporal, 4 sort, 5 track round 1, 6 iou_f64, 7 other. */
+int vdet_last_timing_ms(vdet_ctx *ctx, float *out8);
+/* Number of timed launches per stage behind the sums of vdet_last_timing_ms (call it first). */
+int vdet_last_launches(vdet_ctx *ctx, int *out8);
+/* Enable (1) / disable (0) per-stage HIP-event timing (default off: events cost launches). */
+int vdet_set_timing(vdet_ctx *ctx, int enable);
+
+/* ---- utils/cython_nms replacements (host buffers, synchronous) ------------------------------- */
+
+/*
+ * nms      (utils/nms.pyx:17-68)   ncols == 5, rows (x1,y1,x2,y2,score)
+ * vid_nms  (utils/nms.pyx:71-125)  ncols == 6, rows (frame,x1,y1,x2,y2,score); detections on
+ *                                  different frames (float32 equality, :111) never suppress.
+ * h_dets: float32, n rows, row stride `ld` elements (>= ncols).  thresh is the reference's boxed
+ * python float: suppression iff (double)ovr_f32 >= thresh.  h_order: NULL, or the n indices the
+ * reference's argsort()[::-1] produced (tie reproduction).  h_keep: capacity n; receives indices
+ * in descending score order; *n_keep their count.  VDET_EDIVZERO mirrors ZeroDivisionError.
+ */
+int vdet_nms_f32(vdet_ctx *ctx, const float *h_dets, int64_t n, int64_t ld, int ncols,
+                 double thresh, const int64_t *h_order, int64_t *h_keep, int64_t *n_keep);
+
+/*
+ * track_det_nms (utils/nms.pyx:128-189): h_tracks t rows (frame,x1,y1,x2,y2) stride ldt;
+ * h_dets m rows (frame,x1,y1,x2,y2,score) stride ldd.  Round 1: a det is dropped when it overlaps
+ * (IoU >= thresh, det as the "i" box) a same-frame track; round 2: vid_nms among the survivors.
+ * h_keep (capacity m): indices into dets, descending score.
+ */
+int vdet_track_det_nms_f32(vdet_ctx *ctx, const float *h_tracks, int64_t t, int64_t ldt,
+                           const float *h_dets, int64_t m, int64_t ldd, double thresh,
+                           int64_t *h_keep, int64_t *n_keep);
+
+/* iou (utils/common.py:451-468): float64 IoU matrix out[n1,n2] of boxes1[n1,4] x boxes2[n2,4]. */
+int vdet_iou_f64(vdet_ctx *ctx, const double *h_boxes1, int64_t n1, const double *h_boxes2,
+                 int64_t n2, double *h_out);
+
+/* ---- device-resident array forms (asynchronous; see vdet_sync) ------------------------------- */
+
+#define VDET_LAYOUT_FBC 0 /* scores [F,B,C], class innermost (zs[B,C], utils/protocol.py:538) */
+#define VDET_LAYOUT_FCB 1 /* scores [F,C,B] */
+
+/*
+ * Per-(frame,class) greedy NMS over a whole video: apply_image_nms (vdet/image_det.py:117-123)
+ * for every frame and class of fast_rcnn_det_vid's per-class loop (vdet/video_det.py:89-99),
+ * == vid_nms (utils/nms.pyx:71-125) of each class decomposed per frame.
+ *   d_boxes  [F,B,4] f32    d_scores [F,B,C] or [F,C,B] f32
+ *   use_score_thresh != 0: only boxes with score > score_thresh are candidates (video_det.py:90)
+ *   d_keep_idx [F,C,cap] int32: kept box indices (0..B-1), descending score; entries >= count
+ *                               are left untouched.   d_keep_cnt [F,C] int32.
+ *   A (frame,class) with more than cap survivors latches VDET_ECAP (its count is still written).
+ * Limits: B <= 32767.
+ */
+int vdet_nms_volume(vdet_ctx *ctx, const float *d_boxes, const float *d_scores, int layout,
+                    int64_t F, int64_t B, int64_t C, double thresh, int use_score_thresh,
+                    float score_thresh, int32_t *d_keep_idx, int32_t *d_keep_cnt, int64_t cap);
+
+/*
+ * Centred sliding temporal max over series laid out [F,S] (series s = in[f*S+s]); the array form
+ * of score_proto_temporal_maxpool (vdet/tubelet_cls.py:386-414): out[f] = max(in[f-h..f+h]),
+ * out-of-range samples = pad (-1e5 in the reference, :402); NaN propagates (np.max).  window must
+ * be odd (else VDET_EINVAL, the reference's ValueError :389-390).  d_in != d_out.
+ * For a score volume [F,B,C] pass S = B*C.
+ */
+int vdet_temporal_maxpool_f32(vdet_ctx *ctx, const float *d_in, float *d_out, int64_t F, int64_t S,
+                              int window, float pad);
+
+/*
+ * Single-channel temporal convolution over [F,S] series: out[f] = bias + sum_k taps[k] *
+ * in[f+k-K/2] (out-of-range = pad), accumulated left to right in f32, no FMA contraction.
+ * Stands in for the external Caffe TCN of score_conv_cls (vdet/tubelet_cls.py:15-51), whose
+ * prototxt/weights are not part of the reference tree (parity unpinned).
+ * h_taps: K (odd, <= 31) host floats.
+ */
+int vdet_temporal_conv_f32(vdet_ctx *ctx, const float *d_in, float *d_out, int64_t F, int64_t S,
+                           const float *h_taps, int K, float bias, float pad);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VDET_HIP_H */

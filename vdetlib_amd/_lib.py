@@ -1,0 +1,122 @@
+"""ctypes binding of libvdet_hip.so (C-ABI: include/vdet_hip.h).
+
+Fails loudly: no library or no GPU -> RuntimeError.  Nothing here (or anywhere under
+vdetlib_amd/) falls back to a CPU implementation.
+"""
+import ctypes
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvdet_hip.so")
+
+VDET_OK, VDET_EINVAL, VDET_ECAP, VDET_EHIP, VDET_EDIVZERO, VDET_ENOMEM = 0, -1, -2, -3, -4, -5
+LAYOUT_FBC, LAYOUT_FCB = 0, 1
+
+# every symbol include/vdet_hip.h declares: (name, restype, argtypes)
+_i64, _f64, _f32, _vp, _ci = ctypes.c_int64, ctypes.c_double, ctypes.c_float, ctypes.c_void_p, ctypes.c_int
+SYMBOLS = {
+    "vdet_create": (_ci, [ctypes.POINTER(_vp), _ci]),
+    "vdet_destroy": (_ci, [_vp]),
+    "vdet_set_stream": (_ci, [_vp, _vp]),
+    "vdet_sync": (_ci, [_vp]),
+    "vdet_last_error": (ctypes.c_char_p, [_vp]),
+    "vdet_version": (ctypes.c_char_p, []),
+    "vdet_last_timing_ms": (_ci, [_vp, _vp]),
+    "vdet_last_launches": (_ci, [_vp, _vp]),
+    "vdet_set_timing": (_ci, [_vp, _ci]),
+    "vdet_nms_f32": (_ci, [_vp, _vp, _i64, _i64, _ci, _f64, _vp, _vp, ctypes.POINTER(_i64)]),
+    "vdet_track_det_nms_f32": (_ci, [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _f64, _vp, ctypes.POINTER(_i64)]),
+    "vdet_iou_f64": (_ci, [_vp, _vp, _i64, _vp, _i64, _vp]),
+    "vdet_nms_volume": (_ci, [_vp, _vp, _vp, _ci, _i64, _i64, _i64, _f64, _ci, _f32, _vp, _vp, _i64]),
+    "vdet_temporal_maxpool_f32": (_ci, [_vp, _vp, _vp, _i64, _i64, _ci, _f32]),
+    "vdet_temporal_conv_f32": (_ci, [_vp, _vp, _vp, _i64, _i64, _vp, _ci, _f32, _f32]),
+}
+
+_lib = None
+_lock = threading.Lock()
+_ctxs = {}
+
+
+def load_library():
+    """dlopen libvdet_hip.so and declare the prototypes (no GPU needed for this step)."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise RuntimeError(
+                "libvdet_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or vdetlib_amd/csrc/build.sh. There is no CPU fallback." % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)     # AttributeError if the .so does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+class Context(object):
+    """One vdet_ctx (one GPU, one stream). Not thread-safe, like the reference (GIL held)."""
+
+    def __init__(self, device=-1):
+        self.lib = load_library()
+        h = _vp()
+        rc = self.lib.vdet_create(ctypes.byref(h), int(device))
+        if rc != VDET_OK or not h.value:
+            raise RuntimeError("vdet_create failed (rc=%d): no usable MI355X/HIP device. "
+                               "vdetlib_amd has no CPU fallback." % rc)
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h.value:
+            self.lib.vdet_destroy(self.h)
+            self.h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def error(self):
+        m = self.lib.vdet_last_error(self.h)
+        return m.decode() if m else ""
+
+    def check(self, rc):
+        if rc == VDET_OK:
+            return
+        msg = self.error()
+        if rc == VDET_EDIVZERO:
+            raise ZeroDivisionError("float division")
+        if rc in (VDET_EINVAL, VDET_ECAP):
+            raise ValueError(msg or "invalid argument")
+        if rc == VDET_ENOMEM:
+            raise MemoryError(msg)
+        raise RuntimeError("libvdet_hip: %s (rc=%d)" % (msg, rc))
+
+    def set_stream(self, stream_ptr):
+        self.check(self.lib.vdet_set_stream(self.h, _vp(stream_ptr or 0)))
+
+    def sync(self):
+        self.check(self.lib.vdet_sync(self.h))
+
+    def set_timing(self, on):
+        self.check(self.lib.vdet_set_timing(self.h, 1 if on else 0))
+
+    def last_timing(self):
+        ms = (ctypes.c_float * 8)()
+        n = (ctypes.c_int * 8)()
+        self.check(self.lib.vdet_last_timing_ms(self.h, ms))
+        self.check(self.lib.vdet_last_launches(self.h, n))
+        names = ["iou_bits", "adj_build", "mis", "temporal", "sort", "track_round1", "iou_f64", "other"]
+        return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(names)}
+
+
+def get_context(device=-1):
+    """Process-wide context per device (created on first use)."""
+    with _lock:
+        c = _ctxs.get(device)
+        if c is None:
+            c = Context(device)
+            _ctxs[device] = c
+        return c

@@ -1,0 +1,146 @@
+// temporal_kernels.hpp -- gfx950 kernels for the temporal passes over [F, S] series
+// (S = B*C for a score volume [F,B,C], S = #tubelets for tubelet score tracks) and the float64
+// IoU matrix.  Reference: vdet/tubelet_cls.py:386-414 (score_proto_temporal_maxpool),
+// vdet/tubelet_cls.py:15-51 (score_conv_cls; external net -> build-defined op),
+// utils/common.py:451-468 (iou).
+//
+// HBM-bound streaming kernels: one thread owns 4 adjacent series (16-B loads/stores, fully
+// coalesced along S) and walks the frames with the window held in registers, so every input
+// element is read from HBM exactly once and every output written once (8 B per element).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vdet {
+
+struct Taps { float w[32]; };
+
+__device__ __forceinline__ float4 splat4(float v) { return make_float4(v, v, v, v); }
+
+// np.max semantics: NaN propagates (v_max_f32 alone would drop it)
+struct MaxAcc {
+    float4 m; uint32_t nan;
+    __device__ __forceinline__ void init(float4 v)
+    {
+        m = v;
+        nan = (v.x != v.x) | ((v.y != v.y) << 1) | ((v.z != v.z) << 2) | ((v.w != v.w) << 3);
+    }
+    __device__ __forceinline__ void add(float4 v)
+    {
+        m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+        nan |= (v.x != v.x) | ((v.y != v.y) << 1) | ((v.z != v.z) << 2) | ((v.w != v.w) << 3);
+    }
+    __device__ __forceinline__ float4 get() const
+    {
+        const float q = __uint_as_float(0x7FC00000u);
+        return make_float4((nan & 1) ? q : m.x, (nan & 2) ? q : m.y, (nan & 4) ? q : m.z, (nan & 8) ? q : m.w);
+    }
+};
+
+// MODE 0: max-pool, MODE 1: convolution.  W = window (odd).  Each block covers 256*4 series and
+// the frame range [blockIdx.y*fchunk, ...) with a W/2 halo re-read at chunk borders.
+template <int W, int MODE>
+__global__ __launch_bounds__(256) void temporal_vec4_kernel(const float4 *__restrict__ in, float4 *__restrict__ out,
+                                                            int64_t F, int64_t S4, int64_t fchunk, float pad,
+                                                            float bias, Taps taps)
+{
+    constexpr int H = W / 2;
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= S4) return;
+    const int64_t f0 = (int64_t)blockIdx.y * fchunk;
+    const int64_t f1 = min(F, f0 + fchunk);
+    if (f0 >= f1) return;
+    const float4 padv = splat4(pad);
+    float4 win[W];   // win[k] = in[f - H + k]
+#pragma unroll
+    for (int k = 0; k < W - 1; ++k) {
+        const int64_t g = f0 - H + k;
+        win[k + 1] = (g >= 0 && g < F) ? in[g * S4 + s] : padv;
+    }
+    for (int64_t f = f0; f < f1; ++f) {
+#pragma unroll
+        for (int k = 0; k < W - 1; ++k) win[k] = win[k + 1];
+        const int64_t g = f + H;
+        win[W - 1] = (g < F) ? in[g * S4 + s] : padv;
+        float4 r;
+        if (MODE == 0) {
+            MaxAcc a;
+            a.init(win[0]);
+#pragma unroll
+            for (int k = 1; k < W; ++k) a.add(win[k]);
+            r = a.get();
+        } else {
+            r = splat4(bias);
+#pragma unroll
+            for (int k = 0; k < W; ++k) {
+                const float t = taps.w[k];
+                r.x = r.x + t * win[k].x; r.y = r.y + t * win[k].y;
+                r.z = r.z + t * win[k].z; r.w = r.w + t * win[k].w;
+            }
+        }
+        out[f * S4 + s] = r;
+    }
+}
+
+// Generic fallback: any odd window, any S (no alignment requirement); one thread per element.
+template <int MODE>
+__global__ __launch_bounds__(256) void temporal_scalar_kernel(const float *__restrict__ in, float *__restrict__ out,
+                                                              int64_t F, int64_t S, int W, float pad, float bias,
+                                                              Taps taps)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= F * S) return;
+    const int64_t f = i / S, s = i - f * S;
+    const int H = W / 2;
+    if (MODE == 0) {
+        float m = 0.0f;
+        bool nan = false;
+        for (int k = 0; k < W; ++k) {
+            const int64_t g = f + k - H;
+            const float v = (g >= 0 && g < F) ? in[g * S + s] : pad;
+            nan |= (v != v);
+            m = (k == 0) ? v : fmaxf(m, v);
+        }
+        out[i] = nan ? __uint_as_float(0x7FC00000u) : m;
+    } else {
+        float acc = bias;
+        for (int k = 0; k < W; ++k) {
+            const int64_t g = f + k - H;
+            const float v = (g >= 0 && g < F) ? in[g * S + s] : pad;
+            acc = acc + taps.w[k] * v;
+        }
+        out[i] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// utils/common.py:451-468  iou(boxes1, boxes2) -> [n1, n2] float64
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double np_maximum(double a, double b) { return (a != a || b != b) ? (a + b) : (a > b ? a : b); }
+__device__ __forceinline__ double np_minimum(double a, double b) { return (a != a || b != b) ? (a + b) : (a < b ? a : b); }
+
+__device__ __forceinline__ double iou_f64_pair(const double *p, const double *q)
+{
+    const double ix1 = np_maximum(p[0], q[0]);
+    const double ix2 = np_minimum(p[2], q[2]);
+    const double iy1 = np_maximum(p[1], q[1]);
+    const double iy2 = np_minimum(p[3], q[3]);
+    const double iw = np_maximum(0.0, (ix2 - ix1) + 1.0);
+    const double ih = np_maximum(0.0, (iy2 - iy1) + 1.0);
+    const double a1 = ((p[2] - p[0]) + 1.0) * ((p[3] - p[1]) + 1.0);
+    const double a2 = ((q[2] - q[0]) + 1.0) * ((q[3] - q[1]) + 1.0);
+    const double inter = iw * ih;
+    return inter / ((a1 + a2) - inter);
+}
+
+__global__ __launch_bounds__(256) void iou_f64_kernel(const double *__restrict__ b1, int64_t n1,
+                                                      const double *__restrict__ b2, int64_t n2,
+                                                      double *__restrict__ out)
+{
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n2) return;
+    for (int64_t i = blockIdx.y; i < n1; i += gridDim.y)
+        out[i * n2 + j] = iou_f64_pair(b1 + 4 * i, b2 + 4 * j);
+}
+
+}  // namespace vdet

@@ -1,0 +1,798 @@
+// vdet_capi.hip -- C-ABI of libvdet_hip.so (see include/vdet_hip.h) and the host-side
+// orchestration of the gfx950 kernels.  Built with
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared
+// (-ffp-contract=off is load-bearing: the f32 operation order of the IoU predicate is the spec).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/vdet_hip.h"
+#include "nms_kernels.hpp"
+#include "temporal_kernels.hpp"
+
+using namespace vdet;
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 4 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {  // retry exact
+            want = bytes;
+            e = hipMalloc(&p, want);
+        }
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <typename T> T *as() { return static_cast<T *>(p); }
+};
+
+enum Stage { ST_IOU_BITS = 0, ST_ADJ = 1, ST_MIS = 2, ST_TEMPORAL = 3, ST_SORT = 4, ST_ROUND1 = 5, ST_IOU64 = 6, ST_OTHER = 7 };
+
+struct Counters {            // one small device block
+    int status;
+    unsigned int glob_cnt;
+    unsigned long long pool_used;
+};
+
+}  // namespace
+
+struct vdet_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipStream_t own_stream = nullptr;
+    std::string err;
+    Counters *d_cnt = nullptr;
+    int latched = 0;              // first failure latched by async entry points
+    size_t bits_budget = (size_t)1 << 30;
+    size_t max_lds = 160 * 1024;
+    int n_cu = 256;
+    // scratch
+    DevBuf boxes, scores, keys, excl, frames, groups, tiles, bits, rowz, rowoff, rowdeg, groupz, adj, comp, origidx,
+        out64, trk_frames, trk_boxes, b1, b2, iou_out;
+    // timing
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    std::vector<int> ev_stage;
+    size_t ev_used = 0;
+    float last_ms[8] = {0};
+    int last_launches[8] = {0};
+    bool mis_attr_set = false;
+};
+
+namespace {
+
+int fail(vdet_ctx *c, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    return code;
+}
+
+#define HIPCHK(c, expr)                                                                          \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess)                                                                    \
+            return fail((c), VDET_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+struct StageTimer {
+    vdet_ctx *c;
+    size_t slot = (size_t)-1;
+    StageTimer(vdet_ctx *ctx, int stage) : c(ctx)
+    {
+        if (!c->timing) return;
+        if (c->ev_used == c->ev_pool.size()) {
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+            c->ev_pool.push_back({a, b});
+            c->ev_stage.push_back(0);
+        }
+        slot = c->ev_used++;
+        c->ev_stage[slot] = stage;
+        (void)hipEventRecord(c->ev_pool[slot].first, c->stream);
+    }
+    ~StageTimer()
+    {
+        if (slot != (size_t)-1) (void)hipEventRecord(c->ev_pool[slot].second, c->stream);
+    }
+};
+
+void timing_reset(vdet_ctx *c) { c->ev_used = 0; }
+
+// smallest float32 f with (double)f >= thresh: "(double)ovr_f32 >= thresh" <=> "ovr_f32 >= f"
+float thresh_to_f32(double thresh)
+{
+    if (thresh != thresh) return NAN;
+    float f = (float)thresh;  // round to nearest
+    if ((double)f < thresh) f = nextafterf(f, INFINITY);
+    return f;
+}
+
+uint32_t pow2ceil(uint32_t x)
+{
+    uint32_t p = 1;
+    while (p < x) p <<= 1;
+    return p;
+}
+
+int translate_status(vdet_ctx *c, int st)
+{
+    if (st & kStDivZero) return fail(c, VDET_EDIVZERO, "float division (zero union)");
+    if (st & kStCap) return fail(c, VDET_ECAP, "more survivors than the output capacity");
+    if (st & kStPool) return fail(c, VDET_EHIP, "internal: adjacency pool overflow");
+    return VDET_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// NMS orchestration
+// ---------------------------------------------------------------------------------------------
+struct NmsPlan {
+    std::vector<GroupDesc> groups;   // bits_off is batch-local
+    std::vector<TileDesc> tiles;     // ordered by batch
+    std::vector<std::pair<int, int>> batch_tiles;  // [t0, t1) per batch
+    size_t bits_words_max = 0;       // largest batch
+    int64_t ntot = 0;
+    int nmax = 0;
+};
+
+int make_plan(vdet_ctx *c, NmsPlan &pl)
+{
+    const size_t budget_words = std::max<size_t>(c->bits_budget / 8, 1);
+    size_t cur = 0;
+    int t0 = 0;
+    pl.nmax = 0;
+    pl.ntot = 0;
+    for (size_t g = 0; g < pl.groups.size(); ++g) {
+        GroupDesc &gd = pl.groups[g];
+        pl.ntot = std::max<int64_t>(pl.ntot, (int64_t)gd.box_off + gd.nbox);
+        pl.nmax = std::max(pl.nmax, gd.nbox);
+        if (gd.nbox < 2) { gd.bits_off = 0; continue; }       // singletons: no graph
+        const size_t words = (size_t)((gd.nbox + 63) / 64) * gd.nbox;
+        if (cur && cur + words > budget_words) {
+            pl.batch_tiles.push_back({t0, (int)pl.tiles.size()});
+            t0 = (int)pl.tiles.size();
+            pl.bits_words_max = std::max(pl.bits_words_max, cur);
+            cur = 0;
+        }
+        gd.bits_off = (int64_t)cur;
+        cur += words;
+        for (int rt = 0; rt * kRowsPerTile < gd.nbox; ++rt) pl.tiles.push_back({(int32_t)g, rt});
+    }
+    if ((int)pl.tiles.size() > t0) pl.batch_tiles.push_back({t0, (int)pl.tiles.size()});
+    pl.bits_words_max = std::max(pl.bits_words_max, cur);
+    (void)c;
+    return VDET_OK;
+}
+
+// K1 + K2 for every batch; retries once with a larger adjacency pool.  Synchronizes the stream.
+int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32)
+{
+    const size_t G = pl.groups.size();
+    HIPCHK(c, c->groups.reserve(G * sizeof(GroupDesc)));
+    HIPCHK(c, c->tiles.reserve(std::max<size_t>(pl.tiles.size(), 1) * sizeof(TileDesc)));
+    HIPCHK(c, c->bits.reserve(std::max<size_t>(pl.bits_words_max, 1) * 8));
+    HIPCHK(c, c->rowz.reserve((size_t)pl.ntot * 4));
+    HIPCHK(c, c->rowoff.reserve((size_t)pl.ntot * 4));
+    HIPCHK(c, c->rowdeg.reserve((size_t)pl.ntot * 2));
+    HIPCHK(c, c->groupz.reserve(G * 4));
+    HIPCHK(c, hipMemcpyAsync(c->groups.p, pl.groups.data(), G * sizeof(GroupDesc), hipMemcpyHostToDevice, c->stream));
+    if (!pl.tiles.empty())
+        HIPCHK(c, hipMemcpyAsync(c->tiles.p, pl.tiles.data(), pl.tiles.size() * sizeof(TileDesc),
+                                 hipMemcpyHostToDevice, c->stream));
+    // the host vectors must outlive the async copies; also pick up a failure latched by an earlier
+    // asynchronous call before the status word is cleared below
+    {
+        Counters h0;
+        HIPCHK(c, hipMemcpyAsync(&h0, c->d_cnt, sizeof h0, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (h0.status && !c->latched) c->latched = translate_status(c, h0.status);
+    }
+    if (c->adj.cap < (size_t)pl.ntot * 32 * 2) HIPCHK(c, c->adj.reserve((size_t)pl.ntot * 32 * 2 + 4096));
+
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        HIPCHK(c, hipMemsetAsync(c->rowz.p, 0, (size_t)pl.ntot * 4, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->rowoff.p, 0, (size_t)pl.ntot * 4, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->rowdeg.p, 0, (size_t)pl.ntot * 2, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->groupz.p, 0, G * 4, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_cnt, 0, sizeof(Counters), c->stream));
+        const unsigned long long pool_cap = c->adj.cap / 2;
+        for (auto bt : pl.batch_tiles) {
+            const int nt = bt.second - bt.first;
+            if (nt <= 0) continue;
+            // enough column splits to fill the chip when there are few row tiles
+            int splits = 1;
+            if (nt < 4 * c->n_cu) {
+                int wmax = 1;
+                for (int t = bt.first; t < bt.second; ++t)
+                    wmax = std::max(wmax, (pl.groups[pl.tiles[t].group].nbox + 63) / 64);
+                splits = std::min((4 * c->n_cu + nt - 1) / nt, (wmax + 3) / 4);
+                splits = std::max(1, std::min(splits, 65535));
+            }
+            {
+                StageTimer tm(c, ST_IOU_BITS);
+                hipLaunchKernelGGL(iou_bits_kernel, dim3(nt, splits), dim3(256), 0, c->stream, d_boxes,
+                                   c->groups.as<GroupDesc>(), c->tiles.as<TileDesc>() + bt.first, t32,
+                                   c->bits.as<uint64_t>(), c->rowz.as<uint32_t>(), c->groupz.as<uint32_t>());
+            }
+            {
+                StageTimer tm(c, ST_ADJ);
+                hipLaunchKernelGGL(adj_build_kernel, dim3(nt), dim3(256), 0, c->stream, d_boxes,
+                                   c->groups.as<GroupDesc>(), c->tiles.as<TileDesc>() + bt.first,
+                                   c->bits.as<uint64_t>(), c->rowz.as<uint32_t>(), c->rowoff.as<uint32_t>(),
+                                   c->rowdeg.as<uint16_t>(), c->adj.as<uint16_t>(), &c->d_cnt->pool_used, pool_cap,
+                                   &c->d_cnt->status);
+            }
+        }
+        HIPCHK(c, hipGetLastError());
+        Counters h;
+        HIPCHK(c, hipMemcpyAsync(&h, c->d_cnt, sizeof h, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (!(h.status & kStPool)) return VDET_OK;
+        if (h.pool_used > 0xFFFFFFFFull) return fail(c, VDET_ENOMEM, "suppression graph has more than 2^32 edges");
+        if (attempt == 1) break;
+        HIPCHK(c, c->adj.reserve((size_t)h.pool_used * 2 + 4096));
+    }
+    return fail(c, VDET_EHIP, "internal: adjacency pool overflow after regrow");
+}
+
+size_t mis_lds_bytes(int nmax, int64_t cap, bool sorted, int block, MisParams &prm)
+{
+    auto r16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    const size_t keysB = r16((size_t)4 * nmax);
+    const size_t stateB = r16((size_t)nmax);
+    size_t curB = (size_t)2 * nmax;
+    if (sorted) {
+        const uint32_t sc = pow2ceil((uint32_t)std::min<int64_t>(cap, nmax));
+        curB = std::max<size_t>(curB, (size_t)8 * sc);
+    }
+    curB = r16(curB);
+    prm.lds_state_off = (int)keysB;
+    prm.lds_cursor_off = (int)(keysB + stateB);
+    prm.lds_scan_off = (int)(keysB + stateB + curB);
+    return keysB + stateB + curB + (size_t)4 * block;
+}
+
+int launch_mis(vdet_ctx *c, MisParams prm, int nmax, bool sorted)
+{
+    if (prm.P <= 0) return VDET_OK;
+    const int block = nmax > 2048 ? 1024 : 256;
+    const size_t lds = mis_lds_bytes(std::max(nmax, 1), prm.cap, sorted, block, prm);
+    if (lds > c->max_lds)
+        return fail(c, VDET_EINVAL,
+                    "a frame with %d boxes (survivor capacity %lld) needs %zu B of LDS; the limit is %zu B "
+                    "(about 23000 boxes per frame, fewer with a large capacity)",
+                    nmax, (long long)prm.cap, lds, c->max_lds);
+    if (!c->mis_attr_set) {
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(mis_kernel<1024>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->max_lds));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(mis_kernel<256>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->max_lds));
+        c->mis_attr_set = true;
+    }
+    const int grid = (prm.P + 7) & ~7;
+    StageTimer tm(c, ST_MIS);
+    if (block == 1024) hipLaunchKernelGGL(mis_kernel<1024>, dim3(grid), dim3(1024), lds, c->stream, prm);
+    else hipLaunchKernelGGL(mis_kernel<256>, dim3(grid), dim3(256), lds, c->stream, prm);
+    HIPCHK(c, hipGetLastError());
+    return VDET_OK;
+}
+
+// descending sort of n composites held in c->comp (zero padded to a power of two)
+int sort_comp_desc(vdet_ctx *c, uint32_t n)
+{
+    if (n <= 1) return VDET_OK;
+    const uint32_t n2 = pow2ceil(n);
+    unsigned long long *d = c->comp.as<unsigned long long>();
+    StageTimer tm(c, ST_SORT);
+    const uint32_t nb = (n2 + 2047) / 2048;
+    hipLaunchKernelGGL(bitonic_lds_kernel, dim3(nb), dim3(1024), 0, c->stream, d, n2, 2u, std::min(n2, 2048u));
+    for (uint32_t k = 4096; k <= n2 && k; k <<= 1) {
+        for (uint32_t j = k >> 1; j >= 2048; j >>= 1)
+            hipLaunchKernelGGL(bitonic_global_step, dim3((n2 + 255) / 256), dim3(256), 0, c->stream, d, n2, j, k);
+        hipLaunchKernelGGL(bitonic_lds_kernel, dim3(nb), dim3(1024), 0, c->stream, d, n2, k, k);
+    }
+    HIPCHK(c, hipGetLastError());
+    return VDET_OK;
+}
+
+// Shared tail of nms / vid_nms / track_det_nms on grouped, uploaded data:
+//   graph -> MIS (append) -> global sort -> indices.
+int nms_grouped_host(vdet_ctx *c, NmsPlan &pl, float t32, const float *d_scores, const uint32_t *d_keys,
+                     const uint8_t *d_excl, int64_t *h_keep, int64_t *n_keep)
+{
+    int rc = build_graph(c, c->boxes.as<float4>(), pl, t32);
+    if (rc) return rc;
+    const uint32_t n2 = pow2ceil((uint32_t)std::max<int64_t>(pl.ntot, 1));
+    HIPCHK(c, c->comp.reserve((size_t)n2 * 8));
+    HIPCHK(c, hipMemsetAsync(c->comp.p, 0, (size_t)n2 * 8, c->stream));
+    MisParams prm{};
+    prm.mode = 2;
+    prm.P = (int)pl.groups.size();
+    prm.scores = d_scores;
+    prm.keys = d_keys;
+    prm.excl = d_excl;
+    prm.groups = c->groups.as<GroupDesc>();
+    prm.row_off = c->rowoff.as<uint32_t>();
+    prm.row_deg = c->rowdeg.as<uint16_t>();
+    prm.adj = c->adj.as<uint16_t>();
+    prm.group_z = c->groupz.as<uint32_t>();
+    prm.cap = 0;
+    prm.glob_comp = c->comp.as<unsigned long long>();
+    prm.glob_cnt = &c->d_cnt->glob_cnt;
+    prm.orig_idx = c->origidx.as<uint32_t>();
+    prm.status = &c->d_cnt->status;
+    rc = launch_mis(c, prm, pl.nmax, false);
+    if (rc) return rc;
+    Counters h;
+    HIPCHK(c, hipMemcpyAsync(&h, c->d_cnt, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    rc = translate_status(c, h.status);
+    if (rc) return rc;
+    const uint32_t nk = h.glob_cnt;
+    rc = sort_comp_desc(c, nk);
+    if (rc) return rc;
+    if (nk) {
+        HIPCHK(c, c->out64.reserve((size_t)nk * 8));
+        hipLaunchKernelGGL(comp_to_index_kernel, dim3((nk + 255) / 256), dim3(256), 0, c->stream,
+                           c->comp.as<unsigned long long>(), nk, c->out64.as<int64_t>());
+        HIPCHK(c, hipMemcpyAsync(h_keep, c->out64.p, (size_t)nk * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    *n_keep = nk;
+    return VDET_OK;
+}
+
+// Group rows by frame value with float32 equality semantics (utils/nms.pyx:111: f_idx[i] != f_idx[j]):
+// -0.0 == +0.0; a NaN frame equals nothing, not even itself (singleton groups).
+// perm = original indices in grouped order.
+int group_by_frame(vdet_ctx *c, const float *frames, int64_t n, int64_t ld, std::vector<int64_t> &perm,
+                   std::vector<GroupDesc> &groups)
+{
+    perm.resize((size_t)n);
+    for (int64_t i = 0; i < n; ++i) perm[(size_t)i] = i;
+    auto key = [&](int64_t i) { return frames[i * ld] + 0.0f; };
+    std::stable_sort(perm.begin(), perm.end(), [&](int64_t a, int64_t b) {
+        const float fa = key(a), fb = key(b);
+        const bool na = fa != fa, nb = fb != fb;
+        if (na || nb) return !na && nb;   // NaNs last
+        return fa < fb;
+    });
+    groups.clear();
+    int64_t s = 0;
+    while (s < n) {
+        const float f = key(perm[(size_t)s]);
+        int64_t e = s + 1;
+        if (f == f)
+            while (e < n && key(perm[(size_t)e]) == f) ++e;
+        if (e - s > 32767)
+            return fail(c, VDET_EINVAL, "%lld detections on one frame; the limit is 32767", (long long)(e - s));
+        groups.push_back({(int32_t)s, (int32_t)(e - s), 0});
+        s = e;
+    }
+    return VDET_OK;
+}
+
+}  // namespace
+
+// =============================================================================================
+// C-ABI
+// =============================================================================================
+extern "C" {
+
+const char *vdet_version(void) { return "vdet_hip 0.1 gfx950"; }
+
+int vdet_create(vdet_ctx **out, int device)
+{
+    if (!out) return VDET_EINVAL;
+    *out = nullptr;
+    vdet_ctx *c = new (std::nothrow) vdet_ctx;
+    if (!c) return VDET_ENOMEM;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        delete c;
+        return VDET_EHIP;   // fail loudly: there is NO CPU fallback in this library
+    }
+    if (device < 0) {
+        if (hipGetDevice(&device) != hipSuccess) { delete c; return VDET_EHIP; }
+    }
+    if (device >= ndev || hipSetDevice(device) != hipSuccess) { delete c; return VDET_EINVAL; }
+    c->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+        c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        // gfx950: one workgroup may own the CU's whole 160 KiB LDS (opt-in via hipFuncSetAttribute)
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) c->max_lds = 64 * 1024;
+    }
+    if (const char *e = getenv("VDET_BITS_BUDGET_MB")) {
+        const long mb = atol(e);
+        if (mb > 0) c->bits_budget = (size_t)mb << 20;
+    }
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc((void **)&c->d_cnt, sizeof(Counters)) != hipSuccess) {
+        delete c;
+        return VDET_EHIP;
+    }
+    c->stream = c->own_stream;
+    (void)hipMemsetAsync(c->d_cnt, 0, sizeof(Counters), c->stream);
+    *out = c;
+    return VDET_OK;
+}
+
+int vdet_destroy(vdet_ctx *c)
+{
+    if (!c) return VDET_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    DevBuf *bufs[] = {&c->boxes, &c->scores, &c->keys, &c->excl, &c->frames, &c->groups, &c->tiles, &c->bits,
+                      &c->rowz, &c->rowoff, &c->rowdeg, &c->groupz, &c->adj, &c->comp, &c->origidx, &c->out64,
+                      &c->trk_frames, &c->trk_boxes, &c->b1, &c->b2, &c->iou_out};
+    for (DevBuf *b : bufs) b->release();
+    for (auto &e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    if (c->d_cnt) (void)hipFree(c->d_cnt);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return VDET_OK;
+}
+
+int vdet_set_stream(vdet_ctx *c, void *s)
+{
+    if (!c) return VDET_EINVAL;
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return VDET_OK;
+}
+
+const char *vdet_last_error(vdet_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+int vdet_set_timing(vdet_ctx *c, int enable)
+{
+    if (!c) return VDET_EINVAL;
+    c->timing = enable != 0;
+    return VDET_OK;
+}
+
+int vdet_last_timing_ms(vdet_ctx *c, float *out8)
+{
+    if (!c || !out8) return VDET_EINVAL;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 8; ++i) { c->last_ms[i] = 0; c->last_launches[i] = 0; }
+    for (size_t i = 0; i < c->ev_used; ++i) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, c->ev_pool[i].first, c->ev_pool[i].second) == hipSuccess) {
+            c->last_ms[c->ev_stage[i]] += ms;
+            c->last_launches[c->ev_stage[i]] += 1;
+        }
+    }
+    for (int i = 0; i < 8; ++i) out8[i] = c->last_ms[i];
+    return VDET_OK;
+}
+
+int vdet_last_launches(vdet_ctx *c, int *out8)
+{
+    if (!c || !out8) return VDET_EINVAL;
+    for (int i = 0; i < 8; ++i) out8[i] = c->last_launches[i];
+    return VDET_OK;
+}
+
+int vdet_sync(vdet_ctx *c)
+{
+    if (!c) return VDET_EINVAL;
+    Counters h;
+    HIPCHK(c, hipMemcpyAsync(&h, c->d_cnt, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemsetAsync(&c->d_cnt->status, 0, sizeof(int), c->stream));
+    const int l = c->latched;
+    c->latched = 0;
+    if (l) return l;
+    return translate_status(c, h.status);
+}
+
+// ---------------------------------------------------------------------------------------------
+int vdet_nms_f32(vdet_ctx *c, const float *h_dets, int64_t n, int64_t ld, int ncols, double thresh,
+                 const int64_t *h_order, int64_t *h_keep, int64_t *n_keep)
+{
+    if (!c || !n_keep) return VDET_EINVAL;
+    *n_keep = 0;
+    if (n < 0 || (ncols != 5 && ncols != 6) || (n > 0 && (!h_dets || !h_keep || ld < ncols)))
+        return fail(c, VDET_EINVAL, "dets must be float32 [n,%d]", ncols);
+    if (n == 0) return VDET_OK;
+    if (n > 0x7FFFFFFF) return fail(c, VDET_EINVAL, "too many detections");
+    HIPCHK(c, hipSetDevice(c->device));
+    timing_reset(c);
+    const int o = ncols == 6 ? 1 : 0;
+
+    NmsPlan pl;
+    std::vector<int64_t> perm;
+    if (o) {
+        int rc = group_by_frame(c, h_dets, n, ld, perm, pl.groups);
+        if (rc) return rc;
+    } else {
+        if (n > 32767) return fail(c, VDET_EINVAL, "%lld boxes in one image; the limit is 32767", (long long)n);
+        perm.resize((size_t)n);
+        for (int64_t i = 0; i < n; ++i) perm[(size_t)i] = i;
+        pl.groups.push_back({0, (int32_t)n, 0});
+    }
+    make_plan(c, pl);
+
+    std::vector<float> hb((size_t)n * 4), hs((size_t)n);
+    std::vector<uint32_t> hidx((size_t)n), hkeys;
+    for (int64_t r = 0; r < n; ++r) {
+        const float *row = h_dets + perm[(size_t)r] * ld + o;
+        memcpy(&hb[(size_t)r * 4], row, 16);
+        hs[(size_t)r] = row[4];
+        hidx[(size_t)r] = (uint32_t)perm[(size_t)r];
+    }
+    if (h_order) {   // caller-supplied order: priority = position (earlier = higher)
+        std::vector<uint32_t> rank((size_t)n, 0);
+        for (int64_t pos = 0; pos < n; ++pos) {
+            const int64_t i = h_order[pos];
+            if (i < 0 || i >= n || rank[(size_t)i]) return fail(c, VDET_EINVAL, "order is not a permutation of 0..n-1");
+            rank[(size_t)i] = (uint32_t)(n - pos);
+        }
+        hkeys.resize((size_t)n);
+        for (int64_t r = 0; r < n; ++r) hkeys[(size_t)r] = rank[(size_t)perm[(size_t)r]];
+    }
+    HIPCHK(c, c->boxes.reserve((size_t)n * 16));
+    HIPCHK(c, c->scores.reserve((size_t)n * 4));
+    HIPCHK(c, c->origidx.reserve((size_t)n * 4));
+    HIPCHK(c, hipMemcpyAsync(c->boxes.p, hb.data(), (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->scores.p, hs.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->origidx.p, hidx.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    const uint32_t *d_keys = nullptr;
+    if (h_order) {
+        HIPCHK(c, c->keys.reserve((size_t)n * 4));
+        HIPCHK(c, hipMemcpyAsync(c->keys.p, hkeys.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+        d_keys = c->keys.as<uint32_t>();
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return nms_grouped_host(c, pl, thresh_to_f32(thresh), c->scores.as<float>(), d_keys, nullptr, h_keep, n_keep);
+}
+
+int vdet_track_det_nms_f32(vdet_ctx *c, const float *h_tracks, int64_t t, int64_t ldt, const float *h_dets,
+                           int64_t m, int64_t ldd, double thresh, int64_t *h_keep, int64_t *n_keep)
+{
+    if (!c || !n_keep) return VDET_EINVAL;
+    *n_keep = 0;
+    if (t < 0 || m < 0 || (t > 0 && (!h_tracks || ldt < 5)) || (m > 0 && (!h_dets || !h_keep || ldd < 6)))
+        return fail(c, VDET_EINVAL, "tracks must be float32 [t,5], dets float32 [m,6]");
+    if (m == 0) return VDET_OK;
+    if (m > 0x7FFFFFFF || t > 0x7FFFFFFF) return fail(c, VDET_EINVAL, "too many rows");
+    HIPCHK(c, hipSetDevice(c->device));
+    timing_reset(c);
+    NmsPlan pl;
+    std::vector<int64_t> perm;
+    int rc = group_by_frame(c, h_dets, m, ldd, perm, pl.groups);
+    if (rc) return rc;
+    make_plan(c, pl);
+    std::vector<float> hb((size_t)m * 4), hs((size_t)m), hf((size_t)m);
+    std::vector<uint32_t> hidx((size_t)m);
+    for (int64_t r = 0; r < m; ++r) {
+        const float *row = h_dets + perm[(size_t)r] * ldd;
+        hf[(size_t)r] = row[0];
+        memcpy(&hb[(size_t)r * 4], row + 1, 16);
+        hs[(size_t)r] = row[5];
+        hidx[(size_t)r] = (uint32_t)perm[(size_t)r];
+    }
+    std::vector<float> tb((size_t)std::max<int64_t>(t, 1) * 4), tf((size_t)std::max<int64_t>(t, 1));
+    for (int64_t j = 0; j < t; ++j) {
+        tf[(size_t)j] = h_tracks[j * ldt];
+        memcpy(&tb[(size_t)j * 4], h_tracks + j * ldt + 1, 16);
+    }
+    const float t32 = thresh_to_f32(thresh);
+    HIPCHK(c, c->boxes.reserve((size_t)m * 16));
+    HIPCHK(c, c->scores.reserve((size_t)m * 4));
+    HIPCHK(c, c->frames.reserve((size_t)m * 4));
+    HIPCHK(c, c->origidx.reserve((size_t)m * 4));
+    HIPCHK(c, c->excl.reserve((size_t)m));
+    HIPCHK(c, c->trk_boxes.reserve(tb.size() * 4));
+    HIPCHK(c, c->trk_frames.reserve(tf.size() * 4));
+    HIPCHK(c, hipMemcpyAsync(c->boxes.p, hb.data(), (size_t)m * 16, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->scores.p, hs.data(), (size_t)m * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->frames.p, hf.data(), (size_t)m * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->origidx.p, hidx.data(), (size_t)m * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->trk_boxes.p, tb.data(), tb.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->trk_frames.p, tf.data(), tf.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // build_graph clears the status word, so round 1 runs after it (inside the same stream order):
+    rc = build_graph(c, c->boxes.as<float4>(), pl, t32);
+    if (rc) return rc;
+    {
+        StageTimer tm(c, ST_ROUND1);
+        hipLaunchKernelGGL(track_round1_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream,
+                           c->frames.as<float>(), c->boxes.as<float4>(), (int)m, c->trk_frames.as<float>(),
+                           c->trk_boxes.as<float4>(), (int)t, t32, c->excl.as<uint8_t>(), &c->d_cnt->status);
+    }
+    HIPCHK(c, hipGetLastError());
+    // tail (same as nms_grouped_host, graph already built)
+    const uint32_t n2 = pow2ceil((uint32_t)m);
+    HIPCHK(c, c->comp.reserve((size_t)n2 * 8));
+    HIPCHK(c, hipMemsetAsync(c->comp.p, 0, (size_t)n2 * 8, c->stream));
+    MisParams prm{};
+    prm.mode = 2;
+    prm.P = (int)pl.groups.size();
+    prm.scores = c->scores.as<float>();
+    prm.excl = c->excl.as<uint8_t>();
+    prm.groups = c->groups.as<GroupDesc>();
+    prm.row_off = c->rowoff.as<uint32_t>();
+    prm.row_deg = c->rowdeg.as<uint16_t>();
+    prm.adj = c->adj.as<uint16_t>();
+    prm.group_z = c->groupz.as<uint32_t>();
+    prm.glob_comp = c->comp.as<unsigned long long>();
+    prm.glob_cnt = &c->d_cnt->glob_cnt;
+    prm.orig_idx = c->origidx.as<uint32_t>();
+    prm.status = &c->d_cnt->status;
+    rc = launch_mis(c, prm, pl.nmax, false);
+    if (rc) return rc;
+    Counters h;
+    HIPCHK(c, hipMemcpyAsync(&h, c->d_cnt, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    rc = translate_status(c, h.status);
+    if (rc) return rc;
+    const uint32_t nk = h.glob_cnt;
+    rc = sort_comp_desc(c, nk);
+    if (rc) return rc;
+    if (nk) {
+        HIPCHK(c, c->out64.reserve((size_t)nk * 8));
+        hipLaunchKernelGGL(comp_to_index_kernel, dim3((nk + 255) / 256), dim3(256), 0, c->stream,
+                           c->comp.as<unsigned long long>(), nk, c->out64.as<int64_t>());
+        HIPCHK(c, hipMemcpyAsync(h_keep, c->out64.p, (size_t)nk * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    *n_keep = nk;
+    return VDET_OK;
+}
+
+int vdet_iou_f64(vdet_ctx *c, const double *h_b1, int64_t n1, const double *h_b2, int64_t n2, double *h_out)
+{
+    if (!c || n1 < 0 || n2 < 0) return VDET_EINVAL;
+    if (n1 == 0 || n2 == 0) return VDET_OK;
+    if (!h_b1 || !h_b2 || !h_out) return fail(c, VDET_EINVAL, "null buffer");
+    HIPCHK(c, hipSetDevice(c->device));
+    timing_reset(c);
+    HIPCHK(c, c->b1.reserve((size_t)n1 * 32));
+    HIPCHK(c, c->b2.reserve((size_t)n2 * 32));
+    HIPCHK(c, c->iou_out.reserve((size_t)n1 * n2 * 8));
+    HIPCHK(c, hipMemcpyAsync(c->b1.p, h_b1, (size_t)n1 * 32, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->b2.p, h_b2, (size_t)n2 * 32, hipMemcpyHostToDevice, c->stream));
+    {
+        StageTimer tm(c, ST_IOU64);
+        hipLaunchKernelGGL(iou_f64_kernel, dim3((unsigned)((n2 + 255) / 256), (unsigned)std::min<int64_t>(n1, 4096)),
+                           dim3(256), 0, c->stream, c->b1.as<double>(), n1, c->b2.as<double>(), n2,
+                           c->iou_out.as<double>());
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(h_out, c->iou_out.p, (size_t)n1 * n2 * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VDET_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+int vdet_nms_volume(vdet_ctx *c, const float *d_boxes, const float *d_scores, int layout, int64_t F, int64_t B,
+                    int64_t C, double thresh, int use_score_thresh, float score_thresh, int32_t *d_keep_idx,
+                    int32_t *d_keep_cnt, int64_t cap)
+{
+    if (!c) return VDET_EINVAL;
+    if (F < 0 || B < 0 || C < 0 || cap < 0 || (layout != VDET_LAYOUT_FBC && layout != VDET_LAYOUT_FCB))
+        return fail(c, VDET_EINVAL, "bad shape/layout");
+    if (F == 0 || C == 0) return VDET_OK;
+    if (!d_keep_cnt || (cap > 0 && !d_keep_idx)) return fail(c, VDET_EINVAL, "null output");
+    if (B > 32767) return fail(c, VDET_EINVAL, "B = %lld boxes per frame; the limit is 32767", (long long)B);
+    if (F * C > 0x7FFFFFF0ll || F * B > 0x7FFFFFF0ll) return fail(c, VDET_EINVAL, "volume too large");
+    if (((uintptr_t)d_boxes & 15) != 0) return fail(c, VDET_EINVAL, "d_boxes must be 16-byte aligned");
+    HIPCHK(c, hipSetDevice(c->device));
+    timing_reset(c);
+    if (B == 0) {
+        HIPCHK(c, hipMemsetAsync(d_keep_cnt, 0, (size_t)(F * C) * 4, c->stream));
+        return VDET_OK;
+    }
+    NmsPlan pl;
+    pl.groups.resize((size_t)F);
+    for (int64_t f = 0; f < F; ++f) pl.groups[(size_t)f] = {(int32_t)(f * B), (int32_t)B, 0};
+    make_plan(c, pl);
+    int rc = build_graph(c, reinterpret_cast<const float4 *>(d_boxes), pl, thresh_to_f32(thresh));
+    if (rc) return rc;
+    MisParams prm{};
+    prm.mode = layout;
+    prm.P = (int)(F * C);
+    prm.B = (int)B;
+    prm.C = (int)C;
+    prm.scores = d_scores;
+    prm.use_thr = use_score_thresh;
+    prm.thr = score_thresh;
+    prm.groups = c->groups.as<GroupDesc>();
+    prm.row_off = c->rowoff.as<uint32_t>();
+    prm.row_deg = c->rowdeg.as<uint16_t>();
+    prm.adj = c->adj.as<uint16_t>();
+    prm.group_z = c->groupz.as<uint32_t>();
+    prm.keep_idx = d_keep_idx;
+    prm.keep_cnt = d_keep_cnt;
+    prm.cap = cap;
+    prm.status = &c->d_cnt->status;
+    return launch_mis(c, prm, (int)B, true);
+}
+
+// ---------------------------------------------------------------------------------------------
+static int temporal_launch(vdet_ctx *c, int mode, const float *d_in, float *d_out, int64_t F, int64_t S, int W,
+                           float pad, float bias, const Taps &taps)
+{
+    if (F == 0 || S == 0) return VDET_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    timing_reset(c);
+    StageTimer tm(c, ST_TEMPORAL);
+    const bool vec = (S % 4 == 0) && (((uintptr_t)d_in | (uintptr_t)d_out) & 15) == 0 && (W == 3 || W == 5 || W == 7 || W == 9);
+    if (vec) {
+        const int64_t S4 = S / 4;
+        const unsigned gx = (unsigned)((S4 + 255) / 256);
+        // few series (tubelet tracks): split the frame axis so the chip is still filled
+        int64_t chunks = 1;
+        if ((int64_t)gx < 4 * c->n_cu) chunks = std::min<int64_t>(std::max<int64_t>(F / 16, 1), (4 * c->n_cu + gx - 1) / gx);
+        chunks = std::min<int64_t>(chunks, 65535);
+        const int64_t fchunk = (F + chunks - 1) / chunks;
+        const dim3 grid(gx, (unsigned)((F + fchunk - 1) / fchunk));
+        const float4 *in4 = reinterpret_cast<const float4 *>(d_in);
+        float4 *out4 = reinterpret_cast<float4 *>(d_out);
+#define VDET_TL(WW, MM) hipLaunchKernelGGL((temporal_vec4_kernel<WW, MM>), grid, dim3(256), 0, c->stream, in4, out4, F, S4, fchunk, pad, bias, taps)
+        if (mode == 0) {
+            if (W == 3) VDET_TL(3, 0); else if (W == 5) VDET_TL(5, 0); else if (W == 7) VDET_TL(7, 0); else VDET_TL(9, 0);
+        } else {
+            if (W == 3) VDET_TL(3, 1); else if (W == 5) VDET_TL(5, 1); else if (W == 7) VDET_TL(7, 1); else VDET_TL(9, 1);
+        }
+#undef VDET_TL
+    } else {
+        const int64_t n = F * S;
+        const dim3 grid((unsigned)((n + 255) / 256));
+        if (mode == 0) hipLaunchKernelGGL(temporal_scalar_kernel<0>, grid, dim3(256), 0, c->stream, d_in, d_out, F, S, W, pad, bias, taps);
+        else hipLaunchKernelGGL(temporal_scalar_kernel<1>, grid, dim3(256), 0, c->stream, d_in, d_out, F, S, W, pad, bias, taps);
+    }
+    HIPCHK(c, hipGetLastError());
+    return VDET_OK;
+}
+
+int vdet_temporal_maxpool_f32(vdet_ctx *c, const float *d_in, float *d_out, int64_t F, int64_t S, int window, float pad)
+{
+    if (!c) return VDET_EINVAL;
+    if (window < 1 || window % 2 != 1) return fail(c, VDET_EINVAL, "Window size must be odd!");
+    if (F < 0 || S < 0 || F * S > ((int64_t)1 << 40) || (F * S > 0 && (!d_in || !d_out || d_in == d_out)))
+        return fail(c, VDET_EINVAL, "bad temporal_maxpool arguments");
+    Taps taps{};
+    return temporal_launch(c, 0, d_in, d_out, F, S, window, pad, 0.0f, taps);
+}
+
+int vdet_temporal_conv_f32(vdet_ctx *c, const float *d_in, float *d_out, int64_t F, int64_t S, const float *h_taps,
+                           int K, float bias, float pad)
+{
+    if (!c) return VDET_EINVAL;
+    if (K < 1 || K % 2 != 1 || K > 31 || !h_taps) return fail(c, VDET_EINVAL, "taps: K must be odd and <= 31");
+    if (F < 0 || S < 0 || F * S > ((int64_t)1 << 40) || (F * S > 0 && (!d_in || !d_out || d_in == d_out)))
+        return fail(c, VDET_EINVAL, "bad temporal_conv arguments");
+    Taps taps{};
+    for (int k = 0; k < K; ++k) taps.w[k] = h_taps[k];
+    return temporal_launch(c, 1, d_in, d_out, F, S, K, pad, bias, taps);
+}
+
+}  // extern "C"

@@ -1,0 +1,86 @@
+"""Drop-in for the reference's only native module ``vdetlib.utils.cython_nms``
+(built from utils/nms.pyx by setup.py:8-14; imported by vdet/image_det.py:9, vdet/video_det.py:11,
+vdet/track.py:13).  Same three functions, same argument meaning, same return type (a python list
+of python ints in descending score order), same errors -- computed by the gfx950 kernels behind
+``vdet_nms_f32`` / ``vdet_track_det_nms_f32`` (include/vdet_hip.h).  No CPU fallback.
+"""
+import ctypes
+
+import numpy as np
+
+from .. import _lib
+
+
+def _as_f32_2d(a, name, ncols):
+    # Cython signature np.ndarray[np.float32_t, ndim=2]: anything else is rejected
+    if not isinstance(a, np.ndarray):
+        raise TypeError("Argument '%s' has incorrect type (expected numpy.ndarray, got %s)"
+                        % (name, type(a).__name__))
+    if a.ndim != 2:
+        raise ValueError("Buffer has wrong number of dimensions (expected 2, got %d)" % a.ndim)
+    if a.dtype != np.float32:
+        raise ValueError("Buffer dtype mismatch, expected 'float32_t' but got '%s'" % a.dtype.name)
+    if a.shape[1] < ncols:
+        raise IndexError("index %d is out of bounds for axis 1 with size %d" % (ncols - 1, a.shape[1]))
+    # the buffer interface honours arbitrary strides; the C-ABI wants a row stride in elements
+    if a.strides[1] != 4 or a.strides[0] % 4 != 0 or a.strides[0] < 0:
+        a = np.ascontiguousarray(a)
+    return a
+
+
+def _thresh(thresh):
+    if thresh is None:
+        raise TypeError("a float is required")
+    return float(thresh)
+
+
+def _run_nms(dets, thresh, ncols, order):
+    d = _as_f32_2d(dets, 'dets', ncols)
+    t = _thresh(thresh)
+    n = d.shape[0]
+    if n == 0:
+        return []
+    ctx = _lib.get_context()
+    keep = np.empty(n, dtype=np.int64)
+    nk = ctypes.c_int64(0)
+    o = None
+    if order is not None:
+        o = np.ascontiguousarray(order, dtype=np.int64)
+        if o.shape != (n,):
+            raise ValueError("order must have one entry per detection")
+    ld = d.strides[0] // 4 if n > 1 else d.shape[1]
+    ctx.check(ctx.lib.vdet_nms_f32(ctx.h, d.ctypes.data, n, ld, ncols, t,
+                                   o.ctypes.data if o is not None else None,
+                                   keep.ctypes.data, ctypes.byref(nk)))
+    return keep[:nk.value].tolist()
+
+
+def nms(dets, thresh, order=None):
+    """utils/nms.pyx:17-68 -- dets float32 [N,5] (x1,y1,x2,y2,score).
+
+    ``order`` (extension): the permutation the reference's ``scores.argsort()[::-1]`` produced, to
+    reproduce a specific machine's tie order; default = descending score, ties by descending index."""
+    return _run_nms(dets, thresh, 5, order)
+
+
+def vid_nms(dets, thresh, order=None):
+    """utils/nms.pyx:71-125 -- dets float32 [N,6] (frame,x1,y1,x2,y2,score)."""
+    return _run_nms(dets, thresh, 6, order)
+
+
+def track_det_nms(tracks, dets, thresh):
+    """utils/nms.pyx:128-189 -- tracks float32 [T,5] (frame,x1,y1,x2,y2), dets float32 [M,6]."""
+    t = _as_f32_2d(tracks, 'tracks', 5)
+    d = _as_f32_2d(dets, 'dets', 6)
+    th = _thresh(thresh)
+    m = d.shape[0]
+    if m == 0:
+        return []
+    ctx = _lib.get_context()
+    keep = np.empty(m, dtype=np.int64)
+    nk = ctypes.c_int64(0)
+    ldt = t.strides[0] // 4 if t.shape[0] > 1 else max(t.shape[1], 5)
+    ldd = d.strides[0] // 4 if m > 1 else d.shape[1]
+    ctx.check(ctx.lib.vdet_track_det_nms_f32(ctx.h, t.ctypes.data if t.shape[0] else None, t.shape[0], ldt,
+                                             d.ctypes.data, m, ldd, th, keep.ctypes.data, ctypes.byref(nk)))
+    return keep[:nk.value].tolist()
