@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""bench.py -- whole-job throughput of the hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL)
+
+A "step" = one pass of the hot path over one synthetic video per GPU, inputs already resident in
+HBM: per-(frame,class) greedy NMS of all boxes (vdet/image_det.py:117-123 over
+vdet/video_det.py:89-99 == utils/nms.pyx vid_nms per class) + the temporal pass over the
+[frame x box x class] score volume (vdet/tubelet_cls.py:386-414), and for N > 1 the RCCL all-gather
+of the per-video results (top-100 kept indices per (frame,class) + counts).  Workload at N=1 =
+BASELINE.json configs[1]: 300 frames x 10 000 boxes x 200 classes.  Videos are sharded one per
+GPU ("weak" scaling: per-GPU work fixed).
+
+Prints ONE JSON line (rank 0) with BASELINE.json's metric plus `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK = 8.0e12          # B/s, MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def synth_video_cuda(torch, seed, F, B, C, device):
+    """boxes [F,B,4] (integer-valued f32, 1280x720, SURVEY 8d recipe), scores [F,B,C] f32 ~U(0,1)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    x1 = torch.rand(F, B, generator=g, device=device) * 1230
+    y1 = torch.rand(F, B, generator=g, device=device) * 670
+    w = 10 + torch.rand(F, B, generator=g, device=device) * 290
+    h = 10 + torch.rand(F, B, generator=g, device=device) * 290
+    boxes = torch.stack([x1, y1, torch.clamp(x1 + w, max=1279), torch.clamp(y1 + h, max=719)], -1).round().contiguous()
+    scores = torch.rand(F, B, C, generator=g, device=device)
+    return boxes, scores
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=300)
+    ap.add_argument("--boxes", type=int, default=10000)
+    ap.add_argument("--classes", type=int, default=200)
+    ap.add_argument("--cap", type=int, default=2048, help="survivor capacity per (frame,class)")
+    ap.add_argument("--window", type=int, default=3)
+    ap.add_argument("--thresh", type=float, default=0.3)
+    ap.add_argument("--cpu-problems", type=int, default=120, help="(frame,class) problems timed on the CPU oracle")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from vdetlib_amd import ops, _lib
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    F, B, C = args.frames, args.boxes, args.classes
+    TOPK = 100
+
+    boxes, scores = synth_video_cuda(torch, 2000 + rank, F, B, C, dev)
+    ctx = _lib.get_context(local)
+    gathered = None
+
+    def step():
+        nonlocal gathered
+        keep_idx, keep_cnt = ops.nms_volume(boxes, scores, args.thresh, cap=args.cap, sync=False)
+        pooled = ops.temporal_maxpool(scores, args.window)
+        if world > 1:   # RCCL all-gather of the per-video results over xGMI
+            top = keep_idx[:, :, :TOPK].contiguous()
+            g_idx = torch.empty((world,) + tuple(top.shape), dtype=top.dtype, device=dev)
+            g_cnt = torch.empty((world,) + tuple(keep_cnt.shape), dtype=keep_cnt.dtype, device=dev)
+            dist.all_gather_into_tensor(g_idx, top)
+            dist.all_gather_into_tensor(g_cnt, keep_cnt)
+            gathered = (g_idx, g_cnt)
+        return keep_idx, keep_cnt, pooled
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+    ctx.sync()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    dt = time.perf_counter() - t0
+    ctx.sync()          # surfaces latched device-side failures (capacity / zero union)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    ms_per_step = dt / args.steps * 1e3
+    boxes_per_s = world * F * B * args.steps / dt
+
+    # ---- per-kernel timing (HIP events on the kernels' stream), outside the timed region
+    result = None
+    if rank == 0:
+        ctx.set_timing(True)
+        reps = 3
+        agg = {}
+        for _ in range(reps):
+            ops.nms_volume(boxes, scores, args.thresh, cap=args.cap, sync=True)
+            for k, (ms, n) in ctx.last_timing().items():
+                a = agg.setdefault(k, [0.0, 0]); a[0] += ms; a[1] += n
+            ops.temporal_maxpool(scores, args.window)
+            for k, (ms, n) in ctx.last_timing().items():
+                a = agg.setdefault(k, [0.0, 0]); a[0] += ms; a[1] += n
+        ctx.set_timing(False)
+        stages = {k: {"ms_per_step": v[0] / reps, "launches_per_step": v[1] // reps,
+                      "avg_launch_ms": (v[0] / v[1]) if v[1] else 0.0} for k, v in agg.items() if v[1]}
+        dom = max(stages, key=lambda k: stages[k]["ms_per_step"])
+        bytes_per_box = 16 * C + 16                       # algorithmic bytes per box
+        units_per_launch = F * B / stages[dom]["launches_per_step"]
+        achieved = bytes_per_box * units_per_launch / (stages[dom]["avg_launch_ms"] * 1e-3)
+        traffic = None
+        pj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.isfile(pj):
+            try:
+                traffic = json.load(open(pj)).get(dom, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK, "traffic": traffic,
+                    "algorithmic_bytes_per_box": bytes_per_box,
+                    "whole_path_frac": boxes_per_s / world * bytes_per_box / HBM_PEAK,
+                    "stages": stages}
+        # the temporal kernel is the one genuinely HBM-bound stage: report its own stream rate too
+        if "temporal" in stages:
+            tb = 8.0 * F * B * C                          # read 4 B + write 4 B per element
+            roofline["temporal_GBps"] = tb / (stages["temporal"]["avg_launch_ms"] * 1e-3) / 1e9
+
+        cpu = None
+        if not args.no_cpu:
+            from oracle import oracle
+            oracle.build()
+            nprob = max(1, args.cpu_problems)
+            nf = min(F, 3)
+            nc = min(C, max(1, nprob // nf))
+            hb = boxes[:nf].cpu().numpy()
+            hs = scores[:nf, :, :nc].contiguous().cpu().numpy()
+            t1 = time.perf_counter()
+            widx, wcnt = oracle.nms_volume(hb, hs, args.thresh, cap=args.cap)
+            oracle.temporal_maxpool(hs, args.window)
+            cdt = time.perf_counter() - t1
+            cpu_boxes = nf * B * (nc / C)
+            cpu = {"value": cpu_boxes / cdt, "unit": "boxes/s", "cores": 1, "kind": "port",
+                   "sample": "%d frames x %d classes x %d boxes (%d nms problems + temporal max-pool) in %.1f s, "
+                             "oracle/vdet_oracle.c single thread" % (nf, nc, B, nf * nc, cdt)}
+            # and use the sample as a last parity check of this very run
+            gi = out[0][:nf, :nc].cpu().numpy()
+            gc = out[1][:nf, :nc].cpu().numpy()
+            cpu["parity_checked"] = bool(np.array_equal(gc, wcnt) and np.array_equal(gi, widx))
+
+        result = {
+            "metric": "boxes/sec whole-node (NMS+temporal-conv+link), 300fx10k-box synth",
+            "value": boxes_per_s, "unit": "boxes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: 1 video/GPU, %d frames x %d boxes x %d classes; per-(frame,class) "
+                                   "NMS thresh %.2f + temporal max-pool w=%d%s" %
+                                   (F, B, C, args.thresh, args.window,
+                                    "; RCCL all-gather of top-%d kept/(frame,class)" % TOPK if world > 1 else ""),
+                       "frames": F, "boxes": B, "classes": C, "parallelism": "video-per-gpu x%d" % world},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

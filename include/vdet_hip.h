@@ -52,8 +52,11 @@ typedef enum vdet_status {
 /* device < 0: use the calling thread's current HIP device. */
 int vdet_create(vdet_ctx **out, int device);
 int vdet_destroy(vdet_ctx *ctx);
-/* Enqueue on an existing hipStream_t (e.g. torch's current stream); NULL = the context's own. */
+/* Enqueue on an existing hipStream_t, used verbatim (e.g. torch's current stream; NULL = HIP's null
+ * stream, which is torch's default stream). */
 int vdet_set_stream(vdet_ctx *ctx, void *hip_stream);
+/* Back to the context's own (non-blocking) stream, the default after vdet_create. */
+int vdet_reset_stream(vdet_ctx *ctx);
 /* Wait for the context's stream; return (and clear) the first latched device-side failure. */
 int vdet_sync(vdet_ctx *ctx);
 const char *vdet_last_error(vdet_ctx *ctx);
@@ -61,7 +64,7 @@ const char *vdet_last_error(vdet_ctx *ctx);
 const char *vdet_version(void);
 /* Wall-clock (ms, HIP events on the context's stream) of the kernels enqueued by the most recent
  * d_* call, by stage; used by bench.py for the roofline object.  out[8]: 0 iou_bits (K1), 1 adj_build
- * (K2), 2 mis (K3), 3 temporal, 4 sort, 5 track round 1, 6 iou_f64, 7 other. */
+ * (K2), 2 sort (K3), 3 walk (K4), 4 temporal, 5 merge sort, 6 track round 1, 7 other. */
 int vdet_last_timing_ms(vdet_ctx *ctx, float *out8);
 /* Number of timed launches per stage behind the sums of vdet_last_timing_ms (call it first). */
 int vdet_last_launches(vdet_ctx *ctx, int *out8);
@@ -110,7 +113,7 @@ int vdet_iou_f64(vdet_ctx *ctx, const double *h_boxes1, int64_t n1, const double
  *   d_keep_idx [F,C,cap] int32: kept box indices (0..B-1), descending score; entries >= count
  *                               are left untouched.   d_keep_cnt [F,C] int32.
  *   A (frame,class) with more than cap survivors latches VDET_ECAP (its count is still written).
- * Limits: B <= 32767.
+ * Limits: B <= ~18000 (the per-problem argsort lives in the CU's 160 KiB LDS).
  */
 int vdet_nms_volume(vdet_ctx *ctx, const float *d_boxes, const float *d_scores, int layout,
                     int64_t F, int64_t B, int64_t C, double thresh, int use_score_thresh,

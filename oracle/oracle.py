@@ -49,7 +49,7 @@ def lib():
         L.oracle_track_det_nms.argtypes = [vp, i64, i64, vp, i64, i64, f64, vp, vp]
         L.oracle_iou_f64.argtypes = [vp, i64, vp, i64, vp]
         L.oracle_iou_f64.restype = None
-        L.oracle_nms_volume.argtypes = [vp, vp, i64, i64, i64, i64, i64, i64, i64, f64,
+        L.oracle_nms_volume.argtypes = [vp, vp, i64, i64, i64, i64, i64, i64, i64, f64, ci,
                                         ctypes.c_float, vp, vp, i64]
         L.oracle_temporal_maxpool_f32.argtypes = [vp, vp, i64, i64, ci, ctypes.c_float]
         L.oracle_temporal_conv_f32.argtypes = [vp, vp, i64, i64, vp, ci, ctypes.c_float,
@@ -125,7 +125,7 @@ def iou(boxes1, boxes2):
     return out
 
 
-def nms_volume(boxes, scores, thresh, score_thresh=-np.inf, cap=None, frames=None, classes=None):
+def nms_volume(boxes, scores, thresh, score_thresh=None, cap=None, frames=None, classes=None):
     """Per-(frame,class) nms over boxes [F,B,4] / scores [F,B,C]: image_det.py:117-123 applied to
     every (frame, class) of video_det.py:89-99's loop.  Returns keep_idx [F,C,cap] (-1 padded),
     keep_cnt [F,C]; only the requested frame/class sub-ranges are filled."""
@@ -138,7 +138,9 @@ def nms_volume(boxes, scores, thresh, score_thresh=-np.inf, cap=None, frames=Non
     idx = np.full((F, C, cap), -1, dtype=np.int32)
     cnt = np.zeros((F, C), dtype=np.int32)
     _check(lib().oracle_nms_volume(_p(b), _p(s), F, B, C, f0, f1, c0, c1, float(thresh),
-                                   float(score_thresh), _p(idx), _p(cnt), cap))
+                                   0 if score_thresh is None else 1,
+                                   0.0 if score_thresh is None else float(score_thresh),
+                                   _p(idx), _p(cnt), cap))
     return idx, cnt
 
 

@@ -214,14 +214,15 @@ void oracle_iou_f64(const double *b1, int64_t n1, const double *b2, int64_t n2, 
  * Batched per-(frame,class) greedy NMS over a score volume: the array form of
  * "apply_image_nms for every frame and class" (vdet/image_det.py:117-123 over
  * vdet/video_det.py:89-99's per-class loop).  boxes [F,B,4], scores [F,B,C]
- * (class innermost, as zs[B,C] -- utils/protocol.py:538).  Candidates are the
- * boxes with score > score_thresh (video_det.py:90; pass -INFINITY for "all").
+ * (class innermost, as zs[B,C] -- utils/protocol.py:538).  With use_score_thresh the
+ * candidates are the boxes with score > score_thresh (video_det.py:90), else all boxes.
  * keep_idx [F,C,cap] (descending score), keep_cnt [F,C].  frames/classes give
  * the half-open sub-ranges to process so bench.py can time a bounded sample.
  */
 int oracle_nms_volume(const float *boxes, const float *scores, int64_t F, int64_t B, int64_t C,
                       int64_t f0, int64_t f1, int64_t c0, int64_t c1,
-                      double thresh, float score_thresh, int32_t *keep_idx, int32_t *keep_cnt, int64_t cap)
+                      double thresh, int use_score_thresh, float score_thresh, int32_t *keep_idx,
+                      int32_t *keep_cnt, int64_t cap)
 {
     (void)F;
     float *d = (float *)malloc((size_t)(B ? B : 1) * 5 * sizeof(float));
@@ -233,7 +234,7 @@ int oracle_nms_volume(const float *boxes, const float *scores, int64_t F, int64_
             int64_t n = 0;
             for (int64_t b = 0; b < B; ++b) {
                 const float s = scores[(f * B + b) * C + c];
-                if (!(s > score_thresh)) continue;
+                if (use_score_thresh && !(s > score_thresh)) continue;
                 memcpy(d + n * 5, boxes + (f * B + b) * 4, 4 * sizeof(float));
                 d[n * 5 + 4] = s; map[n++] = b;
             }

@@ -21,8 +21,7 @@ def _check_volume(torch, oracle, boxes, scores, thresh, score_thresh=None, cap=N
     idx, cnt = ops.nms_volume(tb, ts, thresh, score_thresh=score_thresh, cap=cap, layout=layout)
     idx, cnt = idx.cpu().numpy(), cnt.cpu().numpy()
     B = boxes.shape[1]
-    widx, wcnt = oracle.nms_volume(boxes, scores, thresh, -np.inf if score_thresh is None else score_thresh,
-                                   cap=B if cap is None else cap)
+    widx, wcnt = oracle.nms_volume(boxes, scores, thresh, score_thresh, cap=B if cap is None else cap)
     assert np.array_equal(cnt, wcnt)
     assert np.array_equal(idx, widx)
 

@@ -4,6 +4,7 @@ Fails loudly: no library or no GPU -> RuntimeError.  Nothing here (or anywhere u
 vdetlib_amd/) falls back to a CPU implementation.
 """
 import ctypes
+import importlib.util
 import os
 import threading
 
@@ -19,6 +20,7 @@ SYMBOLS = {
     "vdet_create": (_ci, [ctypes.POINTER(_vp), _ci]),
     "vdet_destroy": (_ci, [_vp]),
     "vdet_set_stream": (_ci, [_vp, _vp]),
+    "vdet_reset_stream": (_ci, [_vp]),
     "vdet_sync": (_ci, [_vp]),
     "vdet_last_error": (ctypes.c_char_p, [_vp]),
     "vdet_version": (ctypes.c_char_p, []),
@@ -38,10 +40,30 @@ _lock = threading.Lock()
 _ctxs = {}
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64 (same SONAME
+    libamdhip64.so.7 as /opt/rocm's).  If libvdet_hip.so pulled in the system copy first, a later
+    `import torch` would map a SECOND runtime (torch then sees no device, and streams / pointers
+    could not be shared).  Loading torch's copy first makes the dynamic linker hand that same
+    runtime to libvdet_hip.so (SONAME match) and to torch."""
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is not None and spec.origin:
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.isfile(cand):
+            try:
+                ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+            except OSError:
+                pass
+
+
 def load_library():
     """dlopen libvdet_hip.so and declare the prototypes (no GPU needed for this step)."""
     global _lib
     if _lib is None:
+        _preload_hip_runtime()
         if not os.path.isfile(LIB_PATH):
             raise RuntimeError(
                 "libvdet_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -97,6 +119,9 @@ class Context(object):
     def set_stream(self, stream_ptr):
         self.check(self.lib.vdet_set_stream(self.h, _vp(stream_ptr or 0)))
 
+    def reset_stream(self):
+        self.check(self.lib.vdet_reset_stream(self.h))
+
     def sync(self):
         self.check(self.lib.vdet_sync(self.h))
 
@@ -108,7 +133,7 @@ class Context(object):
         n = (ctypes.c_int * 8)()
         self.check(self.lib.vdet_last_timing_ms(self.h, ms))
         self.check(self.lib.vdet_last_launches(self.h, n))
-        names = ["iou_bits", "adj_build", "mis", "temporal", "sort", "track_round1", "iou_f64", "other"]
+        names = ["iou_bits", "adj_build", "sort", "walk", "temporal", "merge_sort", "track_round1", "other"]
         return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(names)}
 
 

@@ -6,31 +6,34 @@
 //   class whose scores order them.  So per FRAME (geometry group) we build the suppression graph
 //   once, and every (frame, class) problem is a lexicographically-first maximal independent set on
 //   that shared graph under its own priority order -- which is exactly what the reference's greedy
-//   loop computes (box v is kept iff no higher-priority neighbour is kept).
+//   loop computes (box v is kept iff no higher-priority box that suppresses it is kept).
 //
-//   K1 iou_bits_kernel   all-pairs predicate of one frame, one lane per row, column boxes broadcast
-//                        from LDS; 64 predicates packed per u64, written transposed ([word][row]) so
-//                        the stores and the later loads are coalesced.  VALU-bound.
-//   K2 adj_build_kernel  bit rows -> compact u16 adjacency lists (CSR slabs allocated with one
-//                        atomicAdd per 256-row tile).
-//   K3 mis_kernel        one workgroup per (frame, class): priorities (sortable score keys) in LDS,
-//                        rounds of "decide every vertex whose higher-priority neighbours are all
-//                        decided" (deterministic parallel greedy MIS), then an in-LDS bitonic sort
-//                        of the survivors into descending-score order.  LDS/latency-bound.
+//   K1 iou_bits_kernel   all-pairs predicate of one frame, one lane per row (the "i" box), column boxes
+//                        (the "j" boxes) broadcast from LDS; 64 predicates packed per u64, written
+//                        transposed ([word][row]) so the stores and the later loads are coalesced.
+//                        VALU-bound.
+//   K2 adj_build_kernel  bit rows -> compact u16 adjacency lists = OUT-lists "whom do I suppress"
+//                        (CSR slabs allocated with one atomicAdd per 256-row tile).
+//   K3 sort_kernel       one workgroup per (frame, class): stable LSD radix argsort of the scores,
+//                        entirely in LDS (keys stay put, a u16 index list is permuted).
+//   K4 walk_kernel       one WAVE per (frame, class): visits the candidates in descending order;
+//                        a survivor ORs its adjacency list into a "dead" bitmask held in LDS.
+//                        32 independent walks per CU hide the L2 latency of the list reads.
 //
-//   No sort of the B candidates is needed at all (only the ~K survivors are sorted), and the
-//   O(B^2) float work is shared by all C classes.
+//   The O(B^2) float work is shared by all C classes; per class only integer work remains.
+//   (A first version resolved each class as a parallel greedy MIS without sorting -- correct, but
+//   latency-bound at the real graph degree (~90 at B = 10k): 1021 ms vs the sorted walk.)
 //
 // Exactness notes (all verified against the oracle / golden vectors in tests/):
 //   * the predicate reproduces utils/nms.pyx:57-65 operation by operation in f32 (TU is compiled
 //     with -ffp-contract=off; '/' is the correctly rounded IEEE division), with the reference's
-//     "a if a >= b else b" max/min (NaN: second operand wins) and explicit i/j roles, so the graph
-//     is stored as IN-lists of j (who can suppress me) and stays exact for NaN coordinates;
+//     "a if a >= b else b" max/min (NaN: second operand wins) and explicit i/j roles (the graph is
+//     directed: row = i box, entry = j box), so it stays exact for NaN coordinates;
 //   * "ovr >= thresh" is an f64 compare of the promoted f32 quotient (thresh is a boxed python
 //     float); t32 = min{f in f32 : (double)f >= thresh} makes  ovr >= t32  the same predicate;
 //   * a zero union raises ZeroDivisionError in the reference (Cython cdivision=False) only for
 //     pairs it actually evaluates; zero-union pairs are kept as TAGGED adjacency entries and the
-//     evaluated-pair rule is re-checked after the MIS converged (mis_kernel epilogue).
+//     walk applies the evaluated-pair rule (entry not dead when its row box survives).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -96,7 +99,9 @@ __device__ __forceinline__ uint32_t pair_pred(float4 bi, float iarea, float4 bj,
 
 // ------------------------------------------------------------------------------------------------
 // K1: all-pairs predicate bits.  grid = (n_tiles, col_splits); block = 256 (one lane per row v).
-// bits[g.bits_off + w*nbox + v] bit k  <=>  box u = 64*w+k (as i) suppresses box v (as j), u != v.
+// The ROW box is the "i" box (the survivor that suppresses), the column box the "j" box:
+// bits[g.bits_off + w*nbox + v] bit k  <=>  box v (as i) suppresses box u = 64*w+k (as j), u != v,
+// i.e. row v is v's OUT-list -- what the greedy walk needs when v survives.
 // row_z[flat v] += number of zero-union partners of v.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void iou_bits_kernel(const float4 *__restrict__ boxes,
@@ -122,9 +127,9 @@ __global__ __launch_bounds__(256) void iou_bits_kernel(const float4 *__restrict_
     if (w0 >= w1) return;
 
     const float qnan = __uint_as_float(0x7FC00000u);
-    float4 bj = make_float4(qnan, qnan, qnan, qnan);
-    if (v < B) bj = boxes[gd.box_off + v];
-    const float jarea = box_area(bj);
+    float4 brow = make_float4(qnan, qnan, qnan, qnan);
+    if (v < B) brow = boxes[gd.box_off + v];
+    const float rarea = box_area(brow);
     uint32_t zcnt = 0;
 
     for (int wt = w0; wt < w1; wt += 4) {
@@ -142,13 +147,13 @@ __global__ __launch_bounds__(256) void iou_bits_kernel(const float4 *__restrict_
             uint32_t lo = 0, hi = 0;
 #pragma unroll
             for (int k = 0; k < 32; ++k) {
-                const uint32_t p = pair_pred(sbox[q * 64 + k], sarea[q * 64 + k], bj, jarea, t32);
+                const uint32_t p = pair_pred(brow, rarea, sbox[q * 64 + k], sarea[q * 64 + k], t32);
                 lo |= (p & 1u) << k;
                 zcnt += p >> 1;
             }
 #pragma unroll
             for (int k = 0; k < 32; ++k) {
-                const uint32_t p = pair_pred(sbox[q * 64 + 32 + k], sarea[q * 64 + 32 + k], bj, jarea, t32);
+                const uint32_t p = pair_pred(brow, rarea, sbox[q * 64 + 32 + k], sarea[q * 64 + 32 + k], t32);
                 hi |= (p & 1u) << k;
                 zcnt += p >> 1;
             }
@@ -156,7 +161,7 @@ __global__ __launch_bounds__(256) void iou_bits_kernel(const float4 *__restrict_
             const int cbase = (wt + q) * 64;
             if (v >= cbase && v < cbase + 64) {
                 m &= ~(1ull << (v - cbase));                       // no self edge
-                const uint32_t ps = pair_pred(bj, jarea, bj, jarea, t32);
+                const uint32_t ps = pair_pred(brow, rarea, brow, rarea, t32);
                 zcnt -= ps >> 1;                                   // ... and no self zero-union
             }
             if (v < B) bits[gd.bits_off + (int64_t)(wt + q) * B + v] = m;
@@ -233,212 +238,310 @@ __global__ __launch_bounds__(256) void adj_build_kernel(const float4 *__restrict
         }
     }
     if (zc) {  // rare: degenerate boxes.  Recompute which partners have a zero union.
-        const float4 bj = boxes[gd.box_off + v];
-        const float jarea = box_area(bj);
+        const float4 brow = boxes[gd.box_off + v];
+        const float rarea = box_area(brow);
         for (int u = 0; u < B; ++u) {
             if (u == v) continue;
-            const float4 bi = boxes[gd.box_off + u];
-            if (pair_pred(bi, box_area(bi), bj, jarea, 0.0f) & 2u) adj[p++] = (uint16_t)u | kZTag;
+            const float4 bu = boxes[gd.box_off + u];
+            if (pair_pred(brow, rarea, bu, box_area(bu), 0.0f) & 2u) adj[p++] = (uint16_t)u | kZTag;
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// K3: per-problem parallel greedy MIS + descending sort of the survivors.
+// K3: per-problem descending argsort of the scores, entirely in LDS.
+// One workgroup per (frame, class).  Stable LSD radix sort, 4 passes x 8 bits, on the inverted
+// sortable key; the initial arrangement is DESCENDING index, so equal scores come out by
+// descending index (= scores.argsort(kind='stable')[::-1], the build's tie rule).  Only the u16
+// index list is permuted (ping-pong), the keys stay put and are gathered through it.
+// Non-candidates (score <= thr / excluded) get the largest inverted key and land at the tail;
+// ncand[p] = number of real candidates.
+// Stable ranks inside a 64-key chunk come from an 8-ballot "match" (lanes with the same digit),
+// chunks of one wave are processed in order against per-(wave,digit) running bases.
 // ------------------------------------------------------------------------------------------------
-enum : uint8_t { ST_U = 0, ST_K = 1, ST_S = 2, ST_X = 3 };  // undecided / kept / suppressed / not a candidate
-
-struct MisParams {
-    // problem -> (group, score vector)
+struct SortParams {
     int mode;                 // 0: volume [F,B,C]  1: volume [F,C,B]  2: flat, problem p == group p
-    int P;                    // number of problems
-    int B, C;                 // volume dims (mode 0/1)
-    const float *scores;      // mode 0/1: the volume; mode 2: flat [Ntot] (may be null if keys given)
-    const uint32_t *keys;     // mode 2 only: explicit priorities (caller-supplied order), else null
-    const uint8_t *excl;      // mode 2 only: flat [Ntot], nonzero = not a candidate (track_det_nms round 1)
-    int use_thr;              // candidates are score > thr  (vdet/video_det.py:90)
+    int P;
+    int B, C;
+    const float *scores;
+    const uint32_t *keys;     // mode 2: explicit priorities (caller-supplied order) or null
+    const uint8_t *excl;      // mode 2: flat [Ntot] nonzero = not a candidate
+    int use_thr;
     float thr;
     const GroupDesc *groups;
+    uint16_t *order;          // mode 0/1: [P,B]; mode 2: flat [Ntot] at the group's box_off
+    int32_t *ncand;           // [P]
+    int lds_idxa_off, lds_idxb_off, lds_base_off;   // dynamic-LDS carve, multiples of 16
+};
+
+struct ProblemRef { int g, N, rb; int64_t sbase, sstride, obase; };
+
+__device__ __forceinline__ ProblemRef decode_problem(int mode, int p, int B, int C, const GroupDesc *groups)
+{
+    ProblemRef r;
+    if (mode == 0) { r.g = p / C; const int c = p - r.g * C; r.sbase = (int64_t)r.g * B * C + c; r.sstride = C; r.obase = (int64_t)p * B; }
+    else if (mode == 1) { r.g = p / C; r.sbase = (int64_t)p * B; r.sstride = 1; r.obase = (int64_t)p * B; }
+    else { r.g = p; r.sbase = groups[p].box_off; r.sstride = 1; r.obase = groups[p].box_off; }
+    r.N = groups[r.g].nbox;
+    r.rb = groups[r.g].box_off;
+    return r;
+}
+
+// XCD-aware problem order: the dispatcher places block b on XCD b % 8; give each XCD a contiguous
+// run of problems so the classes of one frame (which share that frame's score cache lines and
+// adjacency lists) meet in the same L2.  Placement only affects speed.  grid is a multiple of 8.
+__device__ __forceinline__ int xcd_problem(int bid, int nblocks)
+{
+    const int per = nblocks >> 3;
+    return (bid & 7) * per + (bid >> 3);
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void sort_kernel(const SortParams prm)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NW = BLOCK / 64;
+    uint32_t *keys0 = reinterpret_cast<uint32_t *>(smem);
+    uint16_t *src = reinterpret_cast<uint16_t *>(smem + prm.lds_idxa_off);
+    uint16_t *dst = reinterpret_cast<uint16_t *>(smem + prm.lds_idxb_off);
+    uint32_t *bases = reinterpret_cast<uint32_t *>(smem + prm.lds_base_off);   // [NW][256]
+    uint32_t *tot = bases + NW * 256;                                           // [256] + [1] excluded count
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int p = xcd_problem(blockIdx.x, gridDim.x);
+    if (p >= prm.P) return;
+    const ProblemRef pr = decode_problem(prm.mode, p, prm.B, prm.C, prm.groups);
+    const int N = pr.N;
+
+    if (tid == 0) tot[256] = 0;
+    __syncthreads();
+    uint32_t nx = 0;
+    for (int v = tid; v < N; v += BLOCK) {
+        uint32_t ik;
+        bool x = false;
+        if (prm.keys) {
+            ik = ~prm.keys[pr.sbase + v];
+        } else {
+            const float s = prm.scores[pr.sbase + (int64_t)v * pr.sstride];
+            ik = ~score_key(s);
+            if (prm.use_thr && !(s > prm.thr)) x = true;
+        }
+        if (prm.excl && prm.excl[pr.rb + v]) x = true;
+        if (x) { ik = 0xFFFFFFFFu; ++nx; }     // real inverted keys are <= 0xFF800000
+        keys0[v] = ik;
+        src[v] = (uint16_t)(N - 1 - v);
+    }
+    if (nx) atomicAdd(&tot[256], nx);
+    __syncthreads();
+    const int ncand = N - (int)tot[256];
+
+    const int nchunks = (N + 63) >> 6;
+    const int cpw = (nchunks + NW - 1) / NW;
+    const int c0 = w * cpw, c1 = min(nchunks, c0 + cpw);
+
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = pass * 8;
+        for (int i = tid; i < NW * 256; i += BLOCK) bases[i] = 0;
+        __syncthreads();
+        for (int ch = c0; ch < c1; ++ch) {
+            const int q = ch * 64 + lane;
+            if (q < N) atomicAdd(&bases[w * 256 + ((keys0[src[q]] >> shift) & 255u)], 1u);
+        }
+        __syncthreads();
+        if (tid < 256) {   // per digit: exclusive prefix over the waves, total
+            uint32_t run = 0;
+#pragma unroll
+            for (int ww = 0; ww < NW; ++ww) {
+                const uint32_t c = bases[ww * 256 + tid];
+                bases[ww * 256 + tid] = run;
+                run += c;
+            }
+            tot[tid] = run;
+        }
+        __syncthreads();
+        if (w == 0) {      // exclusive scan of the 256 digit totals by one wave (4 digits per lane)
+            const uint32_t a0 = tot[lane * 4], a1 = tot[lane * 4 + 1], a2 = tot[lane * 4 + 2], a3 = tot[lane * 4 + 3];
+            const uint32_t s4 = a0 + a1 + a2 + a3;
+            uint32_t inc = s4;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t t = __shfl_up(inc, d, 64);
+                if (lane >= d) inc += t;
+            }
+            const uint32_t ex = inc - s4;
+            tot[lane * 4] = ex; tot[lane * 4 + 1] = ex + a0; tot[lane * 4 + 2] = ex + a0 + a1; tot[lane * 4 + 3] = ex + a0 + a1 + a2;
+        }
+        __syncthreads();
+        for (int i = tid; i < NW * 256; i += BLOCK) bases[i] += tot[i & 255];
+        __syncthreads();
+        for (int ch = c0; ch < c1; ++ch) {
+            const int q = ch * 64 + lane;
+            const bool valid = q < N;
+            const uint32_t i = valid ? src[q] : 0u;
+            const uint32_t d = valid ? ((keys0[i] >> shift) & 255u) : 0u;
+            unsigned long long peers = __ballot(valid);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const bool bit = (d >> b) & 1u;
+                const unsigned long long m = __ballot(valid && bit);
+                peers &= bit ? m : ~m;
+            }
+            if (valid) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
+                const uint32_t bb = bases[w * 256 + d];
+                dst[bb + rank] = (uint16_t)i;
+                if (rank == 0) bases[w * 256 + d] = bb + (uint32_t)__popcll(peers);
+            }
+            // LDS operations of one wave execute in order; keep the compiler from moving the next
+            // chunk's base read above this chunk's base update
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+        __syncthreads();
+        uint16_t *t = src; src = dst; dst = t;
+    }
+    uint16_t *out = prm.order + pr.obase;
+    for (int v = tid; v < N; v += BLOCK) out[v] = src[v];
+    if (tid == 0) prm.ncand[p] = ncand;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4: the greedy walk.  One WAVE per (frame, class): candidates in descending score order, a
+// "dead" bitmask (suppressed | already kept | not a candidate) in LDS, and for every survivor one
+// coalesced read of its adjacency list whose lanes OR their neighbour's bit.  Survivors come out
+// already in descending score order.  Latency (one L2 round trip per survivor) is hidden by
+// prefetching the lists of the next GRP alive candidates and by 32 resident waves per CU.
+// Zero-union rule: a tagged entry (u,v) raises iff v is not dead when u is kept -- exactly the
+// pairs the reference evaluates (utils/nms.pyx:52-64).
+// ------------------------------------------------------------------------------------------------
+struct WalkParams {
+    int mode, P, B, C;
+    const GroupDesc *groups;
+    const uint16_t *order;
+    const int32_t *ncand;
     const uint32_t *row_off;
     const uint16_t *row_deg;
     const uint16_t *adj;
     const uint32_t *group_z;
-    // per-problem sorted output
-    int32_t *keep_idx;        // [P, cap] or null
-    int32_t *keep_cnt;        // [P] or null
+    int32_t *keep_idx;        // mode 0/1: [P,cap]; mode 2: flat [Ntot] at box_off (cap = nbox)
+    int32_t *keep_cnt;        // [P]
     int64_t cap;
-    // global append output (vid_nms merge): composite = key << 32 | orig_idx
-    unsigned long long *glob_comp;
-    unsigned int *glob_cnt;
-    const uint32_t *orig_idx; // flat [Ntot]
     int *status;
-    // dynamic-LDS carve (byte offsets, all multiples of 16):
-    //   [0, 4*nmax) keys | state | cursor (aliased by the sort buffer after the rounds) | scan[BLOCK]
-    int lds_state_off, lds_cursor_off, lds_scan_off;
+    int mask_words;           // u32 words per wave
 };
 
-__device__ __forceinline__ bool prio_higher(uint32_t ku, int u, uint32_t kv, int v)
-{
-    return ku > kv || (ku == kv && u > v);
-}
+constexpr int kWalkGrp = 8;
 
-template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void mis_kernel(const MisParams prm)
+__global__ __launch_bounds__(256) void walk_kernel(const WalkParams prm)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t *keys = reinterpret_cast<uint32_t *>(smem);
-    uint8_t *state = smem + prm.lds_state_off;
-    uint16_t *cursor = reinterpret_cast<uint16_t *>(smem + prm.lds_cursor_off);
-    unsigned long long *comp = reinterpret_cast<unsigned long long *>(smem + prm.lds_cursor_off);  // aliases cursor
-    uint32_t *sred = reinterpret_cast<uint32_t *>(smem + prm.lds_scan_off);   // no static LDS: keeps the
-                                                                              // dynamic base 16-B aligned
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    volatile uint32_t *mask = reinterpret_cast<uint32_t *>(smem) + w * prm.mask_words;
+    const int nwaves_total = gridDim.x * 4;
+    // wave-granular XCD mapping: block b -> XCD b % 8; consecutive problems share a frame
+    const int per = nwaves_total >> 3;
+    const int p = (blockIdx.x & 7) * per + (blockIdx.x >> 3) * 4 + w;
+    if (p >= prm.P) return;
+    const ProblemRef pr = decode_problem(prm.mode, p, prm.B, prm.C, prm.groups);
+    const int N = pr.N, rb = pr.rb;
+    const uint16_t *order = prm.order + pr.obase;
+    const int ncand = prm.ncand[p];
+    const bool has_z = prm.group_z[pr.g] != 0;
+    int32_t *out = prm.keep_idx + (prm.mode == 2 ? (int64_t)rb : (int64_t)p * prm.cap);
+    const int64_t cap = prm.mode == 2 ? (int64_t)N : prm.cap;
 
-    const int tid = threadIdx.x;
-    // XCD-aware problem order: the dispatcher places block b on XCD b % 8; give each XCD a
-    // contiguous run of problems so the classes of one frame (which share that frame's adjacency
-    // lists and score cache lines) meet in the same L2.  Placement only affects speed.
-    int p;
-    {
-        const int nb = gridDim.x;
-        const int per = (nb + 7) >> 3;
-        p = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-        if (p >= prm.P) return;   // (grid is padded to a multiple of 8)
-    }
-    int g, N;
-    int64_t sbase, sstride;
-    if (prm.mode == 0) { g = p / prm.C; const int c = p - g * prm.C; sbase = (int64_t)g * prm.B * prm.C + c; sstride = prm.C; }
-    else if (prm.mode == 1) { g = p / prm.C; sbase = (int64_t)p * prm.B; sstride = 1; }
-    else { g = p; sbase = prm.groups[g].box_off; sstride = 1; }
-    const GroupDesc gd = prm.groups[g];
-    N = gd.nbox;
-    const int rb = gd.box_off;
-
-    // ---- load priorities / candidate mask
-    for (int v = tid; v < N; v += BLOCK) {
-        uint32_t k;
-        uint8_t st = ST_U;
-        if (prm.keys) {
-            k = prm.keys[sbase + v];
-        } else {
-            const float s = prm.scores[sbase + (int64_t)v * sstride];
-            k = score_key(s);
-            if (prm.use_thr && !(s > prm.thr)) st = ST_X;
+    for (int i = lane; i < ((N + 31) >> 5); i += 64) mask[i] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (has_z) {   // non-candidates must read as dead for the zero-union rule
+        for (int q = ncand + lane; q < N; q += 64) {
+            const int v = order[q];
+            atomicOr(const_cast<uint32_t *>(&mask[v >> 5]), 1u << (v & 31));
         }
-        if (prm.excl && prm.excl[rb + v]) st = ST_X;
-        keys[v] = k;
-        state[v] = st;
-        cursor[v] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
-    __syncthreads();
 
-    // ---- rounds: a vertex is decided as soon as all its higher-priority in-neighbours are
-    for (;;) {
-        int pending = 0;
-        for (int v = tid; v < N; v += BLOCK) {
-            if (state[v] != ST_U) continue;
-            const uint32_t off = prm.row_off[rb + v];
-            const int d = prm.row_deg[rb + v];
-            int c = cursor[v];
-            const uint32_t kv = keys[v];
-            uint8_t ns = ST_U;
-            while (c < d) {
-                const uint16_t e = prm.adj[off + c];
-                if (e & kZTag) { ++c; continue; }
-                const int u = e;
-                const uint32_t ku = keys[u];
-                if (!prio_higher(ku, u, kv, v)) { ++c; continue; }
-                const uint8_t su = state[u];
-                if (su == ST_K) { ns = ST_S; break; }
-                if (su == ST_U) break;      // wait for u
-                ++c;                        // u suppressed or not a candidate
+    int nk = 0;
+    int bad = 0;
+    for (int q0 = 0; q0 < ncand; q0 += 64) {
+        const int q = q0 + lane;
+        const bool valid = q < ncand;
+        const int c = valid ? (int)order[q] : 0;
+        const bool alive = valid && !((mask[c >> 5] >> (c & 31)) & 1u);
+        unsigned long long am = __ballot(alive);
+        if (!am) continue;
+        const uint32_t off = alive ? prm.row_off[rb + c] : 0u;
+        const int deg = alive ? (int)prm.row_deg[rb + c] : 0;
+        while (am) {
+            int ls[kWalkGrp];
+            int ng = 0;
+#pragma unroll
+            for (int k = 0; k < kWalkGrp; ++k) {
+                ls[k] = 0;
+                if (am) { ls[k] = __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)am) - 1); am &= am - 1; ng = k + 1; }
             }
-            if (ns == ST_S) state[v] = ST_S;
-            else if (c >= d) state[v] = ST_K;
-            else { cursor[v] = (uint16_t)c; pending = 1; }
-        }
-        if (!__syncthreads_or(pending)) break;
-    }
-
-    // ---- zero-union rule (only groups holding degenerate boxes): the reference raises iff it
-    // EVALUATES a zero-union pair (i kept, j later, j not yet suppressed when i is processed).
-    if (prm.group_z[g]) {
-        int bad = 0;
-        for (int v = tid; v < N; v += BLOCK) {
-            if (state[v] == ST_X) continue;
-            const uint32_t off = prm.row_off[rb + v];
-            const int d = prm.row_deg[rb + v];
-            const uint32_t kv = keys[v];
-            for (int c = 0; c < d; ++c) {
-                const uint16_t e = prm.adj[off + c];
-                if (!(e & kZTag)) continue;
-                const int u = e & 0x7FFF;
-                if (state[u] != ST_K || !prio_higher(keys[u], u, kv, v)) continue;
-                bool earlier = false;   // was v already suppressed by a kept box processed before u?
-                for (int c2 = 0; c2 < d && !earlier; ++c2) {
-                    const uint16_t e2 = prm.adj[off + c2];
-                    if (e2 & kZTag) continue;
-                    const int s = e2;
-                    if (state[s] == ST_K && prio_higher(keys[s], s, keys[u], u)) earlier = true;
-                }
-                if (!earlier) bad = 1;
-            }
-        }
-        if (bad) atomicOr(prm.status, kStDivZero);
-    }
-
-    // ---- compact survivors: composite = key << 32 | index  (unique => any sorting network works)
-    uint32_t mine = 0;
-    for (int v = tid; v < N; v += BLOCK) mine += (state[v] == ST_K);
-    sred[tid] = mine;
-    __syncthreads();
-    for (int d = 1; d < BLOCK; d <<= 1) {
-        const uint32_t t = (tid >= d) ? sred[tid - d] : 0u;
-        __syncthreads();
-        sred[tid] += t;
-        __syncthreads();
-    }
-    const uint32_t K = sred[BLOCK - 1];
-    uint32_t pos = sred[tid] - mine;
-    __syncthreads();
-
-    if (prm.glob_comp) {   // unsorted append; the caller sorts globally
-        if (tid == 0) sred[0] = atomicAdd(prm.glob_cnt, K);
-        __syncthreads();
-        const uint32_t gbase = sred[0];
-        for (int v = tid; v < N; v += BLOCK)
-            if (state[v] == ST_K)
-                prm.glob_comp[gbase + pos++] = ((unsigned long long)keys[v] << 32) | prm.orig_idx[rb + v];
-        return;
-    }
-
-    if (tid == 0) prm.keep_cnt[p] = (int32_t)K;
-    if ((int64_t)K > prm.cap) {
-        if (tid == 0) atomicOr(prm.status, kStCap);
-        return;
-    }
-    if (K == 0) return;
-    uint32_t n2 = 1;
-    while (n2 < K) n2 <<= 1;
-    // comp[] aliases cursor[] (dead since the last round's barrier); keys/state sit below it.
-    for (int v = tid; v < N; v += BLOCK)
-        if (state[v] == ST_K) comp[pos++] = ((unsigned long long)keys[v] << 32) | (uint32_t)v;
-    for (uint32_t i = K + tid; i < n2; i += BLOCK) comp[i] = 0ull;   // real composites are > 0
-    __syncthreads();
-    for (uint32_t k = 2; k <= n2; k <<= 1) {
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t i = tid; i < n2; i += BLOCK) {
-                const uint32_t ixj = i ^ j;
-                if (ixj > i) {
-                    const unsigned long long a = comp[i], b = comp[ixj];
-                    const bool desc = (i & k) == 0;
-                    if (desc ? (a < b) : (a > b)) { comp[i] = b; comp[ixj] = a; }
+            uint16_t pre0[kWalkGrp], pre1[kWalkGrp];
+#pragma unroll
+            for (int k = 0; k < kWalkGrp; ++k) {
+                pre0[k] = 0; pre1[k] = 0;
+                if (k < ng) {
+                    const uint32_t o = __builtin_amdgcn_readlane(off, ls[k]);
+                    const int d = __builtin_amdgcn_readlane(deg, ls[k]);
+                    if (lane < d) pre0[k] = prm.adj[o + lane];
+                    if (lane + 64 < d) pre1[k] = prm.adj[o + 64 + lane];
                 }
             }
-            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < kWalkGrp; ++k) {
+                if (k >= ng) break;
+                const int cu = __builtin_amdgcn_readlane(c, ls[k]);
+                if ((mask[cu >> 5] >> (cu & 31)) & 1u) continue;    // suppressed by an earlier survivor of this chunk
+                if ((int64_t)nk < cap) { if (lane == 0) out[nk] = cu; }
+                ++nk;
+                const uint32_t o = __builtin_amdgcn_readlane(off, ls[k]);
+                const int d = __builtin_amdgcn_readlane(deg, ls[k]);
+                if (lane == 0) atomicOr(const_cast<uint32_t *>(&mask[cu >> 5]), 1u << (cu & 31));
+                for (int e0 = 0; e0 < d; e0 += 64) {
+                    uint16_t e;
+                    if (e0 == 0) e = pre0[k];
+                    else if (e0 == 64) e = pre1[k];
+                    else e = (e0 + lane < d) ? prm.adj[o + e0 + lane] : (uint16_t)0;
+                    if (e0 + lane < d) {
+                        const int v = e & 0x7FFF;
+                        if (e & kZTag) { if (!((mask[v >> 5] >> (v & 31)) & 1u)) bad = 1; }
+                        else atomicOr(const_cast<uint32_t *>(&mask[v >> 5]), 1u << (v & 31));
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            }
         }
     }
-    int32_t *out = prm.keep_idx + (int64_t)p * prm.cap;
-    for (uint32_t i = tid; i < K; i += BLOCK) out[i] = (int32_t)(comp[i] & 0xFFFFFFFFull);
+    if (lane == 0) prm.keep_cnt[p] = nk;
+    if ((int64_t)nk > cap && lane == 0) atomicOr(prm.status, kStCap);
+    if (__ballot(bad != 0) && lane == 0) atomicOr(prm.status, kStDivZero);
+}
+
+// mode-2 merge helper: survivors of every group -> composites key << 32 | original index
+__global__ __launch_bounds__(256) void gather_comp_kernel(const GroupDesc *__restrict__ groups, int P,
+                                                          const int32_t *__restrict__ keep_idx,
+                                                          const int32_t *__restrict__ keep_cnt,
+                                                          const float *__restrict__ scores,
+                                                          const uint32_t *__restrict__ keys,
+                                                          const uint32_t *__restrict__ orig_idx,
+                                                          unsigned long long *__restrict__ comp,
+                                                          unsigned int *__restrict__ glob_cnt)
+{
+    __shared__ unsigned int sbase;
+    const int p = blockIdx.x;
+    if (p >= P) return;
+    const int rb = groups[p].box_off;
+    const int K = keep_cnt[p];
+    if (threadIdx.x == 0) sbase = atomicAdd(glob_cnt, (unsigned int)K);
+    __syncthreads();
+    const unsigned int base = sbase;
+    for (int k = threadIdx.x; k < K; k += 256) {
+        const int v = keep_idx[rb + k];
+        const uint32_t key = keys ? keys[rb + v] : score_key(scores[rb + v]);
+        comp[base + k] = ((unsigned long long)key << 32) | orig_idx[rb + v];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

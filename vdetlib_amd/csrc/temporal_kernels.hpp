@@ -52,16 +52,22 @@ __global__ __launch_bounds__(256) void temporal_vec4_kernel(const float4 *__rest
     if (f0 >= f1) return;
     const float4 padv = splat4(pad);
     float4 win[W];   // win[k] = in[f - H + k]
+    // out-of-range frames: always load a VALID (clamped) address, then select the pad value --
+    // "cond ? in[i] : padv" makes hipcc select between a global and a scratch POINTER (flat load).
 #pragma unroll
     for (int k = 0; k < W - 1; ++k) {
         const int64_t g = f0 - H + k;
-        win[k + 1] = (g >= 0 && g < F) ? in[g * S4 + s] : padv;
+        const int64_t gc = min(max(g, (int64_t)0), F - 1);
+        const float4 v = in[gc * S4 + s];
+        win[k + 1] = (g == gc) ? v : padv;
     }
     for (int64_t f = f0; f < f1; ++f) {
 #pragma unroll
         for (int k = 0; k < W - 1; ++k) win[k] = win[k + 1];
         const int64_t g = f + H;
-        win[W - 1] = (g < F) ? in[g * S4 + s] : padv;
+        const int64_t gc = min(g, F - 1);
+        const float4 v = in[gc * S4 + s];
+        win[W - 1] = (g == gc) ? v : padv;
         float4 r;
         if (MODE == 0) {
             MaxAcc a;
@@ -97,7 +103,9 @@ __global__ __launch_bounds__(256) void temporal_scalar_kernel(const float *__res
         bool nan = false;
         for (int k = 0; k < W; ++k) {
             const int64_t g = f + k - H;
-            const float v = (g >= 0 && g < F) ? in[g * S + s] : pad;
+            const int64_t gc = min(max(g, (int64_t)0), F - 1);
+            float v = in[gc * S + s];
+            v = (g == gc) ? v : pad;
             nan |= (v != v);
             m = (k == 0) ? v : fmaxf(m, v);
         }
@@ -106,7 +114,9 @@ __global__ __launch_bounds__(256) void temporal_scalar_kernel(const float *__res
         float acc = bias;
         for (int k = 0; k < W; ++k) {
             const int64_t g = f + k - H;
-            const float v = (g >= 0 && g < F) ? in[g * S + s] : pad;
+            const int64_t gc = min(max(g, (int64_t)0), F - 1);
+            float v = in[gc * S + s];
+            v = (g == gc) ? v : pad;
             acc = acc + taps.w[k] * v;
         }
         out[i] = acc;

@@ -48,7 +48,7 @@ struct DevBuf {
     template <typename T> T *as() { return static_cast<T *>(p); }
 };
 
-enum Stage { ST_IOU_BITS = 0, ST_ADJ = 1, ST_MIS = 2, ST_TEMPORAL = 3, ST_SORT = 4, ST_ROUND1 = 5, ST_IOU64 = 6, ST_OTHER = 7 };
+enum Stage { ST_IOU_BITS = 0, ST_ADJ = 1, ST_SORTK = 2, ST_WALK = 3, ST_TEMPORAL = 4, ST_SORT = 5, ST_ROUND1 = 6, ST_OTHER = 7 };
 
 struct Counters {            // one small device block
     int status;
@@ -70,7 +70,7 @@ struct vdet_ctx {
     int n_cu = 256;
     // scratch
     DevBuf boxes, scores, keys, excl, frames, groups, tiles, bits, rowz, rowoff, rowdeg, groupz, adj, comp, origidx,
-        out64, trk_frames, trk_boxes, b1, b2, iou_out;
+        out64, trk_frames, trk_boxes, b1, b2, iou_out, order, ncand, keepidx, keepcnt;
     // timing
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -78,7 +78,8 @@ struct vdet_ctx {
     size_t ev_used = 0;
     float last_ms[8] = {0};
     int last_launches[8] = {0};
-    bool mis_attr_set = false;
+    bool sort_attr_set = false;
+    size_t dyn_lds_max = 0;
 };
 
 namespace {
@@ -261,44 +262,83 @@ int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32)
     return fail(c, VDET_EHIP, "internal: adjacency pool overflow after regrow");
 }
 
-size_t mis_lds_bytes(int nmax, int64_t cap, bool sorted, int block, MisParams &prm)
-{
-    auto r16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
-    const size_t keysB = r16((size_t)4 * nmax);
-    const size_t stateB = r16((size_t)nmax);
-    size_t curB = (size_t)2 * nmax;
-    if (sorted) {
-        const uint32_t sc = pow2ceil((uint32_t)std::min<int64_t>(cap, nmax));
-        curB = std::max<size_t>(curB, (size_t)8 * sc);
-    }
-    curB = r16(curB);
-    prm.lds_state_off = (int)keysB;
-    prm.lds_cursor_off = (int)(keysB + stateB);
-    prm.lds_scan_off = (int)(keysB + stateB + curB);
-    return keysB + stateB + curB + (size_t)4 * block;
-}
+// K3 + K4 for P problems.  d_order / d_ncand / keep buffers are caller-provided device pointers.
+struct SortWalkArgs {
+    int mode, P, B, C;
+    const float *scores;
+    const uint32_t *keys;
+    const uint8_t *excl;
+    int use_thr;
+    float thr;
+    int32_t *keep_idx;
+    int32_t *keep_cnt;
+    int64_t cap;
+};
 
-int launch_mis(vdet_ctx *c, MisParams prm, int nmax, bool sorted)
+int launch_sort_walk(vdet_ctx *c, const SortWalkArgs &a, int nmax, int64_t order_elems)
 {
-    if (prm.P <= 0) return VDET_OK;
-    const int block = nmax > 2048 ? 1024 : 256;
-    const size_t lds = mis_lds_bytes(std::max(nmax, 1), prm.cap, sorted, block, prm);
-    if (lds > c->max_lds)
-        return fail(c, VDET_EINVAL,
-                    "a frame with %d boxes (survivor capacity %lld) needs %zu B of LDS; the limit is %zu B "
-                    "(about 23000 boxes per frame, fewer with a large capacity)",
-                    nmax, (long long)prm.cap, lds, c->max_lds);
-    if (!c->mis_attr_set) {
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(mis_kernel<1024>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->max_lds));
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(mis_kernel<256>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->max_lds));
-        c->mis_attr_set = true;
+    if (a.P <= 0) return VDET_OK;
+    auto r16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    HIPCHK(c, c->order.reserve((size_t)std::max<int64_t>(order_elems, 1) * 2));
+    HIPCHK(c, c->ncand.reserve((size_t)a.P * 4));
+    const int block = nmax > 1024 ? 1024 : 256;
+    const int nw = block / 64;
+    if (!c->sort_attr_set) {
+        const void *fns[3] = {reinterpret_cast<const void *>(sort_kernel<1024>),
+                              reinterpret_cast<const void *>(sort_kernel<256>),
+                              reinterpret_cast<const void *>(walk_kernel)};
+        size_t stat = 0;
+        for (const void *fn : fns) {
+            hipFuncAttributes fa;
+            HIPCHK(c, hipFuncGetAttributes(&fa, fn));
+            stat = std::max(stat, (size_t)fa.sharedSizeBytes);
+        }
+        c->dyn_lds_max = c->max_lds - r16(stat);
+        for (const void *fn : fns)
+            HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->dyn_lds_max));
+        c->sort_attr_set = true;
     }
-    const int grid = (prm.P + 7) & ~7;
-    StageTimer tm(c, ST_MIS);
-    if (block == 1024) hipLaunchKernelGGL(mis_kernel<1024>, dim3(grid), dim3(1024), lds, c->stream, prm);
-    else hipLaunchKernelGGL(mis_kernel<256>, dim3(grid), dim3(256), lds, c->stream, prm);
+    SortParams sp{};
+    sp.mode = a.mode; sp.P = a.P; sp.B = a.B; sp.C = a.C;
+    sp.scores = a.scores; sp.keys = a.keys; sp.excl = a.excl; sp.use_thr = a.use_thr; sp.thr = a.thr;
+    sp.groups = c->groups.as<GroupDesc>();
+    sp.order = c->order.as<uint16_t>();
+    sp.ncand = c->ncand.as<int32_t>();
+    const size_t keysB = r16((size_t)4 * std::max(nmax, 1));
+    const size_t idxB = r16((size_t)2 * std::max(nmax, 1));
+    sp.lds_idxa_off = (int)keysB;
+    sp.lds_idxb_off = (int)(keysB + idxB);
+    sp.lds_base_off = (int)(keysB + 2 * idxB);
+    const size_t lds = keysB + 2 * idxB + (size_t)4 * (nw * 256 + 256 + 4);
+    if (lds > c->dyn_lds_max)
+        return fail(c, VDET_EINVAL, "a frame with %d boxes needs %zu B of LDS for the in-LDS sort; the limit is %zu B "
+                                    "(about 18000 boxes per frame)", nmax, lds, c->dyn_lds_max);
+    {
+        const int grid = (a.P + 7) & ~7;
+        StageTimer tm(c, ST_SORTK);
+        if (block == 1024) hipLaunchKernelGGL(sort_kernel<1024>, dim3(grid), dim3(1024), lds, c->stream, sp);
+        else hipLaunchKernelGGL(sort_kernel<256>, dim3(grid), dim3(256), lds, c->stream, sp);
+    }
+    HIPCHK(c, hipGetLastError());
+    WalkParams wp{};
+    wp.mode = a.mode; wp.P = a.P; wp.B = a.B; wp.C = a.C;
+    wp.groups = c->groups.as<GroupDesc>();
+    wp.order = c->order.as<uint16_t>();
+    wp.ncand = c->ncand.as<int32_t>();
+    wp.row_off = c->rowoff.as<uint32_t>();
+    wp.row_deg = c->rowdeg.as<uint16_t>();
+    wp.adj = c->adj.as<uint16_t>();
+    wp.group_z = c->groupz.as<uint32_t>();
+    wp.keep_idx = a.keep_idx;
+    wp.keep_cnt = a.keep_cnt;
+    wp.cap = a.cap;
+    wp.status = &c->d_cnt->status;
+    wp.mask_words = (int)(r16((size_t)4 * ((std::max(nmax, 1) + 31) / 32)) / 4);
+    {
+        const int nblk = (((a.P + 3) / 4) + 7) & ~7;
+        StageTimer tm(c, ST_WALK);
+        hipLaunchKernelGGL(walk_kernel, dim3(nblk), dim3(256), (size_t)wp.mask_words * 4 * 4, c->stream, wp);
+    }
     HIPCHK(c, hipGetLastError());
     return VDET_OK;
 }
@@ -321,34 +361,29 @@ int sort_comp_desc(vdet_ctx *c, uint32_t n)
     return VDET_OK;
 }
 
-// Shared tail of nms / vid_nms / track_det_nms on grouped, uploaded data:
-//   graph -> MIS (append) -> global sort -> indices.
-int nms_grouped_host(vdet_ctx *c, NmsPlan &pl, float t32, const float *d_scores, const uint32_t *d_keys,
+// Shared tail of nms / vid_nms / track_det_nms on grouped, uploaded data (graph already built):
+//   sort -> walk -> survivors of all groups as composites -> global descending sort -> indices.
+int nms_grouped_tail(vdet_ctx *c, NmsPlan &pl, const float *d_scores, const uint32_t *d_keys,
                      const uint8_t *d_excl, int64_t *h_keep, int64_t *n_keep)
 {
-    int rc = build_graph(c, c->boxes.as<float4>(), pl, t32);
+    const int P = (int)pl.groups.size();
+    HIPCHK(c, c->keepidx.reserve((size_t)pl.ntot * 4));
+    HIPCHK(c, c->keepcnt.reserve((size_t)P * 4));
+    SortWalkArgs a{};
+    a.mode = 2; a.P = P;
+    a.scores = d_scores; a.keys = d_keys; a.excl = d_excl;
+    a.keep_idx = c->keepidx.as<int32_t>();
+    a.keep_cnt = c->keepcnt.as<int32_t>();
+    a.cap = 0;
+    int rc = launch_sort_walk(c, a, pl.nmax, pl.ntot);
     if (rc) return rc;
     const uint32_t n2 = pow2ceil((uint32_t)std::max<int64_t>(pl.ntot, 1));
     HIPCHK(c, c->comp.reserve((size_t)n2 * 8));
     HIPCHK(c, hipMemsetAsync(c->comp.p, 0, (size_t)n2 * 8, c->stream));
-    MisParams prm{};
-    prm.mode = 2;
-    prm.P = (int)pl.groups.size();
-    prm.scores = d_scores;
-    prm.keys = d_keys;
-    prm.excl = d_excl;
-    prm.groups = c->groups.as<GroupDesc>();
-    prm.row_off = c->rowoff.as<uint32_t>();
-    prm.row_deg = c->rowdeg.as<uint16_t>();
-    prm.adj = c->adj.as<uint16_t>();
-    prm.group_z = c->groupz.as<uint32_t>();
-    prm.cap = 0;
-    prm.glob_comp = c->comp.as<unsigned long long>();
-    prm.glob_cnt = &c->d_cnt->glob_cnt;
-    prm.orig_idx = c->origidx.as<uint32_t>();
-    prm.status = &c->d_cnt->status;
-    rc = launch_mis(c, prm, pl.nmax, false);
-    if (rc) return rc;
+    hipLaunchKernelGGL(gather_comp_kernel, dim3(P), dim3(256), 0, c->stream, c->groups.as<GroupDesc>(), P,
+                       c->keepidx.as<int32_t>(), c->keepcnt.as<int32_t>(), d_scores, d_keys,
+                       c->origidx.as<uint32_t>(), c->comp.as<unsigned long long>(), &c->d_cnt->glob_cnt);
+    HIPCHK(c, hipGetLastError());
     Counters h;
     HIPCHK(c, hipMemcpyAsync(&h, c->d_cnt, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -451,7 +486,8 @@ int vdet_destroy(vdet_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->boxes, &c->scores, &c->keys, &c->excl, &c->frames, &c->groups, &c->tiles, &c->bits,
                       &c->rowz, &c->rowoff, &c->rowdeg, &c->groupz, &c->adj, &c->comp, &c->origidx, &c->out64,
-                      &c->trk_frames, &c->trk_boxes, &c->b1, &c->b2, &c->iou_out};
+                      &c->trk_frames, &c->trk_boxes, &c->b1, &c->b2, &c->iou_out, &c->order, &c->ncand, &c->keepidx,
+                      &c->keepcnt};
     for (DevBuf *b : bufs) b->release();
     for (auto &e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (c->d_cnt) (void)hipFree(c->d_cnt);
@@ -463,7 +499,14 @@ int vdet_destroy(vdet_ctx *c)
 int vdet_set_stream(vdet_ctx *c, void *s)
 {
     if (!c) return VDET_EINVAL;
-    c->stream = s ? (hipStream_t)s : c->own_stream;
+    c->stream = (hipStream_t)s;        // verbatim: NULL is HIP's null stream (torch's default stream)
+    return VDET_OK;
+}
+
+int vdet_reset_stream(vdet_ctx *c)
+{
+    if (!c) return VDET_EINVAL;
+    c->stream = c->own_stream;
     return VDET_OK;
 }
 
@@ -570,7 +613,9 @@ int vdet_nms_f32(vdet_ctx *c, const float *h_dets, int64_t n, int64_t ld, int nc
         d_keys = c->keys.as<uint32_t>();
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    return nms_grouped_host(c, pl, thresh_to_f32(thresh), c->scores.as<float>(), d_keys, nullptr, h_keep, n_keep);
+    int rc = build_graph(c, c->boxes.as<float4>(), pl, thresh_to_f32(thresh));
+    if (rc) return rc;
+    return nms_grouped_tail(c, pl, c->scores.as<float>(), d_keys, nullptr, h_keep, n_keep);
 }
 
 int vdet_track_det_nms_f32(vdet_ctx *c, const float *h_tracks, int64_t t, int64_t ldt, const float *h_dets,
@@ -628,43 +673,7 @@ int vdet_track_det_nms_f32(vdet_ctx *c, const float *h_tracks, int64_t t, int64_
                            c->trk_boxes.as<float4>(), (int)t, t32, c->excl.as<uint8_t>(), &c->d_cnt->status);
     }
     HIPCHK(c, hipGetLastError());
-    // tail (same as nms_grouped_host, graph already built)
-    const uint32_t n2 = pow2ceil((uint32_t)m);
-    HIPCHK(c, c->comp.reserve((size_t)n2 * 8));
-    HIPCHK(c, hipMemsetAsync(c->comp.p, 0, (size_t)n2 * 8, c->stream));
-    MisParams prm{};
-    prm.mode = 2;
-    prm.P = (int)pl.groups.size();
-    prm.scores = c->scores.as<float>();
-    prm.excl = c->excl.as<uint8_t>();
-    prm.groups = c->groups.as<GroupDesc>();
-    prm.row_off = c->rowoff.as<uint32_t>();
-    prm.row_deg = c->rowdeg.as<uint16_t>();
-    prm.adj = c->adj.as<uint16_t>();
-    prm.group_z = c->groupz.as<uint32_t>();
-    prm.glob_comp = c->comp.as<unsigned long long>();
-    prm.glob_cnt = &c->d_cnt->glob_cnt;
-    prm.orig_idx = c->origidx.as<uint32_t>();
-    prm.status = &c->d_cnt->status;
-    rc = launch_mis(c, prm, pl.nmax, false);
-    if (rc) return rc;
-    Counters h;
-    HIPCHK(c, hipMemcpyAsync(&h, c->d_cnt, sizeof h, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    rc = translate_status(c, h.status);
-    if (rc) return rc;
-    const uint32_t nk = h.glob_cnt;
-    rc = sort_comp_desc(c, nk);
-    if (rc) return rc;
-    if (nk) {
-        HIPCHK(c, c->out64.reserve((size_t)nk * 8));
-        hipLaunchKernelGGL(comp_to_index_kernel, dim3((nk + 255) / 256), dim3(256), 0, c->stream,
-                           c->comp.as<unsigned long long>(), nk, c->out64.as<int64_t>());
-        HIPCHK(c, hipMemcpyAsync(h_keep, c->out64.p, (size_t)nk * 8, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-    }
-    *n_keep = nk;
-    return VDET_OK;
+    return nms_grouped_tail(c, pl, c->scores.as<float>(), nullptr, c->excl.as<uint8_t>(), h_keep, n_keep);
 }
 
 int vdet_iou_f64(vdet_ctx *c, const double *h_b1, int64_t n1, const double *h_b2, int64_t n2, double *h_out)
@@ -680,7 +689,7 @@ int vdet_iou_f64(vdet_ctx *c, const double *h_b1, int64_t n1, const double *h_b2
     HIPCHK(c, hipMemcpyAsync(c->b1.p, h_b1, (size_t)n1 * 32, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->b2.p, h_b2, (size_t)n2 * 32, hipMemcpyHostToDevice, c->stream));
     {
-        StageTimer tm(c, ST_IOU64);
+        StageTimer tm(c, ST_OTHER);
         hipLaunchKernelGGL(iou_f64_kernel, dim3((unsigned)((n2 + 255) / 256), (unsigned)std::min<int64_t>(n1, 4096)),
                            dim3(256), 0, c->stream, c->b1.as<double>(), n1, c->b2.as<double>(), n2,
                            c->iou_out.as<double>());
@@ -716,24 +725,12 @@ int vdet_nms_volume(vdet_ctx *c, const float *d_boxes, const float *d_scores, in
     make_plan(c, pl);
     int rc = build_graph(c, reinterpret_cast<const float4 *>(d_boxes), pl, thresh_to_f32(thresh));
     if (rc) return rc;
-    MisParams prm{};
-    prm.mode = layout;
-    prm.P = (int)(F * C);
-    prm.B = (int)B;
-    prm.C = (int)C;
-    prm.scores = d_scores;
-    prm.use_thr = use_score_thresh;
-    prm.thr = score_thresh;
-    prm.groups = c->groups.as<GroupDesc>();
-    prm.row_off = c->rowoff.as<uint32_t>();
-    prm.row_deg = c->rowdeg.as<uint16_t>();
-    prm.adj = c->adj.as<uint16_t>();
-    prm.group_z = c->groupz.as<uint32_t>();
-    prm.keep_idx = d_keep_idx;
-    prm.keep_cnt = d_keep_cnt;
-    prm.cap = cap;
-    prm.status = &c->d_cnt->status;
-    return launch_mis(c, prm, (int)B, true);
+    SortWalkArgs a{};
+    a.mode = layout; a.P = (int)(F * C); a.B = (int)B; a.C = (int)C;
+    a.scores = d_scores;
+    a.use_thr = use_score_thresh; a.thr = score_thresh;
+    a.keep_idx = d_keep_idx; a.keep_cnt = d_keep_cnt; a.cap = cap;
+    return launch_sort_walk(c, a, (int)B, F * C * B);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -106,6 +106,7 @@ def iou(boxes1, boxes2):
     out = np.empty((b1.shape[0], b2.shape[0]), dtype=np.float64)
     if out.size:
         ctx = _lib.get_context()
+        ctx.reset_stream()
         ctx.check(ctx.lib.vdet_iou_f64(ctx.h, b1.ctypes.data, b1.shape[0], b2.ctypes.data, b2.shape[0],
                                        out.ctypes.data))
     return out

@@ -41,6 +41,7 @@ def _run_nms(dets, thresh, ncols, order):
     if n == 0:
         return []
     ctx = _lib.get_context()
+    ctx.reset_stream()          # host-buffer entry points are synchronous on the context's own stream
     keep = np.empty(n, dtype=np.int64)
     nk = ctypes.c_int64(0)
     o = None
@@ -77,6 +78,7 @@ def track_det_nms(tracks, dets, thresh):
     if m == 0:
         return []
     ctx = _lib.get_context()
+    ctx.reset_stream()
     keep = np.empty(m, dtype=np.int64)
     nk = ctypes.c_int64(0)
     ldt = t.strides[0] // 4 if t.shape[0] > 1 else max(t.shape[1], 5)
