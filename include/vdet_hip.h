@@ -44,7 +44,9 @@ typedef enum vdet_status {
     VDET_EHIP = -3,      /* HIP runtime failure (RuntimeError) */
     VDET_EDIVZERO = -4,  /* zero union where the reference raises ZeroDivisionError
                             (Cython cdivision=False, utils/nms.pyx:64,122,180) */
-    VDET_ENOMEM = -5
+    VDET_ENOMEM = -5,
+    VDET_EINDEX = -6     /* where the reference raises IndexError (do_score_completion on a tubelet
+                            without any valid score, vdet/tubelet_cls.py:293-295) */
 } vdet_status;
 
 /* ---- context ------------------------------------------------------------------------------- */
@@ -98,6 +100,50 @@ int vdet_track_det_nms_f32(vdet_ctx *ctx, const float *h_tracks, int64_t t, int6
 /* iou (utils/common.py:451-468): float64 IoU matrix out[n1,n2] of boxes1[n1,4] x boxes2[n2,4]. */
 int vdet_iou_f64(vdet_ctx *ctx, const double *h_boxes1, int64_t n1, const double *h_boxes2,
                  int64_t n2, double *h_out);
+
+/* ---- tubelet re-scoring cores (host buffers, synchronous, float64 like the reference) --------- */
+
+/*
+ * Spatial max-pooling core of raw_dets_spatial_max_pooling / dets_spatial_max_pooling
+ * (vdet/tubelet_cls.py:514-532, :327-347).  T tubelet boxes h_tub_boxes[T,4]; box t lives on frame
+ * slot h_tub_group[t] whose detections are rows [h_group_off[g], h_group_off[g+1]) of
+ * h_det_boxes[M,4] / h_det_scores[M] (the class column).  Among the detections with
+ * iou > thres (strict, float64, utils/common.py:451-468) the first arg-max of the score (np.argmax:
+ * first occurrence, NaN wins): h_out_idx[t] = its index within the frame (-1: none overlaps),
+ * h_out_score[t] = its score (-1e5 when none, :529).
+ */
+int vdet_spatial_maxpool_f64(vdet_ctx *ctx, const double *h_tub_boxes, const int32_t *h_tub_group, int64_t T,
+                             const double *h_det_boxes, const double *h_det_scores,
+                             const int64_t *h_group_off, int64_t G, double thres, int64_t *h_out_idx,
+                             double *h_out_score);
+
+/*
+ * do_score_completion (vdet/tubelet_cls.py:284-303) on T ragged series h_vals[h_off[t]..h_off[t+1]),
+ * in place.  VDET_EINDEX where the reference raises IndexError (whole series <= -10).
+ */
+int vdet_series_completion_f64(vdet_ctx *ctx, double *h_vals, const int64_t *h_off, int64_t T);
+
+/* score_proto_temporal_maxpool core (vdet/tubelet_cls.py:399-412) on T ragged float64 series. */
+int vdet_series_maxpool_f64(vdet_ctx *ctx, const double *h_in, double *h_out, const int64_t *h_off,
+                            int64_t T, int window, double pad);
+
+/*
+ * score_proto_interpolation core (vdet/tubelet_cls.py:453-487; scipy interp1d linear ==
+ * numpy.interp, plus extrap1d :416-428).  Per tubelet t: knots h_x[h_koff[t]..h_koff[t+1])
+ * (ascending, >= 2), K fields stored field-major h_y[h_koff[t]*K + f*L + k]; queries
+ * h_q[h_qoff[t]..h_qoff[t+1]); results h_out[h_qoff[t]*K + f*Lq + n].
+ */
+int vdet_series_interp_f64(vdet_ctx *ctx, const double *h_x, const double *h_y, const int64_t *h_koff,
+                           const double *h_q, const int64_t *h_qoff, int64_t T, int K, double *h_out);
+
+/*
+ * Per-class threshold + top-k of ONE frame (vdet/video_det.py:89-99).  h_scores [B, ld] float32
+ * (is_f64 = 0) or float64 (1); class columns col0 .. col0+ncls-1.  Per class: inds = rows with
+ * score > thresh; if more than k: the k best by argsort(-score) (stable), in that order; else all
+ * of them in ascending row order.  h_idx [ncls, k] int32, h_cnt [ncls] int32.
+ */
+int vdet_threshold_topk(vdet_ctx *ctx, const void *h_scores, int is_f64, int64_t B, int64_t ld, int col0,
+                        int ncls, double thresh, int k, int32_t *h_idx, int32_t *h_cnt);
 
 /* ---- device-resident array forms (asynchronous; see vdet_sync) ------------------------------- */
 

@@ -206,23 +206,13 @@ def g13_ties(R, npz, index):
 
 
 # ---------------------------------------------------------------------------------------------
-CLS5 = ['__background__', 'airplane', 'antelope', 'bear', 'bicycle']
-
-
-def stub_tracker_factory(R, nan_at=None, span=3):
-    def stub_tracker(vid_proto, anchor_frame_id, anchor_bbox, opts):
-        rows, start = synth.stub_track_rows(len(vid_proto['frames']), anchor_frame_id,
-                                            list(anchor_bbox), span=span, nan_at=nan_at)
-        return R['P'].tracks_proto_from_boxes(rows, vid_proto['video'], anchor_frame_id, start, 1)
-    return stub_tracker
+CLS5 = synth.CLS5
 
 
 def g5_to_g12_protos(R, out):
     P, V, I, T, K, Cm = R['P'], R['V'], R['I'], R['T'], R['K'], R['Cm']
-    name = 'synth_vid_a'
-    F, B = 6, 40
-    vid = synth.make_vid_proto(name, F)
-    det = synth.make_det_proto(501, name, F, B, CLS5)
+    case = synth.proto_case()
+    name, F, B, vid, det = case['name'], case['F'], case['B'], case['vid'], case['det']
 
     # G5 apply_image_nms / apply_vid_nms (incl. ignored `thres`, -inf for a missing class)
     rng = np.random.RandomState(502)
@@ -241,14 +231,7 @@ def g5_to_g12_protos(R, out):
     box6 = synth.make_box_proto(601, 'synth_vid_b', Fv, Bv)
     V.imread = lambda p: None
 
-    def det_fun(net, im, orig_boxes):
-        # deterministic per-frame stand-in for the CNN: keyed on the first box
-        seed = 600 + int(orig_boxes[0][0]) + 7 * int(orig_boxes[0][1])
-        r = np.random.RandomState(seed)
-        scores = r.rand(len(orig_boxes), Cv + 1)
-        deltas = r.uniform(-5, 5, (len(orig_boxes), 4 * (Cv + 1)))
-        boxes = np.tile(orig_boxes.astype(np.float64), (1, Cv + 1)) + deltas
-        return scores, boxes
+    det_fun = synth.det_fun_case(Cv)
     import io
     import contextlib
     with contextlib.redirect_stdout(io.StringIO()):
@@ -263,14 +246,12 @@ def g5_to_g12_protos(R, out):
     # G7 greedy tracking with the stub tracker
     g7 = {}
     for tag, kw in (('plain', {}), ('nan_split', {'nan_at': 1})):
-        trk = stub_tracker_factory(R, **kw)
+        trk = synth.make_stub_tracker(P.tracks_proto_from_boxes, **kw)
         for ci in (1, 2):
             opts = Cm.options({'max_tracks': 5, 'thres': 0.2, 'nms_thres': 0.3})
             g7['%s_det_c%d' % (tag, ci)] = K.greedily_track_from_det(
                 vid, copy.deepcopy(det), trk, lambda d, ci=ci: P.det_score(d, ci), opts)
-        # raw-det twin: det_info [F*B, 5+C] f64 rows (frame, x1,y1,x2,y2, scores of classes 1..C-1)
-        det_info = np.asarray([[d['frame']] + d['bbox'] + [s['score'] for s in d['scores'][1:]]
-                               for d in det['detections']], dtype=np.float64)
+        det_info = case['det_info']
         for ci in (1, 4):
             opts = Cm.options({'max_tracks': 4, 'thres': 0.5})       # nms_thres default 0.3 (:190-193)
             g7['%s_raw_c%d' % (tag, ci)] = K.greedily_track_from_raw_dets(vid, det_info, trk, ci, opts)
@@ -281,15 +262,7 @@ def g5_to_g12_protos(R, out):
     g8 = {}
     g8['dets_c1_0.7'] = T.dets_spatial_max_pooling(vid, copy.deepcopy(track_proto), det, 1, 0.7)
     g8['dets_c2_0.3'] = T.dets_spatial_max_pooling(vid, copy.deepcopy(track_proto), det, 2, 0.3)
-    frame_to_det = {}
-    for f in range(1, F + 1):
-        ds = [d for d in det['detections'] if d['frame'] == f]
-        if f == 4:
-            continue                                            # a frame without det file (:511)
-        frame_to_det[f] = (np.asarray([d['bbox'] for d in ds], dtype=np.float64) + 0.25,
-                           np.asarray([[s['score'] for s in d['scores'][1:]] for d in ds],
-                                      dtype=np.float32))
-    frame_to_det[5] = (np.zeros((0, 4)), np.zeros((0, 4), np.float32))    # empty frame (:513)
+    frame_to_det = case['frame_to_det']
     g8['raw_c1_0.5'] = T.raw_dets_spatial_max_pooling(vid, copy.deepcopy(track_proto), frame_to_det, 1, 0.5)
     g8['raw_c3_0.7'] = T.raw_dets_spatial_max_pooling(vid, copy.deepcopy(track_proto), frame_to_det, 3, 0.7)
     out['spatial_maxpool'] = to_py(g8)
@@ -335,13 +308,7 @@ def g5_to_g12_protos(R, out):
 
     # G11 misc protocol helpers
     g11 = {}
-    annot = {'video': name, 'annotations': [
-        {'id': 0, 'track': [{'frame': f, 'bbox': [10 + f, 20, 110 + f, 140], 'class': 'airplane',
-                             'class_index': 1, 'name': 'n', 'occluded': 0, 'generated': 0}
-                            for f in range(1, 5)]},
-        {'id': 1, 'track': [{'frame': f, 'bbox': [300, 200 + f, 420, 330 + f], 'class': 'bear',
-                             'class_index': 3, 'name': 'n', 'occluded': 0, 'generated': 0}
-                            for f in range(2, 7)]}]}
+    annot = case['annot']
     g11['annot'] = annot
     g11['track_proto_from_annot_proto'] = P.track_proto_from_annot_proto(copy.deepcopy(annot))
     tubs = P.tubelets_proto_from_tracks_proto(copy.deepcopy(track_proto['tracks']), 1)
@@ -384,24 +351,9 @@ def g5_to_g12_protos(R, out):
                                load_gz_pref_eq=bool(P.proto_load(os.path.join(td, 'b.det')) == g5['1']))
 
     # score_conv_cls blob-assembly contract, pinned with a recording fake net (:19-46)
-    class Blob(object):
-        def __init__(self, c): self.shape = (1, c, 1, 1); self.data = np.zeros(self.shape, np.float32)
-        def reshape(self, *s): self.shape = tuple(s); self.data = np.zeros(s, np.float32)
-
-    class FakeNet(object):
-        def __init__(self):
-            self.blobs = {k: Blob(1) for k in ('det_scores', 'track_scores', 'anchors', 'abs_anchors',
-                                              'gt_overlaps', 'labels')}
-            self.calls = []
-        def forward(self):
-            L = self.blobs['det_scores'].shape[3]
-            self.calls.append({k: np.array(b.data).ravel().tolist() for k, b in self.blobs.items()})
-            z = self.blobs['det_scores'].data.reshape(L)
-            p1 = 1.0 / (1.0 + np.exp(-z))
-            return {'probs': np.stack([1 - p1, p1])[None].astype(np.float32)}
     sp = P.tubelets_overlap(copy.deepcopy(g8['dets_c1_0.7']['tubelets']), annot, 1)
     spr = dict(g8['dets_c1_0.7'], tubelets=sp)
-    net = FakeNet()
+    net = synth.FakeTCN()
     with contextlib.redirect_stdout(io.StringIO()):
         res = T.score_conv_cls(copy.deepcopy(spr), net)
     out['score_conv_cls'] = to_py(dict(inp=spr, blobs=net.calls, out=res))

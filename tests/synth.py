@@ -145,3 +145,81 @@ def stub_track_rows(n_frames, anchor_frame, bbox, span=3, drift=(4, 2), nan_at=N
         rows.append([bbox[0] + drift[0] * d, bbox[1] + drift[1] * d,
                      bbox[2] + drift[0] * d, bbox[3] + drift[1] * d, 1.0 / (1 + abs(d))])
     return np.asarray(rows, dtype=np.float64), start
+
+
+# ---------------------------------------------------------------------------------------------
+# the protocol-level golden case (shared by tests/golden/make_golden.py and the tests)
+# ---------------------------------------------------------------------------------------------
+CLS5 = ['__background__', 'airplane', 'antelope', 'bear', 'bicycle']
+
+
+def proto_case():
+    name = 'synth_vid_a'
+    F, B = 6, 40
+    vid = make_vid_proto(name, F)
+    det = make_det_proto(501, name, F, B, CLS5)
+    det_info = np.asarray([[d['frame']] + d['bbox'] + [s['score'] for s in d['scores'][1:]]
+                           for d in det['detections']], dtype=np.float64)
+    frame_to_det = {}
+    for f in range(1, F + 1):
+        ds = [d for d in det['detections'] if d['frame'] == f]
+        if f == 4:
+            continue                                            # a frame without a det file
+        frame_to_det[f] = (np.asarray([d['bbox'] for d in ds], dtype=np.float64) + 0.25,
+                           np.asarray([[s['score'] for s in d['scores'][1:]] for d in ds], dtype=np.float32))
+    frame_to_det[5] = (np.zeros((0, 4)), np.zeros((0, 4), np.float32))    # an empty frame
+    annot = {'video': name, 'annotations': [
+        {'id': 0, 'track': [{'frame': f, 'bbox': [10 + f, 20, 110 + f, 140], 'class': 'airplane',
+                             'class_index': 1, 'name': 'n', 'occluded': 0, 'generated': 0}
+                            for f in range(1, 5)]},
+        {'id': 1, 'track': [{'frame': f, 'bbox': [300, 200 + f, 420, 330 + f], 'class': 'bear',
+                             'class_index': 3, 'name': 'n', 'occluded': 0, 'generated': 0}
+                            for f in range(2, 7)]}]}
+    return dict(name=name, F=F, B=B, vid=vid, det=det, det_info=det_info, frame_to_det=frame_to_det,
+                annot=annot)
+
+
+def det_fun_case(Cv=4):
+    """Deterministic stand-in for the CNN of fast_rcnn_det_vid (keyed on the first proposal)."""
+    def det_fun(net, im, orig_boxes):
+        seed = 600 + int(orig_boxes[0][0]) + 7 * int(orig_boxes[0][1])
+        r = np.random.RandomState(seed)
+        scores = r.rand(len(orig_boxes), Cv + 1)
+        deltas = r.uniform(-5, 5, (len(orig_boxes), 4 * (Cv + 1)))
+        boxes = np.tile(orig_boxes.astype(np.float64), (1, Cv + 1)) + deltas
+        return scores, boxes
+    return det_fun
+
+
+def make_stub_tracker(tracks_proto_from_boxes, nan_at=None, span=3):
+    """track_method plug-in built on either the reference's or the build's tracks_proto_from_boxes."""
+    def stub_tracker(vid_proto, anchor_frame_id, anchor_bbox, opts):
+        rows, start = stub_track_rows(len(vid_proto['frames']), anchor_frame_id, list(anchor_bbox),
+                                      span=span, nan_at=nan_at)
+        return tracks_proto_from_boxes(rows, vid_proto['video'], anchor_frame_id, start, 1)
+    return stub_tracker
+
+
+class FakeTCN(object):
+    """Recording pycaffe-like net for score_conv_cls: probs[1] = sigmoid(det_scores)."""
+
+    class Blob(object):
+        def __init__(self, c):
+            self.shape = (1, c, 1, 1)
+            self.data = np.zeros(self.shape, np.float32)
+
+        def reshape(self, *s):
+            self.shape = tuple(s)
+            self.data = np.zeros(s, np.float32)
+
+    def __init__(self):
+        self.blobs = {k: FakeTCN.Blob(1) for k in ('det_scores', 'track_scores', 'anchors', 'abs_anchors',
+                                                  'gt_overlaps', 'labels')}
+        self.calls = []
+
+    def forward(self):
+        L = self.blobs['det_scores'].shape[3]
+        self.calls.append({k: np.array(b.data).ravel().tolist() for k, b in self.blobs.items()})
+        z = self.blobs['det_scores'].data.reshape(L)
+        p1 = 1.0 / (1.0 + np.exp(-z))
+        return {'probs': np.stack([1 - p1, p1])[None].astype(np.float32)}

@@ -11,7 +11,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvdet_hip.so")
 
-VDET_OK, VDET_EINVAL, VDET_ECAP, VDET_EHIP, VDET_EDIVZERO, VDET_ENOMEM = 0, -1, -2, -3, -4, -5
+VDET_OK, VDET_EINVAL, VDET_ECAP, VDET_EHIP, VDET_EDIVZERO, VDET_ENOMEM, VDET_EINDEX = 0, -1, -2, -3, -4, -5, -6
 LAYOUT_FBC, LAYOUT_FCB = 0, 1
 
 # every symbol include/vdet_hip.h declares: (name, restype, argtypes)
@@ -30,6 +30,11 @@ SYMBOLS = {
     "vdet_nms_f32": (_ci, [_vp, _vp, _i64, _i64, _ci, _f64, _vp, _vp, ctypes.POINTER(_i64)]),
     "vdet_track_det_nms_f32": (_ci, [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _f64, _vp, ctypes.POINTER(_i64)]),
     "vdet_iou_f64": (_ci, [_vp, _vp, _i64, _vp, _i64, _vp]),
+    "vdet_spatial_maxpool_f64": (_ci, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _f64, _vp, _vp]),
+    "vdet_series_completion_f64": (_ci, [_vp, _vp, _vp, _i64]),
+    "vdet_series_maxpool_f64": (_ci, [_vp, _vp, _vp, _vp, _i64, _ci, _f64]),
+    "vdet_series_interp_f64": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _ci, _vp]),
+    "vdet_threshold_topk": (_ci, [_vp, _vp, _ci, _i64, _i64, _ci, _ci, _f64, _ci, _vp, _vp]),
     "vdet_nms_volume": (_ci, [_vp, _vp, _vp, _ci, _i64, _i64, _i64, _f64, _ci, _f32, _vp, _vp, _i64]),
     "vdet_temporal_maxpool_f32": (_ci, [_vp, _vp, _vp, _i64, _i64, _ci, _f32]),
     "vdet_temporal_conv_f32": (_ci, [_vp, _vp, _vp, _i64, _i64, _vp, _ci, _f32, _f32]),
@@ -114,6 +119,8 @@ class Context(object):
             raise ValueError(msg or "invalid argument")
         if rc == VDET_ENOMEM:
             raise MemoryError(msg)
+        if rc == VDET_EINDEX:
+            raise IndexError(msg or "list index out of range")
         raise RuntimeError("libvdet_hip: %s (rc=%d)" % (msg, rc))
 
     def set_stream(self, stream_ptr):

@@ -16,6 +16,7 @@
 #include "../../include/vdet_hip.h"
 #include "nms_kernels.hpp"
 #include "temporal_kernels.hpp"
+#include "tubelet_kernels.hpp"
 
 using namespace vdet;
 
@@ -70,7 +71,7 @@ struct vdet_ctx {
     int n_cu = 256;
     // scratch
     DevBuf boxes, scores, keys, excl, frames, groups, tiles, bits, rowz, rowoff, rowdeg, groupz, adj, comp, origidx,
-        out64, trk_frames, trk_boxes, b1, b2, iou_out, order, ncand, keepidx, keepcnt;
+        out64, trk_frames, trk_boxes, b1, b2, iou_out, order, ncand, keepidx, keepcnt, tmp[8];
     // timing
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -79,6 +80,7 @@ struct vdet_ctx {
     float last_ms[8] = {0};
     int last_launches[8] = {0};
     bool sort_attr_set = false;
+    bool topk_attr_set = false;
     size_t dyn_lds_max = 0;
 };
 
@@ -489,6 +491,7 @@ int vdet_destroy(vdet_ctx *c)
                       &c->trk_frames, &c->trk_boxes, &c->b1, &c->b2, &c->iou_out, &c->order, &c->ncand, &c->keepidx,
                       &c->keepcnt};
     for (DevBuf *b : bufs) b->release();
+    for (DevBuf &b : c->tmp) b.release();
     for (auto &e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (c->d_cnt) (void)hipFree(c->d_cnt);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -731,6 +734,181 @@ int vdet_nms_volume(vdet_ctx *c, const float *d_boxes, const float *d_scores, in
     a.use_thr = use_score_thresh; a.thr = score_thresh;
     a.keep_idx = d_keep_idx; a.keep_cnt = d_keep_cnt; a.cap = cap;
     return launch_sort_walk(c, a, (int)B, F * C * B);
+}
+
+// ---------------------------------------------------------------------------------------------
+// tubelet re-scoring cores (host buffers)
+// ---------------------------------------------------------------------------------------------
+static int upload(vdet_ctx *c, DevBuf &b, const void *h, size_t bytes)
+{
+    HIPCHK(c, b.reserve(std::max<size_t>(bytes, 16)));
+    if (bytes) HIPCHK(c, hipMemcpyAsync(b.p, h, bytes, hipMemcpyHostToDevice, c->stream));
+    return VDET_OK;
+}
+
+static int status_word(vdet_ctx *c, int *out)
+{
+    Counters h;
+    HIPCHK(c, hipMemcpyAsync(&h, c->d_cnt, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *out = h.status;
+    return VDET_OK;
+}
+
+int vdet_spatial_maxpool_f64(vdet_ctx *c, const double *h_tub_boxes, const int32_t *h_tub_group, int64_t T,
+                             const double *h_det_boxes, const double *h_det_scores, const int64_t *h_group_off,
+                             int64_t G, double thres, int64_t *h_out_idx, double *h_out_score)
+{
+    if (!c || T < 0 || G < 0) return VDET_EINVAL;
+    if (T == 0) return VDET_OK;
+    if (!h_tub_boxes || !h_tub_group || !h_group_off || !h_out_idx || !h_out_score || G == 0)
+        return fail(c, VDET_EINVAL, "null buffer");
+    const int64_t M = h_group_off[G];
+    for (int64_t t = 0; t < T; ++t)
+        if (h_tub_group[t] < 0 || h_tub_group[t] >= G) return fail(c, VDET_EINVAL, "tubelet frame slot out of range");
+    HIPCHK(c, hipSetDevice(c->device));
+    timing_reset(c);
+    int rc;
+    if ((rc = upload(c, c->tmp[0], h_tub_boxes, (size_t)T * 32))) return rc;
+    if ((rc = upload(c, c->tmp[1], h_tub_group, (size_t)T * 4))) return rc;
+    if ((rc = upload(c, c->tmp[2], h_det_boxes, (size_t)M * 32))) return rc;
+    if ((rc = upload(c, c->tmp[3], h_det_scores, (size_t)M * 8))) return rc;
+    if ((rc = upload(c, c->tmp[4], h_group_off, (size_t)(G + 1) * 8))) return rc;
+    HIPCHK(c, c->tmp[5].reserve((size_t)T * 8));
+    HIPCHK(c, c->tmp[6].reserve((size_t)T * 8));
+    {
+        StageTimer tm(c, ST_OTHER);
+        hipLaunchKernelGGL(spatial_maxpool_kernel, dim3((unsigned)T), dim3(256), 0, c->stream, c->tmp[0].as<double>(),
+                           c->tmp[1].as<int32_t>(), c->tmp[2].as<double>(), c->tmp[3].as<double>(),
+                           c->tmp[4].as<int64_t>(), thres, c->tmp[5].as<int64_t>(), c->tmp[6].as<double>());
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(h_out_idx, c->tmp[5].p, (size_t)T * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(h_out_score, c->tmp[6].p, (size_t)T * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VDET_OK;
+}
+
+int vdet_series_completion_f64(vdet_ctx *c, double *h_vals, const int64_t *h_off, int64_t T)
+{
+    if (!c || T < 0) return VDET_EINVAL;
+    if (T == 0) return VDET_OK;
+    if (!h_off) return fail(c, VDET_EINVAL, "null buffer");
+    const int64_t n = h_off[T];
+    if (n > 0 && !h_vals) return fail(c, VDET_EINVAL, "null buffer");
+    HIPCHK(c, hipSetDevice(c->device));
+    timing_reset(c);
+    int rc;
+    if ((rc = upload(c, c->tmp[0], h_vals, (size_t)n * 8))) return rc;
+    if ((rc = upload(c, c->tmp[1], h_off, (size_t)(T + 1) * 8))) return rc;
+    HIPCHK(c, hipMemsetAsync(&c->d_cnt->status, 0, sizeof(int), c->stream));
+    hipLaunchKernelGGL(series_completion_kernel, dim3((unsigned)((T + 63) / 64)), dim3(64), 0, c->stream,
+                       c->tmp[0].as<double>(), c->tmp[1].as<int64_t>(), T, &c->d_cnt->status);
+    HIPCHK(c, hipGetLastError());
+    if (n) HIPCHK(c, hipMemcpyAsync(h_vals, c->tmp[0].p, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    int st = 0;
+    if ((rc = status_word(c, &st))) return rc;
+    HIPCHK(c, hipMemsetAsync(&c->d_cnt->status, 0, sizeof(int), c->stream));
+    if (st) return fail(c, VDET_EINDEX, "list index out of range");
+    return VDET_OK;
+}
+
+int vdet_series_maxpool_f64(vdet_ctx *c, const double *h_in, double *h_out, const int64_t *h_off, int64_t T,
+                            int window, double pad)
+{
+    if (!c || T < 0) return VDET_EINVAL;
+    if (window < 1 || window % 2 != 1) return fail(c, VDET_EINVAL, "Window size must be odd!");
+    if (T == 0) return VDET_OK;
+    if (!h_off) return fail(c, VDET_EINVAL, "null buffer");
+    const int64_t n = h_off[T];
+    if (n == 0) return VDET_OK;
+    if (!h_in || !h_out) return fail(c, VDET_EINVAL, "null buffer");
+    std::vector<int32_t> es((size_t)n);
+    for (int64_t t = 0; t < T; ++t)
+        for (int64_t e = h_off[t]; e < h_off[t + 1]; ++e) es[(size_t)e] = (int32_t)t;
+    HIPCHK(c, hipSetDevice(c->device));
+    timing_reset(c);
+    int rc;
+    if ((rc = upload(c, c->tmp[0], h_in, (size_t)n * 8))) return rc;
+    if ((rc = upload(c, c->tmp[1], h_off, (size_t)(T + 1) * 8))) return rc;
+    if ((rc = upload(c, c->tmp[2], es.data(), (size_t)n * 4))) return rc;
+    HIPCHK(c, c->tmp[3].reserve((size_t)n * 8));
+    hipLaunchKernelGGL(series_maxpool_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
+                       c->tmp[0].as<double>(), c->tmp[3].as<double>(), c->tmp[1].as<int64_t>(),
+                       c->tmp[2].as<int32_t>(), n, window, pad);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(h_out, c->tmp[3].p, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VDET_OK;
+}
+
+int vdet_series_interp_f64(vdet_ctx *c, const double *h_x, const double *h_y, const int64_t *h_koff,
+                           const double *h_q, const int64_t *h_qoff, int64_t T, int K, double *h_out)
+{
+    if (!c || T < 0 || K < 1) return VDET_EINVAL;
+    if (T == 0) return VDET_OK;
+    if (!h_x || !h_y || !h_koff || !h_q || !h_qoff || !h_out) return fail(c, VDET_EINVAL, "null buffer");
+    const int64_t nk = h_koff[T], nq = h_qoff[T];
+    for (int64_t t = 0; t < T; ++t)
+        if (h_koff[t + 1] - h_koff[t] < 2) return fail(c, VDET_EINVAL, "interpolation needs at least 2 knots");
+    if (nq == 0) return VDET_OK;
+    std::vector<int32_t> qs((size_t)nq);
+    for (int64_t t = 0; t < T; ++t)
+        for (int64_t e = h_qoff[t]; e < h_qoff[t + 1]; ++e) qs[(size_t)e] = (int32_t)t;
+    HIPCHK(c, hipSetDevice(c->device));
+    timing_reset(c);
+    int rc;
+    if ((rc = upload(c, c->tmp[0], h_x, (size_t)nk * 8))) return rc;
+    if ((rc = upload(c, c->tmp[1], h_y, (size_t)nk * K * 8))) return rc;
+    if ((rc = upload(c, c->tmp[2], h_koff, (size_t)(T + 1) * 8))) return rc;
+    if ((rc = upload(c, c->tmp[3], h_q, (size_t)nq * 8))) return rc;
+    if ((rc = upload(c, c->tmp[4], h_qoff, (size_t)(T + 1) * 8))) return rc;
+    if ((rc = upload(c, c->tmp[5], qs.data(), (size_t)nq * 4))) return rc;
+    HIPCHK(c, c->tmp[6].reserve((size_t)nq * K * 8));
+    hipLaunchKernelGGL(series_interp_kernel, dim3((unsigned)((nq * K + 255) / 256)), dim3(256), 0, c->stream,
+                       c->tmp[0].as<double>(), c->tmp[1].as<double>(), c->tmp[2].as<int64_t>(), c->tmp[3].as<double>(),
+                       c->tmp[4].as<int64_t>(), c->tmp[5].as<int32_t>(), nq, K, c->tmp[6].as<double>());
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(h_out, c->tmp[6].p, (size_t)nq * K * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VDET_OK;
+}
+
+int vdet_threshold_topk(vdet_ctx *c, const void *h_scores, int is_f64, int64_t B, int64_t ld, int col0, int ncls,
+                        double thresh, int k, int32_t *h_idx, int32_t *h_cnt)
+{
+    if (!c || B < 0 || ncls < 0 || k < 0 || col0 < 0 || ld < col0 + ncls) return VDET_EINVAL;
+    if (ncls == 0) return VDET_OK;
+    if (!h_cnt || (k > 0 && !h_idx)) return fail(c, VDET_EINVAL, "null buffer");
+    if (B == 0) { memset(h_cnt, 0, (size_t)ncls * 4); return VDET_OK; }
+    if (!h_scores) return fail(c, VDET_EINVAL, "null buffer");
+    const size_t es = is_f64 ? 8 : 4;
+    const size_t lds = ((es * B + 15) & ~(size_t)15) + (((size_t)4 * B + 15) & ~(size_t)15) + 4 * 260;
+    HIPCHK(c, hipSetDevice(c->device));
+    timing_reset(c);
+    if (!c->topk_attr_set) {
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(threshold_topk_kernel<float>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->max_lds));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(threshold_topk_kernel<double>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->max_lds));
+        c->topk_attr_set = true;
+    }
+    if (lds > c->max_lds) return fail(c, VDET_EINVAL, "too many boxes per frame for threshold_topk (%lld)", (long long)B);
+    int rc;
+    if ((rc = upload(c, c->tmp[0], h_scores, (size_t)B * ld * es))) return rc;
+    HIPCHK(c, c->tmp[1].reserve((size_t)ncls * std::max(k, 1) * 4));
+    HIPCHK(c, c->tmp[2].reserve((size_t)ncls * 4));
+    if (is_f64)
+        hipLaunchKernelGGL(threshold_topk_kernel<double>, dim3(ncls), dim3(256), lds, c->stream, c->tmp[0].as<double>(),
+                           B, ld, col0, thresh, k, c->tmp[1].as<int32_t>(), c->tmp[2].as<int32_t>());
+    else
+        hipLaunchKernelGGL(threshold_topk_kernel<float>, dim3(ncls), dim3(256), lds, c->stream, c->tmp[0].as<float>(),
+                           B, ld, col0, thresh, k, c->tmp[1].as<int32_t>(), c->tmp[2].as<int32_t>());
+    HIPCHK(c, hipGetLastError());
+    if (k > 0) HIPCHK(c, hipMemcpyAsync(h_idx, c->tmp[1].p, (size_t)ncls * k * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(h_cnt, c->tmp[2].p, (size_t)ncls * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VDET_OK;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -1,0 +1,259 @@
+"""Tubelet re-scoring of the reference's vdet/tubelet_cls.py: spatial max-pooling of detection
+scores onto tubelet boxes, gap completion, temporal max-pooling, interpolation, and the channel
+assembly of the temporal-convolution scorer.  Dict plumbing in python, every numeric core on the
+GPU (vdetlib_amd.hot -> include/vdet_hip.h).
+
+Out of scope (external Caffe/SVM engines): fast_rcnn_cls, googlenet_cls,
+rcnn_scoring, rcnn_sampling_scoring, rcnn_sampling_dets_scoring, sampling_boxes (:53-260).
+"""
+import copy
+from collections import defaultdict
+
+import numpy as np
+
+from ..utils.protocol import tubelets_overlap, tubelets_proto_from_tracks_proto
+from ..utils.common import iou
+from ..utils.log import logger as logging
+from .dataset import imagenet_vdet_classes
+from .. import hot
+
+
+def score_conv_cls(score_proto, net):
+    """:15-51 -- feeds each tubelet's channel sequences to a temporal-convolution net and stores
+    probs[:,1,:] as box['conv_score'].  ``net`` is any object with ``.blobs`` (name -> object with
+    ``.shape``, ``.reshape(*dims)``, ``.data``) and ``.forward() -> {'probs': [1,2,L]}`` -- pycaffe's
+    interface; ``vdetlib_amd.vdet.tcn.TCNNet`` is a gfx950 implementation of it."""
+    new_score_proto = copy.copy(score_proto)
+    print("{}: {} tubelet(s).".format(score_proto['video'], len(new_score_proto['tubelets'])))
+    for tubelet in new_score_proto['tubelets']:
+        boxes = tubelet['boxes']
+        track = {'length': len(boxes), 'gt': tubelet['gt']}
+        track['mean_iou'] = np.mean([[b['gt_overlap'] for b in boxes]])
+        track['det_scores'] = [b['det_score'] for b in boxes]
+        track['track_scores'] = [b['track_score'] for b in boxes]
+        track['anchors'] = [b['anchor'] * 1. / track['length'] for b in boxes]
+        track['abs_anchors'] = [abs(a) for a in track['anchors']]
+        track['gt_overlaps'] = [b['gt_overlap'] for b in boxes]
+        track['labels'] = [1 if ov >= 0.5 else 0 for ov in track['gt_overlaps']]
+        if 'all_scores' in net.blobs.keys():
+            track['all_scores'] = [b['all_score'] for b in boxes]
+        if 'feats' in net.blobs.keys():
+            track['feats'] = [b['feat'] for b in boxes]
+        for blob_name in set(net.blobs.keys()).intersection(set(track.keys())):
+            num_channels = net.blobs[blob_name].shape[1]
+            net.blobs[blob_name].reshape(1, num_channels, 1, track['length'])
+            net.blobs[blob_name].data[...] = np.asarray(track[blob_name], dtype='float32')
+        blobs_out = net.forward()
+        probs = blobs_out['probs'][:, 1, :]
+        for box, prob in zip(boxes, np.asarray(probs).ravel()):
+            box['conv_score'] = float(prob)
+    return new_score_proto
+
+
+def scoring_tracks(vid_proto, track_proto, annot_proto, sc_method, net, class_idx):
+    """:263-273"""
+    assert vid_proto['video'] == track_proto['video']
+    tubelets_proto = sc_method(vid_proto, track_proto, net, class_idx)
+    if annot_proto is not None:
+        tubelets_proto = tubelets_overlap(tubelets_proto, annot_proto, class_idx)
+    return {'video': vid_proto['video'], 'method': sc_method.__name__, 'tubelets': tubelets_proto}
+
+
+def classify_tracks(video_proto, track_proto, cls_method, net, class_idx):
+    """:276-282"""
+    assert video_proto['video'] == track_proto['video']
+    return {'video': video_proto['video'], 'method': cls_method.__name__,
+            'tracks': cls_method(video_proto, track_proto, net, class_idx)}
+
+
+def do_score_completion(score_proto):
+    """:284-303 -- in place: runs of det_score <= -10 are filled (edge extension / linear
+    interpolation).  IndexError, like the reference, for a tubelet with no valid score at all."""
+    tubelets = score_proto['tubelets']
+    series = [[box['det_score'] for box in tubelet['boxes']] for tubelet in tubelets]
+    done = hot.series_completion(series)
+    for tubelet, new in zip(tubelets, done):
+        for box, old, v in zip(tubelet['boxes'], [b['det_score'] for b in tubelet['boxes']], new):
+            if old <= -10:            # untouched entries keep their python object (int stays int)
+                box['det_score'] = float(v)
+
+
+def _spatial_max_pooling(vid_proto, tubelets_proto, frame_dets, overlap_thres):
+    """Shared core of :316-347 / :504-532.  frame_dets: frame_id -> (det_boxes array, det_scores
+    1-D array) for the frames that have detections."""
+    frame_to_tubelets_idx = defaultdict(list)
+    for i, tubelet in enumerate(tubelets_proto):
+        for j, box in enumerate(tubelet['boxes']):
+            frame_to_tubelets_idx[box['frame']].append((i, j))
+    slots, det_boxes_list, det_scores_list = {}, [], []
+    tub_boxes, tub_group, targets = [], [], []
+    for frame in vid_proto['frames']:
+        frame_id = frame['frame']
+        if frame_id not in frame_dets:
+            continue
+        for i, j in frame_to_tubelets_idx[frame_id]:
+            cur_box = tubelets_proto[i]['boxes'][j]
+            if cur_box is None:
+                continue
+            if frame_id not in slots:
+                slots[frame_id] = len(det_boxes_list)
+                det_boxes_list.append(frame_dets[frame_id][0])
+                det_scores_list.append(frame_dets[frame_id][1])
+            tub_boxes.append(cur_box['bbox'])
+            tub_group.append(slots[frame_id])
+            targets.append((i, j, frame_id))
+    idx, score = hot.spatial_maxpool(tub_boxes, tub_group, det_boxes_list, det_scores_list, overlap_thres)
+    for (i, j, frame_id), k, s in zip(targets, idx, score):
+        cur_box = tubelets_proto[i]['boxes'][j]
+        if k >= 0:
+            cur_box['det_score'] = float(s)
+            cur_box['bbox'] = frame_dets[frame_id][0][int(k)].tolist()
+        else:
+            print("Warning: Tubelet {} has no overlapping dets (IOU > {}).".format(i, overlap_thres))
+            cur_box['det_score'] = float(-1e5)
+
+
+def dets_spatial_max_pooling(vid_proto, track_proto, det_proto, class_idx, overlap_thres=0.7):
+    """:305-350 -- detections as protocol dicts; the class score is read BY POSITION
+    ``det['scores'][class_idx - 1]['score']`` (:329)."""
+    assert vid_proto['video'] == track_proto['video']
+    score_proto = {'video': vid_proto['video'],
+                   'method': "spatial_max_pooling_IOU_{}".format(overlap_thres)}
+    tubelets_proto = tubelets_proto_from_tracks_proto(track_proto['tracks'], class_idx)
+    logging.info("Sampling dets in {} for {}...".format(vid_proto['video'], imagenet_vdet_classes[class_idx]))
+    frame_to_det_idx = defaultdict(list)
+    for i, det in enumerate(det_proto['detections']):
+        frame_to_det_idx[det['frame']].append(i)
+    frame_dets = {}
+    for frame_id, det_idx in frame_to_det_idx.items():
+        frame_dets[frame_id] = (
+            np.asarray([det_proto['detections'][i]['bbox'] for i in det_idx]),
+            np.asarray([det_proto['detections'][i]['scores'][class_idx - 1]['score'] for i in det_idx]))
+    _spatial_max_pooling(vid_proto, tubelets_proto, frame_dets, overlap_thres)
+    score_proto['tubelets'] = tubelets_proto
+    do_score_completion(score_proto)
+    return score_proto
+
+
+def anchor_propagate(vid_proto, track_proto, det_proto, class_idx):
+    """:353-383 -- every box of a tubelet gets the class score of the detection that overlaps the
+    anchor box (anchor == 0) most."""
+    assert vid_proto['video'] == track_proto['video']
+    tubelets_proto = tubelets_proto_from_tracks_proto(track_proto['tracks'], class_idx)
+    logging.info("Propagating anchor scores in {} for {}...".format(vid_proto['video'],
+                                                                     imagenet_vdet_classes[class_idx]))
+    frame_to_det_idx = defaultdict(list)
+    for i, det in enumerate(det_proto['detections']):
+        frame_to_det_idx[det['frame']].append(i)
+    for tubelet in tubelets_proto:
+        anchor_box = [box for box in tubelet['boxes'] if box['anchor'] == 0]
+        assert len(anchor_box) == 1
+        anchor_box = anchor_box[0]
+        det_idx = frame_to_det_idx[anchor_box['frame']]
+        det_boxes = np.asarray([det_proto['detections'][i]['bbox'] for i in det_idx])
+        det_scores = np.asarray([det_proto['detections'][i]['scores'][class_idx - 1]['score'] for i in det_idx])
+        overlaps = iou([anchor_box['bbox']], det_boxes)[0]
+        anchor_score = det_scores[np.argmax(overlaps)]
+        for box in tubelet['boxes']:
+            box['det_score'] = anchor_score
+    return {'video': vid_proto['video'], 'method': "anchor_propagate", 'tubelets': tubelets_proto}
+
+
+def score_proto_temporal_maxpool(score_proto, window_size):
+    """:386-414 -- centred sliding max of det_score per tubelet (out-of-range = -1e5), written back
+    into the SAME box dicts; the returned proto is a shallow copy whose method gets the suffix
+    '_temporal_maxpool_{w}'.  Raises on an even window and on ground-truth tubelets (after having
+    processed the tubelets before it, like the reference)."""
+    if window_size == 1:
+        return score_proto
+    if window_size % 2 != 1:
+        raise ValueError('Window size must be odd!')
+    new_score_proto = copy.copy(score_proto)
+    new_score_proto['method'] += '_temporal_maxpool_{}'.format(window_size)
+    tubelets = new_score_proto['tubelets']
+    n_ok = len(tubelets)
+    for t, tubelet in enumerate(tubelets):
+        if tubelet['gt'] == 1:
+            n_ok = t
+            break
+    series = [[box['det_score'] for box in tubelet['boxes']] for tubelet in tubelets[:n_ok]]
+    pooled = hot.series_maxpool(series, window_size, -1e+5)
+    for tubelet, new in zip(tubelets[:n_ok], pooled):
+        for box, v in zip(tubelet['boxes'], new):
+            box['det_score'] = float(v)
+    if n_ok < len(tubelets):
+        raise ValueError('Dangerous: Score file contains gt tracks!')
+    return new_score_proto
+
+
+def extrap1d(interpolator):
+    """:416-428 -- point-wise linear extrapolation wrapper around a scipy interp1d-like object
+    (kept for API compatibility; score_proto_interpolation does not need it here)."""
+    xs, ys = interpolator.x, interpolator.y
+
+    def pointwise(x):
+        if x < xs[0]:
+            return ys[0] + (x - xs[0]) * (ys[1] - ys[0]) / (xs[1] - xs[0])
+        elif x > xs[-1]:
+            return ys[-1] + (x - xs[-1]) * (ys[-1] - ys[-2]) / (xs[-1] - xs[-2])
+        return interpolator(x)
+    return pointwise
+
+
+def score_proto_interpolation(score_proto, vid_proto):
+    """:430-490 -- per tubelet with >= 2 boxes: linear interpolation of x1,y1,x2,y2,det_score,
+    anchor to every integer frame of [min, max] (min 2 -> 1 and max F-1 -> F by one-step
+    extrapolation, :472-475).  Output boxes carry only frame, det_score, anchor, bbox."""
+    new_score_proto = {'video': score_proto['video'], 'method': score_proto['method'] + '_interpolation'}
+    max_frames = len(vid_proto['frames'])
+    out = []
+    jobs = []
+    for tubelet in score_proto['tubelets']:
+        if tubelet['gt'] == 1:
+            raise ValueError('Dangerous: Score file contains gt tracks!')
+        if len(tubelet['boxes']) < 2:
+            out.append(copy.copy(tubelet))
+            continue
+        truth_idx = [box['frame'] for box in tubelet['boxes']]
+        fields = np.asarray([[box['bbox'][0], box['bbox'][1], box['bbox'][2], box['bbox'][3],
+                              box['det_score'], box['anchor']] for box in tubelet['boxes']], dtype=np.float64)
+        order = np.argsort(np.asarray(truth_idx), kind='stable')      # interp1d sorts its knots
+        min_idx, max_idx = min(truth_idx), max(truth_idx)
+        if min_idx == 2:
+            min_idx = 1
+        if max_idx == max_frames - 1:
+            max_idx = max_frames
+        new_tubelet = {}
+        for key in ['gt', 'class', 'class_index']:
+            new_tubelet[key] = tubelet[key]
+        new_tubelet['boxes'] = []
+        out.append(new_tubelet)
+        jobs.append((new_tubelet, np.asarray(truth_idx, dtype=np.float64)[order], fields[order],
+                     list(range(min_idx, max_idx + 1))))
+    dense = hot.series_interp([j[1] for j in jobs], [j[2] for j in jobs], [j[3] for j in jobs])
+    for (new_tubelet, _, _, frames), vals in zip(jobs, dense):
+        for dense_idx, v in zip(frames, vals):
+            new_tubelet['boxes'].append({'frame': dense_idx, 'det_score': float(v[4]), 'anchor': float(v[5]),
+                                         'bbox': [float(v[0]), float(v[1]), float(v[2]), float(v[3])]})
+    new_score_proto['tubelets'] = out
+    return new_score_proto
+
+
+def raw_dets_spatial_max_pooling(vid_proto, track_proto, frame_to_det, class_idx, overlap_thres=0.7):
+    """:493-535 -- detections as per-frame arrays {frame_id: (boxes [B,4], zs [B,C])}; class
+    column zs[:, class_idx - 1] (:514).  Frames missing from frame_to_det or without boxes are
+    skipped (:511-513)."""
+    assert vid_proto['video'] == track_proto['video']
+    score_proto = {'video': vid_proto['video'],
+                   'method': "spatial_max_pooling_IOU_{}".format(overlap_thres)}
+    tubelets_proto = tubelets_proto_from_tracks_proto(track_proto['tracks'], class_idx)
+    logging.info("Sampling dets in {} for {}...".format(vid_proto['video'], imagenet_vdet_classes[class_idx]))
+    frame_dets = {}
+    for frame_id, (det_boxes, det_scores) in frame_to_det.items():
+        if np.asarray(det_boxes).size == 0:
+            continue
+        frame_dets[frame_id] = (np.asarray(det_boxes), np.asarray(det_scores)[:, class_idx - 1].ravel())
+    _spatial_max_pooling(vid_proto, tubelets_proto, frame_dets, overlap_thres)
+    score_proto['tubelets'] = tubelets_proto
+    do_score_completion(score_proto)
+    return score_proto
