@@ -58,17 +58,12 @@ def main():
     import torch
     import torch.distributed as dist
     from vdetlib_amd import ops, _lib
+    from vdetlib_amd import dist as vdist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    world, rank, local = vdist.env_world()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+    vdist.init(backend="nccl" if world > 1 else None, device=dev)
     F, B, C = args.frames, args.boxes, args.classes
     TOPK = 100
 
@@ -80,13 +75,9 @@ def main():
         nonlocal gathered
         keep_idx, keep_cnt = ops.nms_volume(boxes, scores, args.thresh, cap=args.cap, sync=False)
         pooled = ops.temporal_maxpool(scores, args.window)
-        if world > 1:   # RCCL all-gather of the per-video results over xGMI
+        if world > 1:   # the one exchange step: RCCL all-gather of the per-video results over xGMI
             top = keep_idx[:, :, :TOPK].contiguous()
-            g_idx = torch.empty((world,) + tuple(top.shape), dtype=top.dtype, device=dev)
-            g_cnt = torch.empty((world,) + tuple(keep_cnt.shape), dtype=keep_cnt.dtype, device=dev)
-            dist.all_gather_into_tensor(g_idx, top)
-            dist.all_gather_into_tensor(g_cnt, keep_cnt)
-            gathered = (g_idx, g_cnt)
+            gathered = vdist.gather_video_results([rank], top[None], torch.clamp(keep_cnt, max=TOPK)[None])
         return keep_idx, keep_cnt, pooled
 
     def fence():

@@ -1,0 +1,70 @@
+"""CPU-only: the N > 1 path (video sharding + the single result exchange) with world_size 2 on the
+gloo backend -- same code that runs on RCCL across 8 MI355X."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from vdetlib_amd import dist as vd
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _fake_result(video_id, F, C, K):
+    rng = np.random.RandomState(video_id)
+    cnt = rng.randint(0, K + 1, (F, C)).astype(np.int32)
+    idx = rng.randint(0, 1000, (F, C, K)).astype(np.int32)
+    return torch.from_numpy(idx), torch.from_numpy(cnt)
+
+
+def _worker(rank, world, port, n_videos, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank),
+                      LOCAL_RANK=str(rank))
+    w, r, _ = vd.init(backend="gloo")
+    assert (w, r) == (world, rank)
+    mine = vd.shard_round_robin(n_videos, rank, world)
+    F, C, K = 3, 4, 5
+    res = [_fake_result(v, F, C, K) for v in mine]
+    idx = torch.stack([a for a, _ in res]) if res else torch.zeros((0, F, C, K), dtype=torch.int32)
+    cnt = torch.stack([b for _, b in res]) if res else torch.zeros((0, F, C), dtype=torch.int32)
+    allres = vd.gather_video_results(mine, idx, cnt)
+    ok = sorted(allres) == list(range(n_videos))
+    for v in range(n_videos):
+        a, b = _fake_result(v, F, C, K)
+        ok = ok and torch.equal(allres[v][0], a) and torch.equal(allres[v][1], b)
+    # ragged gather with an empty rank
+    t = torch.arange(rank * 3, dtype=torch.float32).reshape(-1, 1)
+    parts = vd.all_gather_ragged(t)
+    ok = ok and [p.shape[0] for p in parts] == [r_ * 3 for r_ in range(world)]
+    ret[rank] = bool(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_videos", [5, 1])
+def test_world2_gloo_gather(n_videos):
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), n_videos, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
+
+
+def test_sharding_rules():
+    assert vd.shard_round_robin(10, 1, 4) == [1, 5, 9]
+    assert sorted(sum((vd.shard_round_robin(64, r, 8) for r in range(8)), [])) == list(range(64))
+    owned = vd.shard_lpt([300 * 10000, 30 * 300, 2000 * 300, 300 * 10000, 50 * 300, 700 * 2000], 2)
+    assert sorted(owned[0] + owned[1]) == list(range(6))
+    loads = [sum([300 * 10000, 30 * 300, 2000 * 300, 300 * 10000, 50 * 300, 700 * 2000][i] for i in o) for o in owned]
+    assert abs(loads[0] - loads[1]) <= 700 * 2000
+    assert vd.all_gather_ragged(torch.ones(3, 2))[0].shape == (3, 2)      # single process: identity

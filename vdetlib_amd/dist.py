@@ -1,0 +1,85 @@
+"""Multi-GPU execution of the hot path: one process per GPU, videos sharded across ranks, results
+combined by ONE exchange step -- an RCCL all-gather over xGMI (torch.distributed backend "nccl" is
+RCCL on ROCm; "gloo" runs the same code on CPU tensors for the tests).
+
+The reference has no distributed code at all; every reference function
+takes one ``vid_proto``, so videos are independent units: no data-path collective, only the final
+gather of the per-video results (counts first, then a fixed-capacity padded payload).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    return int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def init(backend=None, device=None):
+    """Initialise torch.distributed from the torchrun environment (no-op for a single process)."""
+    world, rank, local = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this driver
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kw = {}
+        if backend == "nccl" and device is not None:
+            kw["device_id"] = device
+        dist.init_process_group(backend, **kw)
+    return world, rank, local
+
+
+def shard_round_robin(n_items, rank, world):
+    """Indices of the items (videos) this rank owns."""
+    return list(range(rank, n_items, world))
+
+
+def shard_lpt(costs, world):
+    """Longest-processing-time-first assignment (cost = frames x boxes of a video); deterministic.
+    Returns a list of index lists, one per rank."""
+    order = sorted(range(len(costs)), key=lambda i: (-costs[i], i))
+    load = [0] * world
+    owned = [[] for _ in range(world)]
+    for i in order:
+        r = min(range(world), key=lambda k: (load[k], k))
+        owned[r].append(i)
+        load[r] += costs[i]
+    return [sorted(o) for o in owned]
+
+
+def all_gather_ragged(t, group=None):
+    """All-gather tensors whose first dimension differs per rank: counts first, then one padded
+    fixed-capacity payload (a single large collective instead of many small ones -- xGMI rings are
+    per-link bound).  Returns the list of per-rank tensors (on every rank)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return [t]
+    world = dist.get_world_size(group)
+    n = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
+    counts = torch.empty(world, dtype=torch.int64, device=t.device)
+    dist.all_gather_into_tensor(counts, n, group=group)
+    counts = counts.tolist()
+    cap = max(max(counts), 1)
+    pad = torch.zeros((cap,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    pad[:t.shape[0]] = t
+    out = torch.empty((world * cap,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, pad.contiguous(), group=group)
+    return [out[r * cap:r * cap + counts[r]] for r in range(world)]
+
+
+def gather_video_results(video_ids, keep_idx, keep_cnt, group=None):
+    """Combine per-video NMS results across ranks.
+
+    video_ids: list of the global ids of this rank's videos; keep_idx [V,F,C,K] int32 and
+    keep_cnt [V,F,C] int32 for those videos (same F,C,K on all ranks).  Returns
+    {video_id: (keep_idx [F,C,K], keep_cnt [F,C])} for ALL videos, on every rank."""
+    ids = torch.tensor(video_ids, dtype=torch.int64, device=keep_idx.device).reshape(-1)
+    g_ids = all_gather_ragged(ids, group)
+    g_idx = all_gather_ragged(keep_idx, group)
+    g_cnt = all_gather_ragged(keep_cnt, group)
+    out = {}
+    for r in range(len(g_ids)):
+        for k, vid in enumerate(g_ids[r].tolist()):
+            out[int(vid)] = (g_idx[r][k], g_cnt[r][k])
+    return out
