@@ -65,8 +65,8 @@ const char *vdet_last_error(vdet_ctx *ctx);
 /* "vdet_hip <version> gfx950" */
 const char *vdet_version(void);
 /* Wall-clock (ms, HIP events on the context's stream) of the kernels enqueued by the most recent
- * d_* call, by stage; used by bench.py for the roofline object.  out[8]: 0 iou_bits (K1), 1 adj_build
- * (K2), 2 sort (K3), 3 walk (K4), 4 temporal, 5 merge sort, 6 track round 1, 7 other. */
+ * d_* call, by stage; used by bench.py for the roofline object.  out[8]: 0 iou_bits_sym (K1s), 1
+ * adj_build (K2), 2 sort (K3), 3 walk (K4), 4 temporal, 5 merge sort, 6 iou_bits general (K1), 7 other. */
 int vdet_last_timing_ms(vdet_ctx *ctx, float *out8);
 /* Number of timed launches per stage behind the sums of vdet_last_timing_ms (call it first). */
 int vdet_last_launches(vdet_ctx *ctx, int *out8);

@@ -140,7 +140,7 @@ class Context(object):
         n = (ctypes.c_int * 8)()
         self.check(self.lib.vdet_last_timing_ms(self.h, ms))
         self.check(self.lib.vdet_last_launches(self.h, n))
-        names = ["iou_bits", "adj_build", "sort", "walk", "temporal", "merge_sort", "track_round1", "other"]
+        names = ["iou_bits", "adj_build", "sort", "walk", "temporal", "merge_sort", "iou_bits_general", "other"]
         return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(names)}
 
 

@@ -58,6 +58,7 @@ constexpr uint16_t kZTag = 0x8000;
 constexpr int kStCap = 1;       // survivors > cap
 constexpr int kStDivZero = 2;   // evaluated zero-union pair
 constexpr int kStPool = 4;      // adjacency pool too small (internal, retried by the host)
+constexpr uint32_t kFlagRegular = 1u;   // group_flags bit: see frame_flags_kernel
 
 // Sortable key of a float32 score: larger key == earlier in "argsort()[::-1]".
 // -0.0 == +0.0 (numpy compares them equal); NaN sorts last ascending => first descending.
@@ -109,11 +110,13 @@ __global__ __launch_bounds__(256) void iou_bits_kernel(const float4 *__restrict_
                                                        const TileDesc *__restrict__ tiles, float t32,
                                                        uint64_t *__restrict__ bits,
                                                        uint32_t *__restrict__ row_z,
-                                                       uint32_t *__restrict__ group_z)
+                                                       uint32_t *__restrict__ group_z,
+                                                       const uint32_t *__restrict__ group_flags)
 {
     __shared__ float4 sbox[256];
     __shared__ float sarea[256];
     const TileDesc td = tiles[blockIdx.x];
+    if (group_flags && (group_flags[td.group] & kFlagRegular)) return;   // done by iou_bits_sym_kernel
     const GroupDesc gd = groups[td.group];
     const int B = gd.nbox;
     const int tid = threadIdx.x;
@@ -170,6 +173,129 @@ __global__ __launch_bounds__(256) void iou_bits_kernel(const float4 *__restrict_
     if (v < B && zcnt) {
         atomicAdd(&row_z[gd.box_off + v], zcnt);
         group_z[td.group] = 1u;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K0: per-frame "regular" flag.  A frame is regular when every box is finite with positive
+// width/height (+1 convention) and a finite area: then the predicate is symmetric in (i, j) (no NaN
+// for the asymmetric max/min to see), unions are > 0 (no ZeroDivisionError) and the fast kernel
+// below is exact.  Irregular frames take the general iou_bits_kernel.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void frame_flags_kernel(const float4 *__restrict__ boxes,
+                                                          const GroupDesc *__restrict__ groups,
+                                                          uint32_t *__restrict__ group_flags)
+{
+    const GroupDesc gd = groups[blockIdx.x];
+    int bad = 0;
+    const float inf = __uint_as_float(0x7F800000u);
+    for (int v = threadIdx.x; v < gd.nbox; v += 256) {
+        const float4 b = boxes[gd.box_off + v];
+        const float w = (b.z - b.x) + 1.0f, h = (b.w - b.y) + 1.0f;
+        const float a = w * h;
+        const bool ok = fabsf(b.x) < inf && fabsf(b.y) < inf && fabsf(b.z) < inf && fabsf(b.w) < inf &&
+                        w > 0.0f && h > 0.0f && a < inf;
+        bad |= ok ? 0 : 1;
+    }
+    const int any_bad = __syncthreads_or(bad);
+    if (threadIdx.x == 0) group_flags[blockIdx.x] = any_bad ? 0u : kFlagRegular;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1s: predicate bits of REGULAR frames, upper triangle only.  grid = tile pairs (rt <= ct) of
+// 256 x 256 boxes; block = 256 = 4 waves, wave w owns the 64 rows of word-row r = 4*rt + w.
+// For each column word c >= r the wave evaluates the 64 x 64 pairs once and emits BOTH
+//   bits[c][64r + lane]   (row-major accumulation, bit k = column 64c + k)   and, for c > r,
+//   bits[r][64c + lane]   (the transpose: 64 ballots, gathered with v_writelane)
+// -- the predicate is symmetric on regular frames.
+// Predicate, exact without a divide: with r = fma(-t32, uni, inter) (one rounding, sign exact),
+//   r >= 0            =>  inter/uni >= t32            =>  RN(inter/uni) >= t32   (true)
+//   r <  -2^-22*t32*uni => inter/uni < pred(t32)-ish  =>  RN(inter/uni) <  t32   (false)
+//   otherwise (|r| tiny, e.g. IoU exactly 3/10): the wave falls back to the IEEE division.
+// Requires 0 < t32 < inf (the host routes other thresholds to the general kernel).
+// ------------------------------------------------------------------------------------------------
+struct TilePair {
+    int32_t group;
+    int16_t rt, ct;
+};
+
+__device__ __forceinline__ bool pred_regular(float4 br, float rarea, float4 bc, float carea, float t32, float t32e,
+                                             bool &border)
+{
+    const float xx1 = fmaxf(br.x, bc.x);
+    const float yy1 = fmaxf(br.y, bc.y);
+    const float xx2 = fminf(br.z, bc.z);
+    const float yy2 = fminf(br.w, bc.w);
+    const float w = fmaxf(0.0f, (xx2 - xx1) + 1.0f);
+    const float h = fmaxf(0.0f, (yy2 - yy1) + 1.0f);
+    const float inter = w * h;
+    const float uni = (rarea + carea) - inter;
+    const float r = __builtin_fmaf(-t32, uni, inter);
+    const float bnd = t32e * uni;                       // 2^-21 * t32 * uni  >> the half-ulp zone
+    border = (r < 0.0f) && (r >= -bnd);
+    return r >= 0.0f;
+}
+
+__global__ __launch_bounds__(256) void iou_bits_sym_kernel(const float4 *__restrict__ boxes,
+                                                           const GroupDesc *__restrict__ groups,
+                                                           const uint32_t *__restrict__ group_flags,
+                                                           const TilePair *__restrict__ pairs, float t32,
+                                                           uint64_t *__restrict__ bits)
+{
+    __shared__ float4 sbox[256];
+    __shared__ float sarea[256];
+    const TilePair tp = pairs[blockIdx.x];
+    if (!(group_flags[tp.group] & kFlagRegular)) return;
+    const GroupDesc gd = groups[tp.group];
+    const int B = gd.nbox;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r = tp.rt * 4 + w;                 // word-row of this wave
+    const int v = r * 64 + lane;                 // my row box
+    const float t32e = t32 * 4.76837158203125e-7f;   // 2^-21
+
+    float4 br = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (v < B) br = boxes[gd.box_off + v];
+    const float rarea = box_area(br);
+    {
+        const int u = tp.ct * 256 + tid;
+        float4 bc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (u < B) bc = boxes[gd.box_off + u];
+        sbox[tid] = bc;
+        sarea[tid] = box_area(bc);
+    }
+    __syncthreads();
+    const int rows_left = B - r * 64;
+    if (rows_left <= 0) return;
+    const unsigned long long rowvalid = rows_left >= 64 ? ~0ull : ((1ull << rows_left) - 1ull);
+
+    for (int q = 0; q < 4; ++q) {
+        const int c = tp.ct * 4 + q;
+        if (c < r) continue;                     // lower triangle: produced by the transposed stores
+        const int cols_left = B - c * 64;
+        if (cols_left <= 0) break;
+        const unsigned long long colvalid = cols_left >= 64 ? ~0ull : ((1ull << cols_left) - 1ull);
+        uint32_t lo = 0, hi = 0, tlo = 0, thi = 0;
+#pragma unroll 8
+        for (int k = 0; k < 64; ++k) {
+            bool border;
+            bool p = pred_regular(br, rarea, sbox[q * 64 + k], sarea[q * 64 + k], t32, t32e, border);
+            if (__ballot(border)) {              // rare: decide exactly
+                const float4 bc = sbox[q * 64 + k];
+                p = (pair_pred(br, rarea, bc, sarea[q * 64 + k], t32) & 1u) != 0;
+            }
+            if (k < 32) lo |= p ? (1u << k) : 0u; else hi |= p ? (1u << (k - 32)) : 0u;
+            const unsigned long long b = __ballot(p) & rowvalid;
+            // lane k keeps column k's ballot (the compiler turns "lane == k" into a constant mask)
+            tlo = (lane == k) ? (uint32_t)b : tlo;
+            thi = (lane == k) ? (uint32_t)(b >> 32) : thi;
+        }
+        unsigned long long m = (((unsigned long long)hi << 32) | lo) & colvalid;
+        if (c == r) m &= ~(1ull << lane);        // no self edge
+        if (v < B) bits[gd.bits_off + (int64_t)c * B + v] = m;
+        if (c > r) {
+            const int u = c * 64 + lane;
+            if (u < B) bits[gd.bits_off + (int64_t)r * B + u] = ((unsigned long long)thi << 32) | tlo;
+        }
     }
 }
 

@@ -49,7 +49,7 @@ struct DevBuf {
     template <typename T> T *as() { return static_cast<T *>(p); }
 };
 
-enum Stage { ST_IOU_BITS = 0, ST_ADJ = 1, ST_SORTK = 2, ST_WALK = 3, ST_TEMPORAL = 4, ST_SORT = 5, ST_ROUND1 = 6, ST_OTHER = 7 };
+enum Stage { ST_IOU_BITS = 0, ST_ADJ = 1, ST_SORTK = 2, ST_WALK = 3, ST_TEMPORAL = 4, ST_SORT = 5, ST_IOU_GEN = 6, ST_OTHER = 7 };
 
 struct Counters {            // one small device block
     int status;
@@ -71,7 +71,7 @@ struct vdet_ctx {
     int n_cu = 256;
     // scratch
     DevBuf boxes, scores, keys, excl, frames, groups, tiles, bits, rowz, rowoff, rowdeg, groupz, adj, comp, origidx,
-        out64, trk_frames, trk_boxes, b1, b2, iou_out, order, ncand, keepidx, keepcnt, tmp[8];
+        out64, trk_frames, trk_boxes, b1, b2, iou_out, order, ncand, keepidx, keepcnt, gflags, pairs, tmp[8];
     // timing
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -80,6 +80,7 @@ struct vdet_ctx {
     float last_ms[8] = {0};
     int last_launches[8] = {0};
     bool sort_attr_set = false;
+    bool force_general = false;   // VDET_FORCE_GENERAL=1: disable the symmetric fast kernel (tests)
     bool topk_attr_set = false;
     size_t dyn_lds_max = 0;
 };
@@ -158,7 +159,9 @@ int translate_status(vdet_ctx *c, int st)
 struct NmsPlan {
     std::vector<GroupDesc> groups;   // bits_off is batch-local
     std::vector<TileDesc> tiles;     // ordered by batch
+    std::vector<TilePair> pairs;     // upper-triangle 256x256 tile pairs, ordered by batch
     std::vector<std::pair<int, int>> batch_tiles;  // [t0, t1) per batch
+    std::vector<std::pair<int, int>> batch_pairs;  // [p0, p1) per batch
     size_t bits_words_max = 0;       // largest batch
     int64_t ntot = 0;
     int nmax = 0;
@@ -168,7 +171,7 @@ int make_plan(vdet_ctx *c, NmsPlan &pl)
 {
     const size_t budget_words = std::max<size_t>(c->bits_budget / 8, 1);
     size_t cur = 0;
-    int t0 = 0;
+    int t0 = 0, p0 = 0;
     pl.nmax = 0;
     pl.ntot = 0;
     for (size_t g = 0; g < pl.groups.size(); ++g) {
@@ -179,15 +182,23 @@ int make_plan(vdet_ctx *c, NmsPlan &pl)
         const size_t words = (size_t)((gd.nbox + 63) / 64) * gd.nbox;
         if (cur && cur + words > budget_words) {
             pl.batch_tiles.push_back({t0, (int)pl.tiles.size()});
+            pl.batch_pairs.push_back({p0, (int)pl.pairs.size()});
             t0 = (int)pl.tiles.size();
+            p0 = (int)pl.pairs.size();
             pl.bits_words_max = std::max(pl.bits_words_max, cur);
             cur = 0;
         }
         gd.bits_off = (int64_t)cur;
         cur += words;
-        for (int rt = 0; rt * kRowsPerTile < gd.nbox; ++rt) pl.tiles.push_back({(int32_t)g, rt});
+        const int nrt = (gd.nbox + kRowsPerTile - 1) / kRowsPerTile;
+        for (int rt = 0; rt < nrt; ++rt) pl.tiles.push_back({(int32_t)g, rt});
+        for (int rt = 0; rt < nrt; ++rt)
+            for (int ct = rt; ct < nrt; ++ct) pl.pairs.push_back({(int32_t)g, (int16_t)rt, (int16_t)ct});
     }
-    if ((int)pl.tiles.size() > t0) pl.batch_tiles.push_back({t0, (int)pl.tiles.size()});
+    if ((int)pl.tiles.size() > t0) {
+        pl.batch_tiles.push_back({t0, (int)pl.tiles.size()});
+        pl.batch_pairs.push_back({p0, (int)pl.pairs.size()});
+    }
     pl.bits_words_max = std::max(pl.bits_words_max, cur);
     (void)c;
     return VDET_OK;
@@ -204,6 +215,11 @@ int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32)
     HIPCHK(c, c->rowoff.reserve((size_t)pl.ntot * 4));
     HIPCHK(c, c->rowdeg.reserve((size_t)pl.ntot * 2));
     HIPCHK(c, c->groupz.reserve(G * 4));
+    HIPCHK(c, c->gflags.reserve(G * 4));
+    HIPCHK(c, c->pairs.reserve(std::max<size_t>(pl.pairs.size(), 1) * sizeof(TilePair)));
+    if (!pl.pairs.empty())
+        HIPCHK(c, hipMemcpyAsync(c->pairs.p, pl.pairs.data(), pl.pairs.size() * sizeof(TilePair),
+                                 hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->groups.p, pl.groups.data(), G * sizeof(GroupDesc), hipMemcpyHostToDevice, c->stream));
     if (!pl.tiles.empty())
         HIPCHK(c, hipMemcpyAsync(c->tiles.p, pl.tiles.data(), pl.tiles.size() * sizeof(TileDesc),
@@ -225,9 +241,24 @@ int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32)
         HIPCHK(c, hipMemsetAsync(c->groupz.p, 0, G * 4, c->stream));
         HIPCHK(c, hipMemsetAsync(c->d_cnt, 0, sizeof(Counters), c->stream));
         const unsigned long long pool_cap = c->adj.cap / 2;
-        for (auto bt : pl.batch_tiles) {
+        // fast symmetric kernel for regular frames needs 0 < t32 < inf (exact divide-free test)
+        const bool use_sym = t32 > 1e-30f && t32 < INFINITY && !c->force_general;
+        if (use_sym) {
+            StageTimer tm(c, ST_OTHER);
+            hipLaunchKernelGGL(frame_flags_kernel, dim3((unsigned)G), dim3(256), 0, c->stream, d_boxes,
+                               c->groups.as<GroupDesc>(), c->gflags.as<uint32_t>());
+        }
+        for (size_t bi = 0; bi < pl.batch_tiles.size(); ++bi) {
+            const auto bt = pl.batch_tiles[bi];
+            const auto bp = pl.batch_pairs[bi];
             const int nt = bt.second - bt.first;
             if (nt <= 0) continue;
+            if (use_sym && bp.second > bp.first) {
+                StageTimer tm(c, ST_IOU_BITS);
+                hipLaunchKernelGGL(iou_bits_sym_kernel, dim3(bp.second - bp.first), dim3(256), 0, c->stream, d_boxes,
+                                   c->groups.as<GroupDesc>(), c->gflags.as<uint32_t>(),
+                                   c->pairs.as<TilePair>() + bp.first, t32, c->bits.as<uint64_t>());
+            }
             // enough column splits to fill the chip when there are few row tiles
             int splits = 1;
             if (nt < 4 * c->n_cu) {
@@ -238,10 +269,11 @@ int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32)
                 splits = std::max(1, std::min(splits, 65535));
             }
             {
-                StageTimer tm(c, ST_IOU_BITS);
+                StageTimer tm(c, ST_IOU_GEN);
                 hipLaunchKernelGGL(iou_bits_kernel, dim3(nt, splits), dim3(256), 0, c->stream, d_boxes,
                                    c->groups.as<GroupDesc>(), c->tiles.as<TileDesc>() + bt.first, t32,
-                                   c->bits.as<uint64_t>(), c->rowz.as<uint32_t>(), c->groupz.as<uint32_t>());
+                                   c->bits.as<uint64_t>(), c->rowz.as<uint32_t>(), c->groupz.as<uint32_t>(),
+                                   use_sym ? c->gflags.as<uint32_t>() : (const uint32_t *)nullptr);
             }
             {
                 StageTimer tm(c, ST_ADJ);
@@ -466,6 +498,7 @@ int vdet_create(vdet_ctx **out, int device)
         // gfx950: one workgroup may own the CU's whole 160 KiB LDS (opt-in via hipFuncSetAttribute)
         if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) c->max_lds = 64 * 1024;
     }
+    if (const char *e = getenv("VDET_FORCE_GENERAL")) c->force_general = atoi(e) != 0;
     if (const char *e = getenv("VDET_BITS_BUDGET_MB")) {
         const long mb = atol(e);
         if (mb > 0) c->bits_budget = (size_t)mb << 20;
@@ -489,7 +522,7 @@ int vdet_destroy(vdet_ctx *c)
     DevBuf *bufs[] = {&c->boxes, &c->scores, &c->keys, &c->excl, &c->frames, &c->groups, &c->tiles, &c->bits,
                       &c->rowz, &c->rowoff, &c->rowdeg, &c->groupz, &c->adj, &c->comp, &c->origidx, &c->out64,
                       &c->trk_frames, &c->trk_boxes, &c->b1, &c->b2, &c->iou_out, &c->order, &c->ncand, &c->keepidx,
-                      &c->keepcnt};
+                      &c->keepcnt, &c->gflags, &c->pairs};
     for (DevBuf *b : bufs) b->release();
     for (DevBuf &b : c->tmp) b.release();
     for (auto &e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -670,7 +703,7 @@ int vdet_track_det_nms_f32(vdet_ctx *c, const float *h_tracks, int64_t t, int64_
     rc = build_graph(c, c->boxes.as<float4>(), pl, t32);
     if (rc) return rc;
     {
-        StageTimer tm(c, ST_ROUND1);
+        StageTimer tm(c, ST_OTHER);
         hipLaunchKernelGGL(track_round1_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream,
                            c->frames.as<float>(), c->boxes.as<float4>(), (int)m, c->trk_frames.as<float>(),
                            c->trk_boxes.as<float4>(), (int)t, t32, c->excl.as<uint8_t>(), &c->d_cnt->status);
