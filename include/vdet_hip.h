@@ -70,6 +70,10 @@ const char *vdet_version(void);
 int vdet_last_timing_ms(vdet_ctx *ctx, float *out8);
 /* Number of timed launches per stage behind the sums of vdet_last_timing_ms (call it first). */
 int vdet_last_launches(vdet_ctx *ctx, int *out8);
+/* Introspection: what = 0 -> 1 if the per-(frame,class) sort uses the returning-LDS-atomic rank
+ * (selected by a hardware self-test at vdet_create), 0 if it uses the ballot match;
+ * what = 1 -> number of compute units. */
+int vdet_query(vdet_ctx *ctx, int what);
 /* Enable (1) / disable (0) per-stage HIP-event timing (default off: events cost launches). */
 int vdet_set_timing(vdet_ctx *ctx, int enable);
 

@@ -27,6 +27,7 @@ SYMBOLS = {
     "vdet_last_timing_ms": (_ci, [_vp, _vp]),
     "vdet_last_launches": (_ci, [_vp, _vp]),
     "vdet_set_timing": (_ci, [_vp, _ci]),
+    "vdet_query": (_ci, [_vp, _ci]),
     "vdet_nms_f32": (_ci, [_vp, _vp, _i64, _i64, _ci, _f64, _vp, _vp, ctypes.POINTER(_i64)]),
     "vdet_track_det_nms_f32": (_ci, [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _f64, _vp, ctypes.POINTER(_i64)]),
     "vdet_iou_f64": (_ci, [_vp, _vp, _i64, _vp, _i64, _vp]),
@@ -131,6 +132,9 @@ class Context(object):
 
     def sync(self):
         self.check(self.lib.vdet_sync(self.h))
+
+    def query(self, what):
+        return int(self.lib.vdet_query(self.h, int(what)))
 
     def set_timing(self, on):
         self.check(self.lib.vdet_set_timing(self.h, 1 if on else 0))

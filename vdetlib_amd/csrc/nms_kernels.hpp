@@ -387,10 +387,11 @@ __global__ __launch_bounds__(256) void adj_build_kernel(const float4 *__restrict
 // ------------------------------------------------------------------------------------------------
 struct SortParams {
     int mode;                 // 0: volume [F,B,C]  1: volume [F,C,B]  2: flat, problem p == group p
+                              // 3: transposed keys [F*C, B] (from transpose_keys_kernel)
     int P;
     int B, C;
     const float *scores;
-    const uint32_t *keys;     // mode 2: explicit priorities (caller-supplied order) or null
+    const uint32_t *keys;     // mode 2: explicit priorities (caller-supplied order) or null; mode 3: keys
     const uint8_t *excl;      // mode 2: flat [Ntot] nonzero = not a candidate
     int use_thr;
     float thr;
@@ -398,6 +399,7 @@ struct SortParams {
     uint16_t *order;          // mode 0/1: [P,B]; mode 2: flat [Ntot] at the group's box_off
     int32_t *ncand;           // [P]
     int lds_idxa_off, lds_idxb_off, lds_base_off;   // dynamic-LDS carve, multiples of 16
+    int npass;                // 4 (debug knob VDET_SORT_PASSES: fewer passes = timing experiments only)
 };
 
 struct ProblemRef { int g, N, rb; int64_t sbase, sstride, obase; };
@@ -406,7 +408,7 @@ __device__ __forceinline__ ProblemRef decode_problem(int mode, int p, int B, int
 {
     ProblemRef r;
     if (mode == 0) { r.g = p / C; const int c = p - r.g * C; r.sbase = (int64_t)r.g * B * C + c; r.sstride = C; r.obase = (int64_t)p * B; }
-    else if (mode == 1) { r.g = p / C; r.sbase = (int64_t)p * B; r.sstride = 1; r.obase = (int64_t)p * B; }
+    else if (mode == 1 || mode == 3) { r.g = p / C; r.sbase = (int64_t)p * B; r.sstride = 1; r.obase = (int64_t)p * B; }
     else { r.g = p; r.sbase = groups[p].box_off; r.sstride = 1; r.obase = groups[p].box_off; }
     r.N = groups[r.g].nbox;
     r.rb = groups[r.g].box_off;
@@ -422,7 +424,31 @@ __device__ __forceinline__ int xcd_problem(int bid, int nblocks)
     return (bid & 7) * per + (bid >> 3);
 }
 
-template <int BLOCK>
+// 64-lane "match": mask of the valid lanes holding the same 8-bit digit
+__device__ __forceinline__ unsigned long long match8(uint32_t d, bool valid)
+{
+    unsigned long long peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        const bool bit = (d >> b) & 1u;
+        const unsigned long long m = __ballot(valid && bit);
+        peers &= bit ? m : ~m;
+    }
+    return peers;
+}
+
+// CPW = chunks (of 64 keys) per wave, compile-time so the per-chunk state lives in registers:
+// each pass gathers its keys ONCE (phase 1: digit, stable rank inside the chunk, and -- through one
+// returning LDS atomic per distinct digit -- the count of that digit in the wave's earlier chunks),
+// then, after the cross-wave scan, scatters with a single independent LDS read per key (phase 2).
+//
+// ARANK = true: the stable rank comes straight from ONE returning LDS atomic per key
+// (ds_add_rtn_u32 on the wave's private digit counter): lanes of one instruction that hit the same
+// address are served in ascending lane order on gfx950, and a wave's LDS instructions execute in
+// order, so the returned value IS "keys of this digit before me in this wave".  That ordering is
+// measured, not documented: vdet_create runs lds_atomic_order_probe on thousands of conflict
+// patterns and the host only selects ARANK when it holds; otherwise the 8-ballot match is used.
+template <int BLOCK, int CPW, bool ARANK>
 __global__ __launch_bounds__(BLOCK) void sort_kernel(const SortParams prm)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -445,8 +471,10 @@ __global__ __launch_bounds__(BLOCK) void sort_kernel(const SortParams prm)
     for (int v = tid; v < N; v += BLOCK) {
         uint32_t ik;
         bool x = false;
-        if (prm.keys) {
-            ik = ~prm.keys[pr.sbase + v];
+        if (prm.keys) {                        // explicit priorities; 0 marks "not a candidate"
+            const uint32_t k = prm.keys[pr.sbase + v];
+            ik = ~k;
+            x = (k == 0u);
         } else {
             const float s = prm.scores[pr.sbase + (int64_t)v * pr.sstride];
             ik = ~score_key(s);
@@ -462,16 +490,32 @@ __global__ __launch_bounds__(BLOCK) void sort_kernel(const SortParams prm)
     const int ncand = N - (int)tot[256];
 
     const int nchunks = (N + 63) >> 6;
-    const int cpw = (nchunks + NW - 1) / NW;
-    const int c0 = w * cpw, c1 = min(nchunks, c0 + cpw);
+    const int c0 = w * CPW;                      // host guarantees NW * CPW >= nchunks
 
-    for (int pass = 0; pass < 4; ++pass) {
+    for (int pass = 0; pass < prm.npass; ++pass) {
         const int shift = pass * 8;
         for (int i = tid; i < NW * 256; i += BLOCK) bases[i] = 0;
         __syncthreads();
-        for (int ch = c0; ch < c1; ++ch) {
-            const int q = ch * 64 + lane;
-            if (q < N) atomicAdd(&bases[w * 256 + ((keys0[src[q]] >> shift) & 255u)], 1u);
+        uint32_t ra[CPW];        // index | digit << 16
+        uint32_t rl[CPW];        // offset inside this wave's run of the digit
+#pragma unroll
+        for (int ch = 0; ch < CPW; ++ch) {
+            const int q = (c0 + ch) * 64 + lane;
+            const bool valid = (c0 + ch) < nchunks && q < N;
+            const uint32_t i = valid ? src[q] : 0u;
+            const uint32_t d = valid ? ((keys0[i] >> shift) & 255u) : 0u;
+            ra[ch] = i | (d << 16);
+            if (ARANK) {
+                rl[ch] = valid ? atomicAdd(&bases[w * 256 + d], 1u) : 0u;
+            } else {
+                const unsigned long long peers = match8(d, valid);
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
+                uint32_t old = 0;
+                if (valid && rank == 0) old = atomicAdd(&bases[w * 256 + d], (uint32_t)__popcll(peers));
+                const int leader = valid ? (__ffsll((unsigned long long)peers) - 1) : lane;
+                old = __shfl(old, leader, 64);
+                rl[ch] = old + rank;
+            }
         }
         __syncthreads();
         if (tid < 256) {   // per digit: exclusive prefix over the waves, total
@@ -498,29 +542,14 @@ __global__ __launch_bounds__(BLOCK) void sort_kernel(const SortParams prm)
             tot[lane * 4] = ex; tot[lane * 4 + 1] = ex + a0; tot[lane * 4 + 2] = ex + a0 + a1; tot[lane * 4 + 3] = ex + a0 + a1 + a2;
         }
         __syncthreads();
-        for (int i = tid; i < NW * 256; i += BLOCK) bases[i] += tot[i & 255];
-        __syncthreads();
-        for (int ch = c0; ch < c1; ++ch) {
-            const int q = ch * 64 + lane;
-            const bool valid = q < N;
-            const uint32_t i = valid ? src[q] : 0u;
-            const uint32_t d = valid ? ((keys0[i] >> shift) & 255u) : 0u;
-            unsigned long long peers = __ballot(valid);
 #pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                const bool bit = (d >> b) & 1u;
-                const unsigned long long m = __ballot(valid && bit);
-                peers &= bit ? m : ~m;
-            }
+        for (int ch = 0; ch < CPW; ++ch) {
+            const int q = (c0 + ch) * 64 + lane;
+            const bool valid = (c0 + ch) < nchunks && q < N;
             if (valid) {
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
-                const uint32_t bb = bases[w * 256 + d];
-                dst[bb + rank] = (uint16_t)i;
-                if (rank == 0) bases[w * 256 + d] = bb + (uint32_t)__popcll(peers);
+                const uint32_t d = ra[ch] >> 16;
+                dst[bases[w * 256 + d] + tot[d] + rl[ch]] = (uint16_t)(ra[ch] & 0xFFFFu);
             }
-            // LDS operations of one wave execute in order; keep the compiler from moving the next
-            // chunk's base read above this chunk's base update
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
         __syncthreads();
         uint16_t *t = src; src = dst; dst = t;
@@ -528,6 +557,62 @@ __global__ __launch_bounds__(BLOCK) void sort_kernel(const SortParams prm)
     uint16_t *out = prm.order + pr.obase;
     for (int v = tid; v < N; v += BLOCK) out[v] = src[v];
     if (tid == 0) prm.ncand[p] = ncand;
+}
+
+// Self-test for ARANK (see sort_kernel): for each of the n patterns, every lane adds 1 to
+// tbl[pat[lane]] with a returning LDS atomic, twice in a row; the returned values must equal the
+// number of lower lanes (+ the whole first instruction for the second) with the same target.
+__global__ __launch_bounds__(64) void lds_atomic_order_probe(const uint8_t *__restrict__ pats, int n, int *__restrict__ bad)
+{
+    __shared__ uint32_t tbl[256];
+    const int lane = threadIdx.x;
+    int nbad = 0;
+    for (int t = blockIdx.x; t < n; t += gridDim.x) {
+        for (int i = lane; i < 256; i += 64) tbl[i] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const uint32_t d = pats[t * 64 + lane];
+        const bool act = d != 255;                 // 255 = lane inactive in this pattern
+        uint32_t r1 = 0, r2 = 0;
+        if (act) r1 = atomicAdd(&tbl[d], 1u);
+        if (act) r2 = atomicAdd(&tbl[d], 1u);
+        const unsigned long long peers = match8(d, act);
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
+        const uint32_t cnt = (uint32_t)__popcll(peers);
+        if (act && (r1 != rank || r2 != cnt + rank)) nbad = 1;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    if (__ballot(nbad) && lane == 0) atomicOr(bad, 1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Score volume [F,B,C] (class innermost) -> sortable keys [F,C,B]: a coalesced 64x64 LDS transpose,
+// so that the per-(frame,class) sort reads contiguous keys instead of one 4-B element per 128-B
+// line.  key = score_key(s); 0 = "not a candidate" (score <= thr).  HBM-bound: 4 B in + 4 B out.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_keys_kernel(const float *__restrict__ scores, uint32_t *__restrict__ keys,
+                                                             int B, int C, int use_thr, float thr)
+{
+    __shared__ uint32_t tile[64][65];
+    const int f = blockIdx.z;
+    const int b0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;      // 64 x 4
+    const float *src = scores + (int64_t)f * B * C;
+    for (int r = ty; r < 64; r += 4) {
+        const int b = b0 + r, c = c0 + tx;
+        uint32_t k = 0;
+        if (b < B && c < C) {
+            const float s = src[(int64_t)b * C + c];
+            k = score_key(s);
+            if (use_thr && !(s > thr)) k = 0u;
+        }
+        tile[r][tx] = k;
+    }
+    __syncthreads();
+    uint32_t *dst = keys + (int64_t)f * C * B;
+    for (int r = ty; r < 64; r += 4) {
+        const int c = c0 + r, b = b0 + tx;
+        if (c < C && b < B) dst[(int64_t)c * B + b] = tile[tx][r];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

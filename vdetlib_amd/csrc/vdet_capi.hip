@@ -71,7 +71,7 @@ struct vdet_ctx {
     int n_cu = 256;
     // scratch
     DevBuf boxes, scores, keys, excl, frames, groups, tiles, bits, rowz, rowoff, rowdeg, groupz, adj, comp, origidx,
-        out64, trk_frames, trk_boxes, b1, b2, iou_out, order, ncand, keepidx, keepcnt, gflags, pairs, tmp[8];
+        out64, trk_frames, trk_boxes, b1, b2, iou_out, order, ncand, keepidx, keepcnt, gflags, pairs, tkeys, tmp[8];
     // timing
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -80,6 +80,8 @@ struct vdet_ctx {
     float last_ms[8] = {0};
     int last_launches[8] = {0};
     bool sort_attr_set = false;
+    bool atomic_rank = false;     // LDS returning atomics serve same-address lanes in lane order (probed)
+    bool no_transpose = false;    // VDET_NO_TRANSPOSE=1 (tests / A-B)
     bool force_general = false;   // VDET_FORCE_GENERAL=1: disable the symmetric fast kernel (tests)
     bool topk_attr_set = false;
     size_t dyn_lds_max = 0;
@@ -317,11 +319,20 @@ int launch_sort_walk(vdet_ctx *c, const SortWalkArgs &a, int nmax, int64_t order
     HIPCHK(c, c->ncand.reserve((size_t)a.P * 4));
     const int block = nmax > 1024 ? 1024 : 256;
     const int nw = block / 64;
+    const int nchunks = (std::max(nmax, 1) + 63) / 64;
+    const int need_cpw = (nchunks + nw - 1) / nw;
+    // instantiated (BLOCK, CPW) pairs; CPW = chunks of 64 keys per wave
+    struct Variant { int block, cpw; const void *fn[2]; };   // fn[0]: ballot match, fn[1]: atomic rank
+#define VDET_SV(BL, CP) {BL, CP, {reinterpret_cast<const void *>(sort_kernel<BL, CP, false>), reinterpret_cast<const void *>(sort_kernel<BL, CP, true>)}}
+    static const Variant variants[] = {VDET_SV(256, 1), VDET_SV(256, 2), VDET_SV(256, 4), VDET_SV(1024, 2), VDET_SV(1024, 4),
+                                       VDET_SV(1024, 6), VDET_SV(1024, 8), VDET_SV(1024, 10), VDET_SV(1024, 12),
+                                       VDET_SV(1024, 16), VDET_SV(1024, 18)};
+#undef VDET_SV
     if (!c->sort_attr_set) {
-        const void *fns[3] = {reinterpret_cast<const void *>(sort_kernel<1024>),
-                              reinterpret_cast<const void *>(sort_kernel<256>),
-                              reinterpret_cast<const void *>(walk_kernel)};
         size_t stat = 0;
+        std::vector<const void *> fns;
+        for (const Variant &v : variants) { fns.push_back(v.fn[0]); fns.push_back(v.fn[1]); }
+        fns.push_back(reinterpret_cast<const void *>(walk_kernel));
         for (const void *fn : fns) {
             hipFuncAttributes fa;
             HIPCHK(c, hipFuncGetAttributes(&fa, fn));
@@ -332,26 +343,46 @@ int launch_sort_walk(vdet_ctx *c, const SortWalkArgs &a, int nmax, int64_t order
             HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->dyn_lds_max));
         c->sort_attr_set = true;
     }
+    const Variant *var = nullptr;
+    for (const Variant &v : variants)
+        if (v.block == block && v.cpw >= need_cpw) { var = &v; break; }
     SortParams sp{};
     sp.mode = a.mode; sp.P = a.P; sp.B = a.B; sp.C = a.C;
     sp.scores = a.scores; sp.keys = a.keys; sp.excl = a.excl; sp.use_thr = a.use_thr; sp.thr = a.thr;
+    if (a.mode == 0 && !a.keys && !c->no_transpose) {
+        // class-innermost volume: one coalesced transpose to [F,C,B] keys, then the sort reads rows
+        const int64_t F = a.P / a.C;
+        HIPCHK(c, c->tkeys.reserve((size_t)a.P * a.B * 4));
+        {
+            StageTimer tm(c, ST_OTHER);
+            hipLaunchKernelGGL(transpose_keys_kernel, dim3((a.B + 63) / 64, (a.C + 63) / 64, (unsigned)F), dim3(256), 0,
+                               c->stream, a.scores, c->tkeys.as<uint32_t>(), a.B, a.C, a.use_thr, a.thr);
+        }
+        HIPCHK(c, hipGetLastError());
+        sp.mode = 3;             // keys laid out [P,B] (decode like mode 1)
+        sp.keys = c->tkeys.as<uint32_t>();
+        sp.scores = nullptr;
+        sp.use_thr = 0;
+    }
     sp.groups = c->groups.as<GroupDesc>();
     sp.order = c->order.as<uint16_t>();
     sp.ncand = c->ncand.as<int32_t>();
+    sp.npass = 4;
+    if (const char *e = getenv("VDET_SORT_PASSES")) sp.npass = atoi(e);
     const size_t keysB = r16((size_t)4 * std::max(nmax, 1));
     const size_t idxB = r16((size_t)2 * std::max(nmax, 1));
     sp.lds_idxa_off = (int)keysB;
     sp.lds_idxb_off = (int)(keysB + idxB);
     sp.lds_base_off = (int)(keysB + 2 * idxB);
     const size_t lds = keysB + 2 * idxB + (size_t)4 * (nw * 256 + 256 + 4);
-    if (lds > c->dyn_lds_max)
+    if (!var || lds > c->dyn_lds_max)
         return fail(c, VDET_EINVAL, "a frame with %d boxes needs %zu B of LDS for the in-LDS sort; the limit is %zu B "
                                     "(about 18000 boxes per frame)", nmax, lds, c->dyn_lds_max);
     {
         const int grid = (a.P + 7) & ~7;
         StageTimer tm(c, ST_SORTK);
-        if (block == 1024) hipLaunchKernelGGL(sort_kernel<1024>, dim3(grid), dim3(1024), lds, c->stream, sp);
-        else hipLaunchKernelGGL(sort_kernel<256>, dim3(grid), dim3(256), lds, c->stream, sp);
+        void *args[] = {&sp};
+        HIPCHK(c, hipLaunchKernel(var->fn[c->atomic_rank ? 1 : 0], dim3(grid), dim3(block), args, lds, c->stream));
     }
     HIPCHK(c, hipGetLastError());
     WalkParams wp{};
@@ -510,6 +541,38 @@ int vdet_create(vdet_ctx **out, int device)
     }
     c->stream = c->own_stream;
     (void)hipMemsetAsync(c->d_cnt, 0, sizeof(Counters), c->stream);
+    if (const char *e = getenv("VDET_NO_TRANSPOSE")) c->no_transpose = atoi(e) != 0;
+    {   // probe: do returning LDS atomics resolve same-address lanes in ascending lane order?
+        const int npat = 4096;
+        std::vector<uint8_t> pats((size_t)npat * 64);
+        uint32_t rs = 12345u;
+        auto rnd = [&]() { rs = rs * 1664525u + 1013904223u; return rs >> 8; };
+        for (int t = 0; t < npat; ++t) {
+            const int kind = t % 8;
+            const int nd = kind == 0 ? 1 : kind == 1 ? 2 : kind == 2 ? 3 : kind == 3 ? 8 : kind == 4 ? 32 : kind == 5 ? 64 : kind == 6 ? 200 : 254;
+            for (int l = 0; l < 64; ++l) {
+                uint8_t d = (uint8_t)(rnd() % nd);
+                if (kind == 7 && (rnd() & 3) == 0) d = 255;          // inactive lanes
+                if (t % 16 == 9) d = (uint8_t)((l * (1 + t % 7)) % nd); // structured strides
+                pats[(size_t)t * 64 + l] = d;
+            }
+        }
+        bool ok = false;
+        DevBuf pb;
+        if (pb.reserve(pats.size()) == hipSuccess &&
+            hipMemcpyAsync(pb.p, pats.data(), pats.size(), hipMemcpyHostToDevice, c->stream) == hipSuccess) {
+            hipLaunchKernelGGL(lds_atomic_order_probe, dim3(256), dim3(64), 0, c->stream, pb.as<uint8_t>(), npat,
+                               &c->d_cnt->status);
+            Counters h;
+            if (hipMemcpyAsync(&h, c->d_cnt, sizeof h, hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
+                hipStreamSynchronize(c->stream) == hipSuccess)
+                ok = (h.status == 0);
+        }
+        pb.release();
+        (void)hipMemsetAsync(c->d_cnt, 0, sizeof(Counters), c->stream);
+        c->atomic_rank = ok;
+        if (const char *e = getenv("VDET_ATOMIC_RANK")) c->atomic_rank = c->atomic_rank && atoi(e) != 0;
+    }
     *out = c;
     return VDET_OK;
 }
@@ -522,7 +585,7 @@ int vdet_destroy(vdet_ctx *c)
     DevBuf *bufs[] = {&c->boxes, &c->scores, &c->keys, &c->excl, &c->frames, &c->groups, &c->tiles, &c->bits,
                       &c->rowz, &c->rowoff, &c->rowdeg, &c->groupz, &c->adj, &c->comp, &c->origidx, &c->out64,
                       &c->trk_frames, &c->trk_boxes, &c->b1, &c->b2, &c->iou_out, &c->order, &c->ncand, &c->keepidx,
-                      &c->keepcnt, &c->gflags, &c->pairs};
+                      &c->keepcnt, &c->gflags, &c->pairs, &c->tkeys};
     for (DevBuf *b : bufs) b->release();
     for (DevBuf &b : c->tmp) b.release();
     for (auto &e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -547,6 +610,14 @@ int vdet_reset_stream(vdet_ctx *c)
 }
 
 const char *vdet_last_error(vdet_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+int vdet_query(vdet_ctx *c, int what)
+{
+    if (!c) return VDET_EINVAL;
+    if (what == 0) return c->atomic_rank ? 1 : 0;
+    if (what == 1) return c->n_cu;
+    return VDET_EINVAL;
+}
 
 int vdet_set_timing(vdet_ctx *c, int enable)
 {
