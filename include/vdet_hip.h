@@ -189,6 +189,24 @@ int vdet_temporal_maxpool_f32(vdet_ctx *ctx, const float *d_in, float *d_out, in
 int vdet_temporal_conv_f32(vdet_ctx *ctx, const float *d_in, float *d_out, int64_t F, int64_t S,
                            const float *h_taps, int K, float bias, float pad);
 
+/*
+ * Greedy tubelet generation for every class of a score volume, device-resident: the array form of
+ * greedily_track_from_raw_dets (vdet/track.py:189-252) with the built-in IoU-linking tracker as
+ * track_method (the reference's trackers are external MATLAB code).  Per class, up to max_tracks
+ * times: anchor = best still-kept detection of the video (stop when its score < thres, :218);
+ * link it frame by frame to the proposal with the highest float32 IoU with the current (int-
+ * truncated) box while that IoU >= link_thres, at most ceil((max_frames+1)/2) frames per side
+ * (max_frames <= 0: no limit; vdet/track.py:64-78); then, for every tracked box, track_det_nms
+ * (utils/nms.pyx:128-189, threshold nms_thres) prunes that frame's still-kept detections.
+ *   d_boxes [F,B,4] f32, d_scores [F,B,C] f32 (class innermost)
+ *   d_tracks  [C,max_tracks,F,5] f32 rows (x1,y1,x2,y2,score), NaN where a track has no box
+ *   d_anchors [C,max_tracks,3] f32 (1-based frame, box index, score);  d_ntracks [C] int32
+ * Asynchronous after the graph build; failures are latched for vdet_sync.
+ */
+int vdet_track_volume(vdet_ctx *ctx, const float *d_boxes, const float *d_scores, int64_t F, int64_t B,
+                      int64_t C, double nms_thres, double thres, int max_tracks, double link_thres,
+                      int max_frames, float *d_tracks, float *d_anchors, int32_t *d_ntracks);
+
 #ifdef __cplusplus
 }
 #endif

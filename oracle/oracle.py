@@ -284,3 +284,99 @@ def tubelet_interpolation(frames, fields, max_frames):
     dense = list(range(min_idx, max_idx + 1))
     cols = [interp_linear(frames, fields[:, k], dense) for k in range(fields.shape[1])]
     return np.asarray(dense, dtype=np.int64), np.stack(cols, axis=1)
+
+
+# ---------------------------------------------------------------------------------------------
+# greedy tubelet generation on arrays (vdet/track.py:189-252) with the build's IoU-linking tracker
+# ---------------------------------------------------------------------------------------------
+
+def _iou_f32_row(cur, boxes):
+    """float32 IoU of one box (as the "i" box) with boxes [B,4], utils/nms.pyx:57-64 arithmetic."""
+    f = np.float32
+    cur = cur.astype(f)
+    b = boxes.astype(f)
+    with np.errstate(all='ignore'):
+        xx1 = np.where(cur[0] >= b[:, 0], cur[0], b[:, 0])
+        yy1 = np.where(cur[1] >= b[:, 1], cur[1], b[:, 1])
+        xx2 = np.where(cur[2] <= b[:, 2], cur[2], b[:, 2])
+        yy2 = np.where(cur[3] <= b[:, 3], cur[3], b[:, 3])
+        w = (xx2 - xx1) + f(1)
+        w = np.where(f(0) >= w, f(0), w)
+        h = (yy2 - yy1) + f(1)
+        h = np.where(f(0) >= h, f(0), h)
+        inter = w * h
+        carea = ((cur[2] - cur[0]) + f(1)) * ((cur[3] - cur[1]) + f(1))
+        areas = ((b[:, 2] - b[:, 0]) + f(1)) * ((b[:, 3] - b[:, 1]) + f(1))
+        return (inter / ((carea + areas) - inter)).astype(f)
+
+
+def iou_link_rows(boxes, anchor_frame0, anchor_box, link_thres=0.5, max_frames=0):
+    """The build's tracker plug-in on arrays (parity UNPINNED: the reference's trackers are external
+    MATLAB code).  boxes [F,B,4]; returns rows [F,5] (x1,y1,x2,y2,score), NaN where no box."""
+    F = boxes.shape[0]
+    rows = np.full((F, 5), np.nan, dtype=np.float32)
+    anchor = np.trunc(boxes[anchor_frame0, anchor_box]).astype(np.float32)
+    rows[anchor_frame0] = [anchor[0], anchor[1], anchor[2], anchor[3], 1.0]
+    reach = F if max_frames <= 0 else int(np.ceil((max_frames + 1) / 2.)) - 1
+    for direction in (1, -1):
+        cur = anchor
+        for step in range(1, reach + 1):
+            f = anchor_frame0 + direction * step
+            if f < 0 or f >= F:
+                break
+            ious = _iou_f32_row(cur, boxes[f])
+            ok = ~np.isnan(ious)
+            if not ok.any():
+                break
+            j = int(np.argmax(np.where(ok, ious, np.float32(-1))))
+            if not (float(ious[j]) >= link_thres):
+                break
+            cur = np.trunc(boxes[f, j]).astype(np.float32)
+            rows[f] = [cur[0], cur[1], cur[2], cur[3], ious[j]]
+    return rows
+
+
+def greedy_track_volume(boxes, scores_c, nms_thres=0.3, thres=0.0, max_tracks=10, link_thres=0.5, max_frames=0):
+    """vdet/track.py:189-252 for ONE class on arrays: boxes [F,B,4] f32, scores_c [F,B] f32.
+    Returns (tracks [max_tracks,F,5], anchors [max_tracks,3], ntracks)."""
+    F, B = scores_c.shape
+    frame = np.repeat(np.arange(1, F + 1), B).astype(np.float64)
+    det = np.hstack([frame[:, None], boxes.reshape(-1, 4).astype(np.float64),
+                     scores_c.reshape(-1, 1).astype(np.float64)])
+    order = np.argsort(-det[:, 5], kind='stable')           # :200 sorted(..., reverse=True) is stable
+    det_info = det[order].astype(np.float32)
+    ids_by_frame = {}
+    for i, fr in enumerate(det_info[:, 0]):
+        ids_by_frame.setdefault(int(fr), []).append(i)
+    keep = np.ones(len(det_info), dtype=bool)
+    cur = 0
+    tracks = np.full((max_tracks, F, 5), np.nan, dtype=np.float32)
+    anchors = np.zeros((max_tracks, 3), dtype=np.float32)
+    nt = 0
+    while keep.any() and nt < max_tracks:
+        while cur < len(keep) and not keep[cur]:
+            cur += 1
+        if cur == len(keep):
+            break
+        top = det_info[cur]
+        top_flat = order[cur]
+        cur += 1
+        if top[-1] < thres:
+            break
+        af0 = int(top[0]) - 1
+        rows = iou_link_rows(boxes, af0, int(top_flat - af0 * B), link_thres, max_frames)
+        tracks[nt] = rows
+        anchors[nt] = [af0 + 1, top_flat - af0 * B, top[-1]]
+        nt += 1
+        for f in range(F):
+            if np.isnan(rows[f, 0]):
+                continue
+            det_ids = [i for i in ids_by_frame.get(f + 1, []) if keep[i]]
+            if not det_ids:
+                continue
+            t = np.asarray([[f + 1, rows[f, 0], rows[f, 1], rows[f, 2], rows[f, 3]]], dtype=np.float32)
+            kp = set(track_det_nms(t, det_info[det_ids], nms_thres))
+            for i, det_id in enumerate(det_ids):
+                if i not in kp:
+                    keep[det_id] = False
+    return tracks, anchors, nt

@@ -686,19 +686,21 @@ __global__ __launch_bounds__(256) void walk_kernel(const WalkParams prm)
             int ng = 0;
 #pragma unroll
             for (int k = 0; k < kWalkGrp; ++k) {
-                ls[k] = 0;
+                // slots past the last alive candidate repeat the previous one (their loads hit cache)
+                ls[k] = k ? ls[k - 1] : 0;
                 if (am) { ls[k] = __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)am) - 1); am &= am - 1; ng = k + 1; }
             }
+            // Prefetch the first 128 entries of every list of the group.  The loads are
+            // UNCONDITIONAL (clamped lane index, no exec-masked branch): a guarded load forces hipcc
+            // to drain vmcnt at every join and serialises the whole group.
             uint16_t pre0[kWalkGrp], pre1[kWalkGrp];
 #pragma unroll
             for (int k = 0; k < kWalkGrp; ++k) {
-                pre0[k] = 0; pre1[k] = 0;
-                if (k < ng) {
-                    const uint32_t o = __builtin_amdgcn_readlane(off, ls[k]);
-                    const int d = __builtin_amdgcn_readlane(deg, ls[k]);
-                    if (lane < d) pre0[k] = prm.adj[o + lane];
-                    if (lane + 64 < d) pre1[k] = prm.adj[o + 64 + lane];
-                }
+                const uint32_t o = __builtin_amdgcn_readlane(off, ls[k]);
+                const int d = __builtin_amdgcn_readlane(deg, ls[k]);
+                const int dm = max(d, 1) - 1;
+                pre0[k] = prm.adj[o + min(lane, dm)];
+                pre1[k] = prm.adj[o + min(lane + 64, dm)];
             }
 #pragma unroll
             for (int k = 0; k < kWalkGrp; ++k) {
@@ -721,7 +723,8 @@ __global__ __launch_bounds__(256) void walk_kernel(const WalkParams prm)
                         else atomicOr(const_cast<uint32_t *>(&mask[v >> 5]), 1u << (v & 31));
                     }
                 }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                // no fence needed: the LDS executes one wave's operations in order, the mask
+                // accesses are volatile / atomic on possibly-aliasing words, so hipcc keeps them ordered
             }
         }
     }

@@ -1,0 +1,294 @@
+// track_kernels.hpp -- device-resident greedy tubelet generation for a whole score volume
+// (the array form of greedily_track_from_raw_dets, vdet/track.py:189-252, for every class at once).
+//
+// State per (frame, class): the list of still-kept detections in descending score order
+// (initially the full argsort produced by sort_kernel) + its length.  Because the reference only
+// ever REMOVES detections, "keep[i]" is exactly "i is still in its frame's list", the next anchor is
+// the best list head over the frames, and each track_det_nms call (utils/nms.pyx:128-189) rewrites
+// one list: round 1 drops entries overlapping the track box, round 2 is the greedy walk over what
+// is left (same adjacency lists as the NMS stage), survivors are compacted back in place.
+//
+//   track_pick_kernel      one block per class: next anchor = best head over the frames, honouring
+//                          the reference's monotone cursor (cur_top_det_id never goes back) and its
+//                          stop rule (score < opts.thres).
+//   track_link_kernel      one block per class: the built-in IoU-linking tracker plug-in
+//                          (stand-in for the external MATLAB trackers): from the anchor, frame by
+//                          frame, the proposal with the highest IoU with the current box (>= link_thres).
+//   track_suppress_kernel  one wave per (frame, class) crossed by the new track.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "nms_kernels.hpp"
+
+namespace vdet {
+
+struct TrackState {          // per class
+    int32_t active;          // 0 once the class stopped (low confidence / nothing left / max_tracks)
+    int32_t ntracks;
+    uint32_t last_key;       // global-order position of the last anchor: (key desc, flat index asc)
+    int32_t last_flat;       // -1: none yet
+    int32_t anchor_frame;    // 0-based frame of the current anchor
+    int32_t anchor_box;
+    float anchor_score;
+};
+
+// entry e = (key, flat) is at or before the cursor (ka, fa) in the global order
+__device__ __forceinline__ bool at_or_before(uint32_t k, int flat, uint32_t ka, int fa)
+{
+    return fa >= 0 && (k > ka || (k == ka && flat <= fa));
+}
+
+// ------------------------------------------------------------------------------------------------
+// anchor: for every frame the first list entry after the cursor; best over frames by
+// (score desc, flat index asc) == the stable descending sort of vdet/track.py:200.
+// keys: [F*C, B] sortable keys (transpose_keys_kernel);  lists: [F*C, B] u16;  cnt: [F*C].
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void track_pick_kernel(const uint32_t *__restrict__ keys,
+                                                         const uint16_t *__restrict__ lists,
+                                                         const int32_t *__restrict__ cnt, int F, int B, int C,
+                                                         const float *__restrict__ scores, double thres, int max_tracks,
+                                                         TrackState *__restrict__ st, float *__restrict__ anchors)
+{
+    __shared__ uint32_t sk[256];
+    __shared__ int sf[256];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    TrackState s = st[c];
+    if (!s.active) return;
+    uint32_t bk = 0;
+    int bflat = -1;
+    for (int f = tid; f < F; f += 256) {
+        const int p = f * C + c;
+        const int n = cnt[p];
+        const uint16_t *l = lists + (int64_t)p * B;
+        const uint32_t *kk = keys + (int64_t)p * B;
+        // skip entries at/before the cursor (only the previous anchor itself can be there)
+        int q = 0;
+        while (q < n && at_or_before(kk[l[q]], f * B + l[q], s.last_key, s.last_flat)) ++q;
+        if (q >= n) continue;
+        // ties inside the frame are listed by DESCENDING index; the global rule wants the lowest
+        uint32_t k0 = kk[l[q]];
+        int best = l[q];
+        for (int r = q + 1; r < n && kk[l[r]] == k0; ++r)
+            if (!at_or_before(k0, f * B + l[r], s.last_key, s.last_flat)) best = l[r];
+        const int flat = f * B + best;
+        if (bflat < 0 || k0 > bk || (k0 == bk && flat < bflat)) { bk = k0; bflat = flat; }
+    }
+    sk[tid] = bk;
+    sf[tid] = bflat;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) {
+        if (tid < d) {
+            const uint32_t k2 = sk[tid + d];
+            const int f2 = sf[tid + d];
+            if (f2 >= 0 && (sf[tid] < 0 || k2 > sk[tid] || (k2 == sk[tid] && f2 < sf[tid]))) { sk[tid] = k2; sf[tid] = f2; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        if (sf[0] < 0 || s.ntracks >= max_tracks) { st[c].active = 0; return; }     // "while np.any(keep) and len(tracks) < max_tracks"
+        const int f = sf[0] / B, b = sf[0] - f * B;
+        const float sc = scores[((int64_t)f * B + b) * C + c];
+        st[c].last_key = sk[0];
+        st[c].last_flat = sf[0];
+        if ((double)sc < thres) { st[c].active = 0; return; }                       // vdet/track.py:218 (f32 score vs python float)
+        st[c].anchor_frame = f;
+        st[c].anchor_box = b;
+        st[c].anchor_score = sc;
+        float *a = anchors + ((int64_t)c * max_tracks + s.ntracks) * 3;
+        a[0] = (float)(f + 1);      // 1-based frame id
+        a[1] = (float)b;
+        a[2] = sc;
+    }
+}
+
+// IoU of the current track box (as the "i" box) with a proposal (as "j"), utils/nms.pyx arithmetic
+__device__ __forceinline__ float link_iou(float4 cur, float carea, float4 b)
+{
+    const float xx1 = ref_max(cur.x, b.x), yy1 = ref_max(cur.y, b.y);
+    const float xx2 = ref_min(cur.z, b.z), yy2 = ref_min(cur.w, b.w);
+    const float w = ref_max(0.0f, (xx2 - xx1) + 1.0f), h = ref_max(0.0f, (yy2 - yy1) + 1.0f);
+    const float inter = w * h;
+    return inter / ((carea + box_area(b)) - inter);
+}
+
+__device__ __forceinline__ float4 trunc4(float4 b)   // int(cor) of utils/protocol.py:406
+{
+    return make_float4(truncf(b.x), truncf(b.y), truncf(b.z), truncf(b.w));
+}
+
+// ------------------------------------------------------------------------------------------------
+// built-in tracker: tracks [C, max_tracks, F, 5] rows (x1,y1,x2,y2,score), NaN where the track has
+// no box.  The anchor row is the int-truncated anchor box with score 1; a neighbour frame gets the
+// (int-truncated) proposal with the highest f32 IoU with the current box, first index on ties,
+// while that IoU >= link_t32; at most `reach` frames to each side.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void track_link_kernel(const float4 *__restrict__ boxes, int F, int B, int max_tracks,
+                                                         float link_t32, int reach, const TrackState *__restrict__ st,
+                                                         float *__restrict__ tracks)
+{
+    __shared__ float sv[256];
+    __shared__ int si[256];
+    __shared__ float4 scur;
+    const int c = blockIdx.x, tid = threadIdx.x;
+    const TrackState s = st[c];
+    if (!s.active) return;
+    float *trk = tracks + ((int64_t)c * max_tracks + s.ntracks) * F * 5;
+    const float qnan = __uint_as_float(0x7FC00000u);
+    for (int i = tid; i < F * 5; i += 256) trk[i] = qnan;
+    __syncthreads();
+    const float4 anchor = trunc4(boxes[(int64_t)s.anchor_frame * B + s.anchor_box]);
+    if (tid == 0) {
+        float *r = trk + (int64_t)s.anchor_frame * 5;
+        r[0] = anchor.x; r[1] = anchor.y; r[2] = anchor.z; r[3] = anchor.w; r[4] = 1.0f;
+    }
+    for (int dir = 1; dir >= -1; dir -= 2) {
+        float4 cur = anchor;
+        for (int step = 1; step <= reach; ++step) {
+            const int f = s.anchor_frame + dir * step;
+            if (f < 0 || f >= F) break;
+            const float carea = box_area(cur);
+            float bv = -1.0f;
+            int bi = -1;
+            for (int b = tid; b < B; b += 256) {
+                const float v = link_iou(cur, carea, boxes[(int64_t)f * B + b]);
+                if (v > bv) { bv = v; bi = b; }          // NaN never wins; first index on ties
+            }
+            sv[tid] = bv;
+            si[tid] = bi;
+            __syncthreads();
+            for (int d = 128; d > 0; d >>= 1) {
+                if (tid < d) {
+                    const float v2 = sv[tid + d];
+                    const int i2 = si[tid + d];
+                    if (i2 >= 0 && (si[tid] < 0 || v2 > sv[tid] || (v2 == sv[tid] && i2 < si[tid]))) { sv[tid] = v2; si[tid] = i2; }
+                }
+                __syncthreads();
+            }
+            const float best = sv[0];
+            const int bidx = si[0];
+            __syncthreads();
+            if (bidx < 0 || !(best >= link_t32)) break;
+            if (tid == 0) scur = trunc4(boxes[(int64_t)f * B + bidx]);
+            __syncthreads();
+            cur = scur;
+            if (tid == 0) {
+                float *r = trk + (int64_t)f * 5;
+                r[0] = cur.x; r[1] = cur.y; r[2] = cur.z; r[3] = cur.w; r[4] = best;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// track_det_nms of the new track against every frame it crosses: one wave per (frame, class).
+// ------------------------------------------------------------------------------------------------
+struct SuppressParams {
+    const float4 *boxes;
+    int F, B, C, max_tracks;
+    const GroupDesc *groups;       // one group per frame
+    const uint32_t *row_off;
+    const uint16_t *row_deg;
+    const uint16_t *adj;
+    const uint32_t *group_z;
+    uint16_t *lists;               // [F*C, B] in/out
+    int32_t *cnt;                  // [F*C]   in/out
+    const TrackState *st;
+    const float *tracks;
+    float t32;
+    int *status;
+    int mask_words;
+};
+
+__global__ __launch_bounds__(256) void track_suppress_kernel(const SuppressParams prm)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    volatile uint32_t *mask = reinterpret_cast<uint32_t *>(smem) + w * prm.mask_words;
+    const int p = blockIdx.x * 4 + w;                 // p = f * C + c
+    if (p >= prm.F * prm.C) return;
+    const int f = p / prm.C, c = p - f * prm.C;
+    const TrackState s = prm.st[c];
+    if (!s.active) return;
+    const float *row = prm.tracks + (((int64_t)c * prm.max_tracks + s.ntracks) * prm.F + f) * 5;
+    const float tx1 = row[0];
+    if (tx1 != tx1) return;                           // the track has no box on this frame
+    const float4 tb = make_float4(tx1, row[1], row[2], row[3]);
+    const float tarea = box_area(tb);
+    const int B = prm.B, rb = prm.groups[f].box_off;
+    uint16_t *list = prm.lists + (int64_t)p * B;
+    const int n = prm.cnt[p];
+    if (n == 0) return;
+    const bool has_z = prm.group_z[f] != 0;
+
+    for (int i = lane; i < ((B + 31) >> 5); i += 64) mask[i] = 0u;
+    if (has_z) {   // detections that left the list earlier are "not in d": dead for the zero-union rule
+        for (int i = lane; i < ((B + 31) >> 5); i += 64) mask[i] = 0xFFFFFFFFu;
+        for (int q = lane; q < n; q += 64) {
+            const int v = list[q];
+            atomicAnd(const_cast<uint32_t *>(&mask[v >> 5]), ~(1u << (v & 31)));
+        }
+    }
+    int nk = 0, bad = 0;
+    for (int q0 = 0; q0 < n; q0 += 64) {
+        const int q = q0 + lane;
+        const bool valid = q < n;
+        const int cidx = valid ? (int)list[q] : 0;
+        // round 1 (utils/nms.pyx:163-183): the DET is the "i" box, the track the "j" box
+        bool r1 = false;
+        if (valid) {
+            const float4 bd = prm.boxes[rb + cidx];
+            const uint32_t pp = pair_pred(bd, box_area(bd), tb, tarea, prm.t32);
+            if (pp & 2u) bad = 1;
+            r1 = (pp & 1u) != 0;
+        }
+        if (r1) atomicOr(const_cast<uint32_t *>(&mask[cidx >> 5]), 1u << (cidx & 31));
+        const bool alive = valid && !r1 && !((mask[cidx >> 5] >> (cidx & 31)) & 1u);
+        unsigned long long am = __ballot(alive);
+        const uint32_t off = alive ? prm.row_off[rb + cidx] : 0u;
+        const int deg = alive ? (int)prm.row_deg[rb + cidx] : 0;
+        while (am) {
+            const int l = __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)am) - 1);
+            am &= am - 1;
+            const int cu = __builtin_amdgcn_readlane(cidx, l);
+            if ((mask[cu >> 5] >> (cu & 31)) & 1u) continue;
+            if (lane == 0) { list[nk] = (uint16_t)cu; atomicOr(const_cast<uint32_t *>(&mask[cu >> 5]), 1u << (cu & 31)); }
+            ++nk;
+            const uint32_t o = __builtin_amdgcn_readlane(off, l);
+            const int d = __builtin_amdgcn_readlane(deg, l);
+            for (int e0 = 0; e0 < d; e0 += 64) {
+                if (e0 + lane < d) {
+                    const uint16_t e = prm.adj[o + e0 + lane];
+                    const int v = e & 0x7FFF;
+                    if (e & kZTag) { if (!((mask[v >> 5] >> (v & 31)) & 1u)) bad = 1; }
+                    else atomicOr(const_cast<uint32_t *>(&mask[v >> 5]), 1u << (v & 31));
+                }
+            }
+        }
+        // NOTE on the in-place compaction: list[nk] is written only after list[q0..q0+63] was read
+        // (nk <= q0 + 64), by this wave, in program order.
+    }
+    if (lane == 0) prm.cnt[p] = nk;
+    if (__ballot(bad != 0) && lane == 0) atomicOr(prm.status, kStDivZero);
+}
+
+// close the iteration: count the finished track
+__global__ void track_commit_kernel(TrackState *__restrict__ st, int C, int32_t *__restrict__ ntracks_out)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    if (st[c].active) st[c].ntracks += 1;
+    ntracks_out[c] = st[c].ntracks;
+}
+
+__global__ void track_init_kernel(TrackState *__restrict__ st, int C)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    TrackState s;
+    s.active = 1; s.ntracks = 0; s.last_key = 0; s.last_flat = -1; s.anchor_frame = 0; s.anchor_box = 0; s.anchor_score = 0.f;
+    st[c] = s;
+}
+
+}  // namespace vdet

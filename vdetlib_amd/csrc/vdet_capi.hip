@@ -17,6 +17,7 @@
 #include "nms_kernels.hpp"
 #include "temporal_kernels.hpp"
 #include "tubelet_kernels.hpp"
+#include "track_kernels.hpp"
 
 using namespace vdet;
 
@@ -71,7 +72,7 @@ struct vdet_ctx {
     int n_cu = 256;
     // scratch
     DevBuf boxes, scores, keys, excl, frames, groups, tiles, bits, rowz, rowoff, rowdeg, groupz, adj, comp, origidx,
-        out64, trk_frames, trk_boxes, b1, b2, iou_out, order, ncand, keepidx, keepcnt, gflags, pairs, tkeys, tmp[8];
+        out64, trk_frames, trk_boxes, b1, b2, iou_out, order, ncand, keepidx, keepcnt, gflags, pairs, tkeys, tstate, tmp[8];
     // timing
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -300,6 +301,7 @@ int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32)
 
 // K3 + K4 for P problems.  d_order / d_ncand / keep buffers are caller-provided device pointers.
 struct SortWalkArgs {
+    bool sort_only = false;       // tracking: only the per-problem lists are wanted
     int mode, P, B, C;
     const float *scores;
     const uint32_t *keys;
@@ -385,6 +387,7 @@ int launch_sort_walk(vdet_ctx *c, const SortWalkArgs &a, int nmax, int64_t order
         HIPCHK(c, hipLaunchKernel(var->fn[c->atomic_rank ? 1 : 0], dim3(grid), dim3(block), args, lds, c->stream));
     }
     HIPCHK(c, hipGetLastError());
+    if (a.sort_only) return VDET_OK;
     WalkParams wp{};
     wp.mode = a.mode; wp.P = a.P; wp.B = a.B; wp.C = a.C;
     wp.groups = c->groups.as<GroupDesc>();
@@ -585,7 +588,7 @@ int vdet_destroy(vdet_ctx *c)
     DevBuf *bufs[] = {&c->boxes, &c->scores, &c->keys, &c->excl, &c->frames, &c->groups, &c->tiles, &c->bits,
                       &c->rowz, &c->rowoff, &c->rowdeg, &c->groupz, &c->adj, &c->comp, &c->origidx, &c->out64,
                       &c->trk_frames, &c->trk_boxes, &c->b1, &c->b2, &c->iou_out, &c->order, &c->ncand, &c->keepidx,
-                      &c->keepcnt, &c->gflags, &c->pairs, &c->tkeys};
+                      &c->keepcnt, &c->gflags, &c->pairs, &c->tkeys, &c->tstate};
     for (DevBuf *b : bufs) b->release();
     for (DevBuf &b : c->tmp) b.release();
     for (auto &e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -838,6 +841,83 @@ int vdet_nms_volume(vdet_ctx *c, const float *d_boxes, const float *d_scores, in
     a.use_thr = use_score_thresh; a.thr = score_thresh;
     a.keep_idx = d_keep_idx; a.keep_cnt = d_keep_cnt; a.cap = cap;
     return launch_sort_walk(c, a, (int)B, F * C * B);
+}
+
+// ---------------------------------------------------------------------------------------------
+int vdet_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scores, int64_t F, int64_t B, int64_t C,
+                      double nms_thres, double thres, int max_tracks, double link_thres, int max_frames,
+                      float *d_tracks, float *d_anchors, int32_t *d_ntracks)
+{
+    if (!c) return VDET_EINVAL;
+    if (F <= 0 || B <= 0 || C <= 0 || max_tracks < 0) return fail(c, VDET_EINVAL, "bad shape");
+    if (!d_boxes || !d_scores || !d_ntracks || (max_tracks > 0 && (!d_tracks || !d_anchors)))
+        return fail(c, VDET_EINVAL, "null buffer");
+    if (B > 32767) return fail(c, VDET_EINVAL, "B = %lld boxes per frame; the limit is 32767", (long long)B);
+    if (F * C > 0x7FFFFFF0ll || F * B > 0x7FFFFFF0ll) return fail(c, VDET_EINVAL, "volume too large");
+    if (((uintptr_t)d_boxes & 15) != 0) return fail(c, VDET_EINVAL, "d_boxes must be 16-byte aligned");
+    HIPCHK(c, hipSetDevice(c->device));
+    timing_reset(c);
+    NmsPlan pl;
+    pl.groups.resize((size_t)F);
+    for (int64_t f = 0; f < F; ++f) pl.groups[(size_t)f] = {(int32_t)(f * B), (int32_t)B, 0};
+    make_plan(c, pl);
+    const float t32 = thresh_to_f32(nms_thres);
+    int rc = build_graph(c, reinterpret_cast<const float4 *>(d_boxes), pl, t32);
+    if (rc) return rc;
+    // descending lists per (frame, class): always through the transposed keys (pick needs them)
+    const bool saved = c->no_transpose;
+    c->no_transpose = false;
+    SortWalkArgs a{};
+    a.sort_only = true;
+    a.mode = 0; a.P = (int)(F * C); a.B = (int)B; a.C = (int)C;
+    a.scores = d_scores;
+    rc = launch_sort_walk(c, a, (int)B, F * C * B);
+    c->no_transpose = saved;
+    if (rc) return rc;
+    HIPCHK(c, c->tstate.reserve((size_t)C * sizeof(TrackState)));
+    TrackState *st = c->tstate.as<TrackState>();
+    const unsigned cg = (unsigned)((C + 63) / 64);
+    hipLaunchKernelGGL(track_init_kernel, dim3(cg), dim3(64), 0, c->stream, st, (int)C);
+    HIPCHK(c, hipMemsetAsync(d_ntracks, 0, (size_t)C * 4, c->stream));
+    const int reach = max_frames > 0 ? (int)std::ceil((max_frames + 1) / 2.0) - 1 : (int)F;
+    SuppressParams sp{};
+    sp.boxes = reinterpret_cast<const float4 *>(d_boxes);
+    sp.F = (int)F; sp.B = (int)B; sp.C = (int)C; sp.max_tracks = max_tracks;
+    sp.groups = c->groups.as<GroupDesc>();
+    sp.row_off = c->rowoff.as<uint32_t>();
+    sp.row_deg = c->rowdeg.as<uint16_t>();
+    sp.adj = c->adj.as<uint16_t>();
+    sp.group_z = c->groupz.as<uint32_t>();
+    sp.lists = c->order.as<uint16_t>();
+    sp.cnt = c->ncand.as<int32_t>();
+    sp.st = st;
+    sp.tracks = d_tracks;
+    sp.t32 = t32;
+    sp.status = &c->d_cnt->status;
+    sp.mask_words = (int)((((size_t)4 * ((B + 31) / 32) + 15) & ~(size_t)15) / 4);
+    const float link_t32 = thresh_to_f32(link_thres);
+    for (int t = 0; t < max_tracks; ++t) {
+        {
+            StageTimer tm(c, ST_OTHER);
+            hipLaunchKernelGGL(track_pick_kernel, dim3((unsigned)C), dim3(256), 0, c->stream, c->tkeys.as<uint32_t>(),
+                               c->order.as<uint16_t>(), c->ncand.as<int32_t>(), (int)F, (int)B, (int)C, d_scores, thres,
+                               max_tracks, st, d_anchors);
+        }
+        {
+            StageTimer tm(c, ST_IOU_GEN);
+            hipLaunchKernelGGL(track_link_kernel, dim3((unsigned)C), dim3(256), 0, c->stream,
+                               reinterpret_cast<const float4 *>(d_boxes), (int)F, (int)B, max_tracks, link_t32, reach, st,
+                               d_tracks);
+        }
+        {
+            StageTimer tm(c, ST_WALK);
+            hipLaunchKernelGGL(track_suppress_kernel, dim3((unsigned)((F * C + 3) / 4)), dim3(256),
+                               (size_t)sp.mask_words * 16, c->stream, sp);
+        }
+        hipLaunchKernelGGL(track_commit_kernel, dim3(cg), dim3(64), 0, c->stream, st, (int)C, d_ntracks);
+    }
+    HIPCHK(c, hipGetLastError());
+    return VDET_OK;
 }
 
 // ---------------------------------------------------------------------------------------------

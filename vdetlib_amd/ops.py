@@ -110,3 +110,50 @@ def iou(boxes1, boxes2):
         ctx.check(ctx.lib.vdet_iou_f64(ctx.h, b1.ctypes.data, b1.shape[0], b2.ctypes.data, b2.shape[0],
                                        out.ctypes.data))
     return out
+
+
+def track_volume(boxes, scores, nms_thres=0.3, thres=0.0, max_tracks=10, link_thres=0.5, max_frames=0, sync=True):
+    """Greedy tubelet generation for EVERY class of a video on the GPU: the array form of
+    greedily_track_from_raw_dets (vdet/track.py:189-252) with the built-in IoU-linking tracker as
+    ``track_method`` (the reference's trackers are external MATLAB code).
+
+    boxes [F,B,4] f32, scores [F,B,C] f32.  Returns
+      tracks  [C, max_tracks, F, 5] f32 rows (x1,y1,x2,y2,score), NaN where a track has no box,
+      anchors [C, max_tracks, 3] f32 (1-based frame, box index, score),  ntracks [C] int32."""
+    if boxes.dtype != torch.float32 or scores.dtype != torch.float32:
+        raise ValueError("Buffer dtype mismatch, expected 'float32_t'")
+    boxes = boxes.contiguous()
+    scores = scores.contiguous()
+    F, B, C = scores.shape
+    if tuple(boxes.shape) != (F, B, 4):
+        raise ValueError("boxes must be [F,B,4]")
+    ctx = _ctx_for(boxes)
+    tracks = torch.full((C, max_tracks, F, 5), float('nan'), dtype=torch.float32, device=boxes.device)
+    anchors = torch.zeros((C, max_tracks, 3), dtype=torch.float32, device=boxes.device)
+    ntracks = torch.zeros((C,), dtype=torch.int32, device=boxes.device)
+    ctx.check(ctx.lib.vdet_track_volume(ctx.h, boxes.data_ptr(), scores.data_ptr(), F, B, C, float(nms_thres),
+                                        float(thres), int(max_tracks), float(link_thres), int(max_frames),
+                                        tracks.data_ptr(), anchors.data_ptr(), ntracks.data_ptr()))
+    if sync:
+        ctx.sync()
+    return tracks, anchors, ntracks
+
+
+def tracks_to_proto(video_name, tracks, anchors, ntracks, method='iou_link_tracker'):
+    """One class's device tracks -> a .track protocol dict (utils/protocol.py:389-414 fields)."""
+    from .utils.protocol import bbox_hash
+    tr = tracks.cpu().numpy() if hasattr(tracks, 'cpu') else np.asarray(tracks)
+    an = anchors.cpu().numpy() if hasattr(anchors, 'cpu') else np.asarray(anchors)
+    out = []
+    for t in range(int(ntracks)):
+        anchor_frame = int(an[t, 0])
+        tracklet = []
+        for f in range(tr.shape[1]):
+            row = tr[t, f]
+            if np.isnan(row[0]):
+                continue
+            bbox = [int(v) for v in row[:4]]
+            tracklet.append({'frame': f + 1, 'bbox': bbox, 'hash': bbox_hash(video_name, f + 1, row),
+                             'score': float(row[4]), 'anchor': int(f + 1 - anchor_frame)})
+        out.append(tracklet)
+    return {'video': video_name, 'method': method, 'tracks': out}
