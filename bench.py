@@ -5,12 +5,16 @@
     (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL)
 
 A "step" = one pass of the hot path over one synthetic video per GPU, inputs already resident in
-HBM: per-(frame,class) greedy NMS of all boxes (vdet/image_det.py:117-123 over
-vdet/video_det.py:89-99 == utils/nms.pyx vid_nms per class) + the temporal pass over the
-[frame x box x class] score volume (vdet/tubelet_cls.py:386-414), and for N > 1 the RCCL all-gather
-of the per-video results (top-100 kept indices per (frame,class) + counts).  Workload at N=1 =
-BASELINE.json configs[1]: 300 frames x 10 000 boxes x 200 classes.  Videos are sharded one per
-GPU ("weak" scaling: per-GPU work fixed).
+HBM:
+  NMS   per-(frame,class) greedy NMS of all boxes (vdet/image_det.py:117-123 over
+        vdet/video_det.py:89-99 == utils/nms.pyx vid_nms per class),
+  TEMP  the temporal pass over the [frame x box x class] score volume (vdet/tubelet_cls.py:386-414),
+  LINK  greedy tubelet generation for every class (vdet/track.py:189-252, built-in IoU-linking
+        tracker, track_det_nms suppression) + tubelet re-scoring: spatial max-pooling / box
+        regression, completion, temporal max-pool (vdet/tubelet_cls.py:493-535, :284-303, :386-414),
+and for N > 1 the RCCL all-gather of the per-video results (final tubelets + per-(frame,class) kept
+counts).  Workload at N=1 = BASELINE.json configs[1] (+ configs[2]'s tracking on the same video):
+300 frames x 10 000 boxes x 200 classes.  Videos are sharded one per GPU ("weak" scaling).
 
 Prints ONE JSON line (rank 0) with BASELINE.json's metric plus `roofline` and `cpu_baseline`.
 """
@@ -43,14 +47,19 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=300)
     ap.add_argument("--boxes", type=int, default=10000)
     ap.add_argument("--classes", type=int, default=200)
     ap.add_argument("--cap", type=int, default=2048, help="survivor capacity per (frame,class)")
     ap.add_argument("--window", type=int, default=3)
     ap.add_argument("--thresh", type=float, default=0.3)
-    ap.add_argument("--cpu-problems", type=int, default=120, help="(frame,class) problems timed on the CPU oracle")
+    ap.add_argument("--max-tracks", type=int, default=10)
+    ap.add_argument("--track-thres", type=float, default=0.9, help="stop tracking below this score (90th percentile)")
+    ap.add_argument("--link-thres", type=float, default=0.5)
+    ap.add_argument("--pool-thres", type=float, default=0.7)
+    ap.add_argument("--no-link", action="store_true", help="NMS + temporal only")
+    ap.add_argument("--cpu-problems", type=int, default=1200, help="(frame,class) problems timed on the CPU oracle")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
@@ -71,14 +80,29 @@ def main():
     ctx = _lib.get_context(local)
     gathered = None
 
+    ctx.set_cache(True)      # NMS and LINK of one step share the suppression graph and the sorted lists
+
     def step():
         nonlocal gathered
+        ctx.invalidate()     # a new video: nothing may be reused from the previous step
         keep_idx, keep_cnt = ops.nms_volume(boxes, scores, args.thresh, cap=args.cap, sync=False)
         pooled = ops.temporal_maxpool(scores, args.window)
+        tub = None
+        if not args.no_link:
+            tracks, anchors, ntracks = ops.track_volume(boxes, scores, nms_thres=args.thresh, thres=args.track_thres,
+                                                        max_tracks=args.max_tracks, link_thres=args.link_thres,
+                                                        sync=False)
+            det, tpool, tboxes = ops.rescore_tracks(tracks, ntracks, boxes, scores, overlap_thres=args.pool_thres,
+                                                    window=args.window, sync=False)
+            tub = (tracks, ntracks, tpool, tboxes)
         if world > 1:   # the one exchange step: RCCL all-gather of the per-video results over xGMI
-            top = keep_idx[:, :, :TOPK].contiguous()
-            gathered = vdist.gather_video_results([rank], top[None], torch.clamp(keep_cnt, max=TOPK)[None])
-        return keep_idx, keep_cnt, pooled
+            if tub is not None:
+                payload = torch.cat([tub[3].reshape(C, -1), tub[2].to(torch.float32).reshape(C, -1)], 1)
+                gathered = (vdist.all_gather_ragged(payload[None]), vdist.all_gather_ragged(keep_cnt[None]))
+            else:
+                top = keep_idx[:, :, :TOPK].contiguous()
+                gathered = vdist.gather_video_results([rank], top[None], torch.clamp(keep_cnt, max=TOPK)[None])
+        return keep_idx, keep_cnt, pooled, tub
 
     def fence():
         if world > 1:
@@ -105,17 +129,13 @@ def main():
     # ---- per-kernel timing (HIP events on the kernels' stream), outside the timed region
     result = None
     if rank == 0:
-        ctx.set_timing(True)
+        ctx.set_timing(2)
         reps = 3
-        agg = {}
         for _ in range(reps):
-            ops.nms_volume(boxes, scores, args.thresh, cap=args.cap, sync=True)
-            for k, (ms, n) in ctx.last_timing().items():
-                a = agg.setdefault(k, [0.0, 0]); a[0] += ms; a[1] += n
-            ops.temporal_maxpool(scores, args.window)
-            for k, (ms, n) in ctx.last_timing().items():
-                a = agg.setdefault(k, [0.0, 0]); a[0] += ms; a[1] += n
-        ctx.set_timing(False)
+            step()
+        ctx.sync()
+        agg = {k: [ms, n] for k, (ms, n) in ctx.last_timing().items()}
+        ctx.set_timing(0)
         stages = {k: {"ms_per_step": v[0] / reps, "launches_per_step": v[1] // reps,
                       "avg_launch_ms": (v[0] / v[1]) if v[1] else 0.0} for k, v in agg.items() if v[1]}
         dom = max(stages, key=lambda k: stages[k]["ms_per_step"])
@@ -144,7 +164,7 @@ def main():
             from oracle import oracle
             oracle.build()
             nprob = max(1, args.cpu_problems)
-            nf = min(F, 3)
+            nf = min(F, 6)
             nc = min(C, max(1, nprob // nf))
             hb = boxes[:nf].cpu().numpy()
             hs = scores[:nf, :, :nc].contiguous().cpu().numpy()
@@ -154,8 +174,9 @@ def main():
             cdt = time.perf_counter() - t1
             cpu_boxes = nf * B * (nc / C)
             cpu = {"value": cpu_boxes / cdt, "unit": "boxes/s", "cores": 1, "kind": "port",
-                   "sample": "%d frames x %d classes x %d boxes (%d nms problems + temporal max-pool) in %.1f s, "
-                             "oracle/vdet_oracle.c single thread" % (nf, nc, B, nf * nc, cdt)}
+                   "sample": "NMS+TEMP stages on %d frames x %d classes x %d boxes (%d nms problems + temporal "
+                             "max-pool) in %.1f s, oracle/vdet_oracle.c single thread; LINK not included (the C "
+                             "oracle's track_det_nms loop is exercised in tests/)" % (nf, nc, B, nf * nc, cdt)}
             # and use the sample as a last parity check of this very run
             gi = out[0][:nf, :nc].cpu().numpy()
             gc = out[1][:nf, :nc].cpu().numpy()
@@ -166,10 +187,13 @@ def main():
             "value": boxes_per_s, "unit": "boxes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1]: 1 video/GPU, %d frames x %d boxes x %d classes; per-(frame,class) "
-                                   "NMS thresh %.2f + temporal max-pool w=%d%s" %
-                                   (F, B, C, args.thresh, args.window,
-                                    "; RCCL all-gather of top-%d kept/(frame,class)" % TOPK if world > 1 else ""),
+            "config": {"workload": "configs[1]%s: 1 video/GPU, %d frames x %d boxes x %d classes; per-(frame,class) "
+                                   "NMS thresh %.2f + temporal max-pool w=%d%s%s" %
+                                   ("" if args.no_link else "+[2]", F, B, C, args.thresh, args.window,
+                                    "" if args.no_link else "; greedy tubelets: %d tracks/class (stop < %.2f), IoU-link "
+                                    ">= %.2f, spatial max-pool IoU > %.2f + completion + temporal max-pool" %
+                                    (args.max_tracks, args.track_thres, args.link_thres, args.pool_thres),
+                                    "; RCCL all-gather of the final tubelets + kept counts" if world > 1 else ""),
                        "frames": F, "boxes": B, "classes": C, "parallelism": "video-per-gpu x%d" % world},
             "roofline": roofline, "cpu_baseline": cpu,
         }

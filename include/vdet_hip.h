@@ -64,17 +64,27 @@ int vdet_sync(vdet_ctx *ctx);
 const char *vdet_last_error(vdet_ctx *ctx);
 /* "vdet_hip <version> gfx950" */
 const char *vdet_version(void);
-/* Wall-clock (ms, HIP events on the context's stream) of the kernels enqueued by the most recent
- * d_* call, by stage; used by bench.py for the roofline object.  out[8]: 0 iou_bits_sym (K1s), 1
- * adj_build (K2), 2 sort (K3), 3 walk (K4), 4 temporal, 5 merge sort, 6 iou_bits general (K1), 7 other. */
-int vdet_last_timing_ms(vdet_ctx *ctx, float *out8);
+/* Wall-clock (ms, HIP events on the context's stream) of the kernels enqueued since the events were
+ * last read, summed by stage; used by bench.py for the roofline object.  out[16]: 0 iou_bits_sym
+ * (K1s), 1 adj_build (K2), 2 sort (K3), 3 walk (K4), 4 temporal, 5 merge sort, 6 iou_bits general
+ * (K1), 7 other, 8 transpose_keys, 9 track_pick, 10 track_link, 11 track_suppress,
+ * 12 rescore_spatial, 13 rescore_series, 14-15 unused. */
+int vdet_last_timing_ms(vdet_ctx *ctx, float *out16);
 /* Number of timed launches per stage behind the sums of vdet_last_timing_ms (call it first). */
-int vdet_last_launches(vdet_ctx *ctx, int *out8);
+int vdet_last_launches(vdet_ctx *ctx, int *out16);
+/* Opt-in reuse of the per-video preparation between d_* calls: with the cache enabled,
+ * vdet_nms_volume / vdet_track_volume skip the suppression-graph build (same d_boxes pointer, shape
+ * and threshold) and the per-(frame,class) sort (same d_scores pointer/layout) of the previous call.
+ * The CALLER promises the buffers' contents did not change; vdet_invalidate() drops the cache (call
+ * it whenever a buffer was rewritten in place).  Default: disabled. */
+int vdet_set_cache(vdet_ctx *ctx, int enable);
+int vdet_invalidate(vdet_ctx *ctx);
 /* Introspection: what = 0 -> 1 if the per-(frame,class) sort uses the returning-LDS-atomic rank
  * (selected by a hardware self-test at vdet_create), 0 if it uses the ballot match;
  * what = 1 -> number of compute units. */
 int vdet_query(vdet_ctx *ctx, int what);
-/* Enable (1) / disable (0) per-stage HIP-event timing (default off: events cost launches). */
+/* Per-stage HIP-event timing: 0 off (default), 1 on (events of the most recent call), 2 on and
+ * accumulating over calls until vdet_last_timing_ms reads them. */
 int vdet_set_timing(vdet_ctx *ctx, int enable);
 
 /* ---- utils/cython_nms replacements (host buffers, synchronous) ------------------------------- */
@@ -206,6 +216,22 @@ int vdet_temporal_conv_f32(vdet_ctx *ctx, const float *d_in, float *d_out, int64
 int vdet_track_volume(vdet_ctx *ctx, const float *d_boxes, const float *d_scores, int64_t F, int64_t B,
                       int64_t C, double nms_thres, double thres, int max_tracks, double link_thres,
                       int max_frames, float *d_tracks, float *d_anchors, int32_t *d_ntracks);
+
+/*
+ * Re-scoring of the device tracks: raw_dets_spatial_max_pooling (vdet/tubelet_cls.py:493-535: for
+ * every tubelet box the best-scoring detection of its frame with float64 iou > overlap_thres gives
+ * det_score and replaces the box -- the "box regression"), do_score_completion (:284-303) and
+ * score_proto_temporal_maxpool(window) (:386-414; window 1 = none).
+ *   d_tracks [C,T,F,5], d_ntracks [C] as produced by vdet_track_volume
+ *   d_det_score [C,T,F] f64: completed spatial-max-pool score;  d_pooled [C,T,F] f64: after the
+ *   temporal max-pool;  d_boxes_out [C,T,F,4] f32;  NaN where a track has no box.
+ * Latches VDET_EINDEX where the reference raises IndexError (a tubelet without any overlapping
+ * detection).
+ */
+int vdet_rescore_tracks(vdet_ctx *ctx, const float *d_tracks, const int32_t *d_ntracks, const float *d_boxes,
+                        const float *d_scores, int64_t F, int64_t B, int64_t C, int max_tracks,
+                        double overlap_thres, int window, double *d_det_score, double *d_pooled,
+                        float *d_boxes_out);
 
 #ifdef __cplusplus
 }

@@ -65,3 +65,42 @@ def test_tracks_to_proto_and_host_api_agree(oracle):
                           boxes.reshape(-1, 4).astype(np.float64), scores.reshape(F * B, C).astype(np.float64)])
     want = K.greedily_track_from_raw_dets(vid, det_info, iou_link_tracker, c + 1, Cm.options({'max_tracks': 3, 'thres': 0.2}))
     assert want['tracks'] == proto['tracks']
+
+
+def test_rescore_tracks_vs_oracle(oracle):
+    import torch
+    from vdetlib_amd import ops
+    F, B, C = 10, 250, 3
+    boxes, scores = _coherent_video(21, F, B, C, jitter=6)
+    tb, ts = torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda()
+    tr, an, nt = ops.track_volume(tb, ts, thres=0.1, max_tracks=4, link_thres=0.4)
+    for thr, w in ((0.7, 3), (0.5, 5), (0.85, 1)):
+        try:
+            det, pooled, ob = ops.rescore_tracks(tr, nt, tb, ts, overlap_thres=thr, window=w)
+            failed = False
+        except IndexError:
+            failed = True
+        trh, nth = tr.cpu().numpy(), nt.cpu().numpy()
+        want_fail = False
+        for c in range(C):
+            for t in range(nth[c]):
+                frames = [f for f in range(F) if not np.isnan(trh[c, t, f, 0])]
+                s, bx = [], []
+                for f in frames:
+                    ss, bb, hit = oracle.spatial_maxpool([trh[c, t, f, :4]], boxes[f], scores[f, :, c], thr)
+                    s.append(ss[0]); bx.append(bb[0])
+                try:
+                    comp = oracle.score_completion(s)
+                except IndexError:
+                    want_fail = True
+                    continue
+                if failed:
+                    continue
+                pool = comp.copy()
+                h = w // 2
+                for i in range(len(comp)):
+                    pool[i] = max([comp[g] if 0 <= g < len(comp) else -1e5 for g in range(i - h, i + h + 1)])
+                assert np.array_equal(det[c, t].cpu().numpy()[frames], comp), (thr, c, t)
+                assert np.array_equal(pooled[c, t].cpu().numpy()[frames], pool), (thr, c, t)
+                assert np.array_equal(ob[c, t].cpu().numpy()[frames], np.asarray(bx, dtype=np.float32)), (thr, c, t)
+        assert failed == want_fail

@@ -28,6 +28,8 @@ SYMBOLS = {
     "vdet_last_launches": (_ci, [_vp, _vp]),
     "vdet_set_timing": (_ci, [_vp, _ci]),
     "vdet_query": (_ci, [_vp, _ci]),
+    "vdet_set_cache": (_ci, [_vp, _ci]),
+    "vdet_invalidate": (_ci, [_vp]),
     "vdet_nms_f32": (_ci, [_vp, _vp, _i64, _i64, _ci, _f64, _vp, _vp, ctypes.POINTER(_i64)]),
     "vdet_track_det_nms_f32": (_ci, [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _f64, _vp, ctypes.POINTER(_i64)]),
     "vdet_iou_f64": (_ci, [_vp, _vp, _i64, _vp, _i64, _vp]),
@@ -38,6 +40,7 @@ SYMBOLS = {
     "vdet_threshold_topk": (_ci, [_vp, _vp, _ci, _i64, _i64, _ci, _ci, _f64, _ci, _vp, _vp]),
     "vdet_nms_volume": (_ci, [_vp, _vp, _vp, _ci, _i64, _i64, _i64, _f64, _ci, _f32, _vp, _vp, _i64]),
     "vdet_track_volume": (_ci, [_vp, _vp, _vp, _i64, _i64, _i64, _f64, _f64, _ci, _f64, _ci, _vp, _vp, _vp]),
+    "vdet_rescore_tracks": (_ci, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _ci, _f64, _ci, _vp, _vp, _vp]),
     "vdet_temporal_maxpool_f32": (_ci, [_vp, _vp, _vp, _i64, _i64, _ci, _f32]),
     "vdet_temporal_conv_f32": (_ci, [_vp, _vp, _vp, _i64, _i64, _vp, _ci, _f32, _f32]),
 }
@@ -134,18 +137,27 @@ class Context(object):
     def sync(self):
         self.check(self.lib.vdet_sync(self.h))
 
+    def set_cache(self, on):
+        self.check(self.lib.vdet_set_cache(self.h, 1 if on else 0))
+
+    def invalidate(self):
+        self.check(self.lib.vdet_invalidate(self.h))
+
     def query(self, what):
         return int(self.lib.vdet_query(self.h, int(what)))
 
     def set_timing(self, on):
-        self.check(self.lib.vdet_set_timing(self.h, 1 if on else 0))
+        """False/0 off, True/1 on, 2 = accumulate over calls until last_timing() reads."""
+        self.check(self.lib.vdet_set_timing(self.h, int(on)))
 
     def last_timing(self):
-        ms = (ctypes.c_float * 8)()
-        n = (ctypes.c_int * 8)()
+        ms = (ctypes.c_float * 16)()
+        n = (ctypes.c_int * 16)()
         self.check(self.lib.vdet_last_timing_ms(self.h, ms))
         self.check(self.lib.vdet_last_launches(self.h, n))
-        names = ["iou_bits", "adj_build", "sort", "walk", "temporal", "merge_sort", "iou_bits_general", "other"]
+        names = ["iou_bits", "adj_build", "sort", "walk", "temporal", "merge_sort", "iou_bits_general", "other",
+                 "transpose_keys", "track_pick", "track_link", "track_suppress", "rescore_spatial", "rescore_series",
+                 "_14", "_15"]
         return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(names)}
 
 

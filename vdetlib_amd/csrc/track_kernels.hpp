@@ -20,6 +20,7 @@
 #include <stdint.h>
 
 #include "nms_kernels.hpp"
+#include "tubelet_kernels.hpp"
 
 namespace vdet {
 
@@ -123,60 +124,64 @@ __device__ __forceinline__ float4 trunc4(float4 b)   // int(cor) of utils/protoc
 // (int-truncated) proposal with the highest f32 IoU with the current box, first index on ties,
 // while that IoU >= link_t32; at most `reach` frames to each side.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void track_link_kernel(const float4 *__restrict__ boxes, int F, int B, int max_tracks,
-                                                         float link_t32, int reach, const TrackState *__restrict__ st,
-                                                         float *__restrict__ tracks)
+// grid = (C, 2): blockIdx.y = 0 links forward (and writes the anchor row), 1 backward; block = 1024.
+// One barrier per frame: wave-level argmax by shuffles, 16 partial results in a parity-double-
+// buffered LDS slot, every thread finishes the reduction redundantly.
+__global__ __launch_bounds__(1024) void track_link_kernel(const float4 *__restrict__ boxes, int F, int B, int max_tracks,
+                                                          float link_t32, int reach, const TrackState *__restrict__ st,
+                                                          float *__restrict__ tracks)
 {
-    __shared__ float sv[256];
-    __shared__ int si[256];
-    __shared__ float4 scur;
-    const int c = blockIdx.x, tid = threadIdx.x;
+    __shared__ float sv[2][16];
+    __shared__ int si[2][16];
+    const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int dir = blockIdx.y == 0 ? 1 : -1;
     const TrackState s = st[c];
     if (!s.active) return;
     float *trk = tracks + ((int64_t)c * max_tracks + s.ntracks) * F * 5;
     const float qnan = __uint_as_float(0x7FC00000u);
-    for (int i = tid; i < F * 5; i += 256) trk[i] = qnan;
+    // my half of the track starts empty
+    if (dir > 0) { for (int i = s.anchor_frame * 5 + tid; i < F * 5; i += 1024) trk[i] = qnan; }
+    else { for (int i = tid; i < s.anchor_frame * 5; i += 1024) trk[i] = qnan; }
     __syncthreads();
     const float4 anchor = trunc4(boxes[(int64_t)s.anchor_frame * B + s.anchor_box]);
-    if (tid == 0) {
+    if (dir > 0 && tid == 0) {
         float *r = trk + (int64_t)s.anchor_frame * 5;
         r[0] = anchor.x; r[1] = anchor.y; r[2] = anchor.z; r[3] = anchor.w; r[4] = 1.0f;
     }
-    for (int dir = 1; dir >= -1; dir -= 2) {
-        float4 cur = anchor;
-        for (int step = 1; step <= reach; ++step) {
-            const int f = s.anchor_frame + dir * step;
-            if (f < 0 || f >= F) break;
-            const float carea = box_area(cur);
-            float bv = -1.0f;
-            int bi = -1;
-            for (int b = tid; b < B; b += 256) {
-                const float v = link_iou(cur, carea, boxes[(int64_t)f * B + b]);
-                if (v > bv) { bv = v; bi = b; }          // NaN never wins; first index on ties
-            }
-            sv[tid] = bv;
-            si[tid] = bi;
-            __syncthreads();
-            for (int d = 128; d > 0; d >>= 1) {
-                if (tid < d) {
-                    const float v2 = sv[tid + d];
-                    const int i2 = si[tid + d];
-                    if (i2 >= 0 && (si[tid] < 0 || v2 > sv[tid] || (v2 == sv[tid] && i2 < si[tid]))) { sv[tid] = v2; si[tid] = i2; }
-                }
-                __syncthreads();
-            }
-            const float best = sv[0];
-            const int bidx = si[0];
-            __syncthreads();
-            if (bidx < 0 || !(best >= link_t32)) break;
-            if (tid == 0) scur = trunc4(boxes[(int64_t)f * B + bidx]);
-            __syncthreads();
-            cur = scur;
-            if (tid == 0) {
-                float *r = trk + (int64_t)f * 5;
-                r[0] = cur.x; r[1] = cur.y; r[2] = cur.z; r[3] = cur.w; r[4] = best;
-            }
-            __syncthreads();
+    float4 cur = anchor;
+    for (int step = 1; step <= reach; ++step) {
+        const int f = s.anchor_frame + dir * step;
+        if (f < 0 || f >= F) break;
+        const int par = step & 1;
+        const float carea = box_area(cur);
+        const float4 *fb = boxes + (int64_t)f * B;
+        float bv = -1.0f;
+        int bi = -1;
+        for (int b = tid; b < B; b += 1024) {
+            const float v = link_iou(cur, carea, fb[b]);
+            if (v > bv) { bv = v; bi = b; }              // NaN never wins; lowest index on ties
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            const float v2 = __shfl_xor(bv, d, 64);
+            const int i2 = __shfl_xor(bi, d, 64);
+            if (i2 >= 0 && (bi < 0 || v2 > bv || (v2 == bv && i2 < bi))) { bv = v2; bi = i2; }
+        }
+        if (lane == 0) { sv[par][w] = bv; si[par][w] = bi; }
+        __syncthreads();
+        float best = sv[par][0];
+        int bidx = si[par][0];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) {
+            const float v2 = sv[par][k];
+            const int i2 = si[par][k];
+            if (i2 >= 0 && (bidx < 0 || v2 > best || (v2 == best && i2 < bidx))) { best = v2; bidx = i2; }
+        }
+        if (bidx < 0 || !(best >= link_t32)) break;
+        cur = trunc4(fb[bidx]);
+        if (tid == 0) {
+            float *r = trk + (int64_t)f * 5;
+            r[0] = cur.x; r[1] = cur.y; r[2] = cur.z; r[3] = cur.w; r[4] = best;
         }
     }
 }
@@ -192,8 +197,10 @@ struct SuppressParams {
     const uint16_t *row_deg;
     const uint16_t *adj;
     const uint32_t *group_z;
+    const uint32_t *group_flags;   // kFlagRegular per frame, or null
     uint16_t *lists;               // [F*C, B] in/out
     int32_t *cnt;                  // [F*C]   in/out
+    uint8_t *visited;              // [F*C]   1 once a list went through round 2 (it is an independent set)
     const TrackState *st;
     const float *tracks;
     float t32;
@@ -222,6 +229,29 @@ __global__ __launch_bounds__(256) void track_suppress_kernel(const SuppressParam
     if (n == 0) return;
     const bool has_z = prm.group_z[f] != 0;
 
+    const bool seen = prm.visited[p] != 0;
+    int nk = 0, bad = 0;
+    if (seen) {
+        // The list already went through round 2 once: it is an independent set of the frame's
+        // suppression graph, so vid_nms of the round-1 survivors keeps them all -- only round 1
+        // (utils/nms.pyx:163-183) can remove entries.  (A zero-union pair inside the list would
+        // have raised on the first visit.)
+        for (int q0 = 0; q0 < n; q0 += 64) {
+            const int q = q0 + lane;
+            const bool valid = q < n;
+            const int cidx = (int)list[min(q, n - 1)];
+            const float4 bd = prm.boxes[rb + cidx];
+            const uint32_t pp = pair_pred(bd, box_area(bd), tb, tarea, prm.t32);
+            if (valid && (pp & 2u)) bad = 1;
+            const bool stay = valid && !(pp & 1u);
+            const unsigned long long sm = __ballot(stay);
+            if (stay) list[nk + __builtin_amdgcn_mbcnt_hi((uint32_t)(sm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sm, 0u))] = (uint16_t)cidx;
+            nk += __popcll(sm);
+        }
+        if (lane == 0) prm.cnt[p] = nk;
+        if (__ballot(bad != 0) && lane == 0) atomicOr(prm.status, kStDivZero);
+        return;
+    }
     for (int i = lane; i < ((B + 31) >> 5); i += 64) mask[i] = 0u;
     if (has_z) {   // detections that left the list earlier are "not in d": dead for the zero-union rule
         for (int i = lane; i < ((B + 31) >> 5); i += 64) mask[i] = 0xFFFFFFFFu;
@@ -229,46 +259,81 @@ __global__ __launch_bounds__(256) void track_suppress_kernel(const SuppressParam
             const int v = list[q];
             atomicAnd(const_cast<uint32_t *>(&mask[v >> 5]), ~(1u << (v & 31)));
         }
+    } else if (n > 2048 && prm.group_flags && (prm.group_flags[f] & kFlagRegular)) {
+        // long list (first visit of a full frame): round 1 as ONE coalesced sweep over the frame's
+        // boxes by index (sets the dead bit), instead of a 16-B gather per list entry.  Boxes that
+        // are not in the list get a bit too -- harmless, they are never visited.
+        for (int b0 = 0; b0 < B; b0 += 64) {
+            const int b = min(b0 + lane, B - 1);
+            const float4 bd = prm.boxes[rb + b];
+            const uint32_t pp = pair_pred(bd, box_area(bd), tb, tarea, prm.t32);
+            const unsigned long long hit = __ballot((b0 + lane < B) && (pp & 1u));
+            if (lane == 0) { mask[b0 >> 5] = (uint32_t)hit; mask[(b0 >> 5) + 1] = (uint32_t)(hit >> 32); }
+        }
     }
-    int nk = 0, bad = 0;
+    // (regular frame: every det area is > 0, so no union with the track box can be zero)
+    const bool swept = !has_z && n > 2048 && prm.group_flags && (prm.group_flags[f] & kFlagRegular);
     for (int q0 = 0; q0 < n; q0 += 64) {
         const int q = q0 + lane;
         const bool valid = q < n;
-        const int cidx = valid ? (int)list[q] : 0;
-        // round 1 (utils/nms.pyx:163-183): the DET is the "i" box, the track the "j" box
+        const int cidx = (int)list[min(q, n - 1)];          // unconditional loads: no vmcnt drain at joins
         bool r1 = false;
-        if (valid) {
+        if (!swept) {
+            // round 1 (utils/nms.pyx:163-183): the DET is the "i" box, the track the "j" box
             const float4 bd = prm.boxes[rb + cidx];
             const uint32_t pp = pair_pred(bd, box_area(bd), tb, tarea, prm.t32);
-            if (pp & 2u) bad = 1;
-            r1 = (pp & 1u) != 0;
+            if (valid && (pp & 2u)) bad = 1;
+            r1 = valid && (pp & 1u);
+            if (r1) atomicOr(const_cast<uint32_t *>(&mask[cidx >> 5]), 1u << (cidx & 31));
         }
-        if (r1) atomicOr(const_cast<uint32_t *>(&mask[cidx >> 5]), 1u << (cidx & 31));
         const bool alive = valid && !r1 && !((mask[cidx >> 5] >> (cidx & 31)) & 1u);
         unsigned long long am = __ballot(alive);
+        if (!am) continue;
         const uint32_t off = alive ? prm.row_off[rb + cidx] : 0u;
         const int deg = alive ? (int)prm.row_deg[rb + cidx] : 0;
         while (am) {
-            const int l = __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)am) - 1);
-            am &= am - 1;
-            const int cu = __builtin_amdgcn_readlane(cidx, l);
-            if ((mask[cu >> 5] >> (cu & 31)) & 1u) continue;
-            if (lane == 0) { list[nk] = (uint16_t)cu; atomicOr(const_cast<uint32_t *>(&mask[cu >> 5]), 1u << (cu & 31)); }
-            ++nk;
-            const uint32_t o = __builtin_amdgcn_readlane(off, l);
-            const int d = __builtin_amdgcn_readlane(deg, l);
-            for (int e0 = 0; e0 < d; e0 += 64) {
-                if (e0 + lane < d) {
-                    const uint16_t e = prm.adj[o + e0 + lane];
-                    const int v = e & 0x7FFF;
-                    if (e & kZTag) { if (!((mask[v >> 5] >> (v & 31)) & 1u)) bad = 1; }
-                    else atomicOr(const_cast<uint32_t *>(&mask[v >> 5]), 1u << (v & 31));
+            int ls[kWalkGrp];
+            int ng = 0;
+#pragma unroll
+            for (int k = 0; k < kWalkGrp; ++k) {
+                ls[k] = k ? ls[k - 1] : 0;
+                if (am) { ls[k] = __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)am) - 1); am &= am - 1; ng = k + 1; }
+            }
+            uint16_t pre0[kWalkGrp], pre1[kWalkGrp];
+#pragma unroll
+            for (int k = 0; k < kWalkGrp; ++k) {
+                const uint32_t o = __builtin_amdgcn_readlane(off, ls[k]);
+                const int d = __builtin_amdgcn_readlane(deg, ls[k]);
+                const int dm = max(d, 1) - 1;
+                pre0[k] = prm.adj[o + min(lane, dm)];
+                pre1[k] = prm.adj[o + min(lane + 64, dm)];
+            }
+#pragma unroll
+            for (int k = 0; k < kWalkGrp; ++k) {
+                if (k >= ng) break;
+                const int cu = __builtin_amdgcn_readlane(cidx, ls[k]);
+                if ((mask[cu >> 5] >> (cu & 31)) & 1u) continue;
+                if (lane == 0) { list[nk] = (uint16_t)cu; atomicOr(const_cast<uint32_t *>(&mask[cu >> 5]), 1u << (cu & 31)); }
+                ++nk;
+                const uint32_t o = __builtin_amdgcn_readlane(off, ls[k]);
+                const int d = __builtin_amdgcn_readlane(deg, ls[k]);
+                for (int e0 = 0; e0 < d; e0 += 64) {
+                    uint16_t e;
+                    if (e0 == 0) e = pre0[k];
+                    else if (e0 == 64) e = pre1[k];
+                    else e = prm.adj[o + min(e0 + lane, d - 1)];
+                    if (e0 + lane < d) {
+                        const int v = e & 0x7FFF;
+                        if (e & kZTag) { if (!((mask[v >> 5] >> (v & 31)) & 1u)) bad = 1; }
+                        else atomicOr(const_cast<uint32_t *>(&mask[v >> 5]), 1u << (v & 31));
+                    }
                 }
             }
         }
         // NOTE on the in-place compaction: list[nk] is written only after list[q0..q0+63] was read
         // (nk <= q0 + 64), by this wave, in program order.
     }
+    if (lane == 0) prm.visited[p] = 1;
     if (lane == 0) prm.cnt[p] = nk;
     if (__ballot(bad != 0) && lane == 0) atomicOr(prm.status, kStDivZero);
 }
@@ -289,6 +354,115 @@ __global__ void track_init_kernel(TrackState *__restrict__ st, int C)
     TrackState s;
     s.active = 1; s.ntracks = 0; s.last_key = 0; s.last_flat = -1; s.anchor_frame = 0; s.anchor_box = 0; s.anchor_score = 0.f;
     st[c] = s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Tubelet re-scoring of the device tracks (raw_dets_spatial_max_pooling, vdet/tubelet_cls.py:493-535,
+// then do_score_completion :284-303 and score_proto_temporal_maxpool :386-414), all float64.
+//   tracks [C,T,F,5] f32 (NaN = no box), ntracks [C]
+//   out_score [C,T,F] f64 (NaN = no box), out_box [C,T,F,4] f32 (the "regressed" box)
+// ------------------------------------------------------------------------------------------------
+// one block per (class, track, frame)
+__global__ __launch_bounds__(256) void rescore_spatial_kernel(const float *__restrict__ tracks,
+                                                              const int32_t *__restrict__ ntracks,
+                                                              const float4 *__restrict__ boxes,
+                                                              const float *__restrict__ scores, int F, int B, int C, int T,
+                                                              double thres, double *__restrict__ out_score,
+                                                              float *__restrict__ out_box)
+{
+    __shared__ double ss[256];
+    __shared__ long long si[256];
+    const int64_t e = blockIdx.x;                 // (c*T + t)*F + f
+    const int f = (int)(e % F);
+    const int ct = (int)(e / F);
+    const int c = ct / T, t = ct - c * T, tid = threadIdx.x;
+    const double qnan = __longlong_as_double(0x7FF8000000000000ll);
+    const float *row = tracks + e * 5;
+    if (t >= ntracks[c] || row[0] != row[0]) {
+        if (tid == 0) out_score[e] = qnan;
+        if (tid < 4) out_box[e * 4 + tid] = __uint_as_float(0x7FC00000u);
+        return;
+    }
+    const double p[4] = {(double)row[0], (double)row[1], (double)row[2], (double)row[3]};
+    double bs = 0.0;
+    int64_t bi = -1;
+    for (int j = tid; j < B; j += 256) {
+        const float4 bb = boxes[(int64_t)f * B + j];
+        const double q[4] = {(double)bb.x, (double)bb.y, (double)bb.z, (double)bb.w};
+        if (iou_f64_pair(p, q) > thres) {
+            const double s = (double)scores[((int64_t)f * B + j) * C + c];
+            if (argmax_better(s, j, bs, bi)) { bs = s; bi = j; }
+        }
+    }
+    ss[tid] = bs;
+    si[tid] = bi;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) {
+        if (tid < d) {
+            const double s2 = ss[tid + d];
+            const int64_t i2 = si[tid + d];
+            if (i2 >= 0 && argmax_better(s2, i2, ss[tid], si[tid])) { ss[tid] = s2; si[tid] = i2; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        if (si[0] >= 0) {
+            const float4 bb = boxes[(int64_t)f * B + si[0]];
+            out_score[e] = ss[0];
+            out_box[e * 4 + 0] = bb.x; out_box[e * 4 + 1] = bb.y; out_box[e * 4 + 2] = bb.z; out_box[e * 4 + 3] = bb.w;
+        } else {   // no overlapping detection: sentinel score, box unchanged (:526-530)
+            out_score[e] = -1e5;
+            out_box[e * 4 + 0] = row[0]; out_box[e * 4 + 1] = row[1]; out_box[e * 4 + 2] = row[2]; out_box[e * 4 + 3] = row[3];
+        }
+    }
+}
+
+// one thread per (class, track): completion over the track's boxes (its non-NaN frames, in order),
+// then the centred temporal max-pool of window w (w == 1: none) into out2.
+__global__ void rescore_series_kernel(double *__restrict__ sc, double *__restrict__ out2,
+                                      const int32_t *__restrict__ ntracks, int F, int C, int T, int window,
+                                      int *__restrict__ err)
+{
+    const int ct = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ct >= C * T) return;
+    const int c = ct / T, t = ct - c * T;
+    double *s = sc + (int64_t)ct * F;
+    double *o = out2 + (int64_t)ct * F;
+    const double qnan = __longlong_as_double(0x7FF8000000000000ll);
+    for (int f = 0; f < F; ++f) o[f] = qnan;
+    if (t >= ntracks[c]) return;
+    // the tubelet = frames with a box; the linker produces one contiguous run
+    int a = 0;
+    while (a < F && s[a] != s[a]) ++a;
+    int b = F;
+    while (b > a && s[b - 1] != s[b - 1]) --b;
+    const int n = b - a;
+    if (n <= 0) return;
+    double *v = s + a;
+    for (int i = 0; i < n; ++i) {           // do_score_completion
+        if (v[i] > -10) continue;
+        int j = i;
+        while (j < n && v[j] <= -10) ++j;
+        if (i == 0) {
+            if (j == n) { atomicOr(err, 1); return; }
+            for (int k = i; k < j; ++k) v[k] = v[j];
+        } else if (j == n) {
+            for (int k = i; k < j; ++k) v[k] = v[i - 1];
+        } else {
+            const double l = v[i - 1], r = v[j];
+            for (int k = i; k < j; ++k) v[k] = l + (r - l) * (double)(k - i + 1) / (double)(j - i + 1);
+        }
+    }
+    const int h = window / 2;
+    for (int i = 0; i < n; ++i) {           // score_proto_temporal_maxpool
+        double m = v[i];
+        for (int d = -h; d <= h; ++d) {
+            const int g = i + d;
+            const double x = (g < 0 || g >= n) ? -1e5 : v[g];
+            m = (x > m) ? x : m;
+        }
+        o[a + i] = m;
+    }
 }
 
 }  // namespace vdet

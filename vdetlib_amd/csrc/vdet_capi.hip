@@ -50,12 +50,15 @@ struct DevBuf {
     template <typename T> T *as() { return static_cast<T *>(p); }
 };
 
-enum Stage { ST_IOU_BITS = 0, ST_ADJ = 1, ST_SORTK = 2, ST_WALK = 3, ST_TEMPORAL = 4, ST_SORT = 5, ST_IOU_GEN = 6, ST_OTHER = 7 };
+enum Stage { ST_IOU_BITS = 0, ST_ADJ = 1, ST_SORTK = 2, ST_WALK = 3, ST_TEMPORAL = 4, ST_SORT = 5, ST_IOU_GEN = 6, ST_OTHER = 7,
+             ST_TRANSPOSE = 8, ST_TPICK = 9, ST_TLINK = 10, ST_TSUPP = 11, ST_RSPATIAL = 12, ST_RSERIES = 13, ST_COUNT = 16 };
 
 struct Counters {            // one small device block
     int status;
     unsigned int glob_cnt;
     unsigned long long pool_used;
+    int eindex;              // latched "IndexError" of the rescoring kernels
+    int pad;
 };
 
 }  // namespace
@@ -72,15 +75,20 @@ struct vdet_ctx {
     int n_cu = 256;
     // scratch
     DevBuf boxes, scores, keys, excl, frames, groups, tiles, bits, rowz, rowoff, rowdeg, groupz, adj, comp, origidx,
-        out64, trk_frames, trk_boxes, b1, b2, iou_out, order, ncand, keepidx, keepcnt, gflags, pairs, tkeys, tstate, tmp[8];
+        out64, trk_frames, trk_boxes, b1, b2, iou_out, order, ncand, keepidx, keepcnt, gflags, pairs, tkeys, tstate, visited, tmp[8];
     // timing
     bool timing = false;
+    bool timing_accumulate = false;   // vdet_set_timing(ctx, 2): keep events across calls until read
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     std::vector<int> ev_stage;
     size_t ev_used = 0;
-    float last_ms[8] = {0};
-    int last_launches[8] = {0};
+    float last_ms[ST_COUNT] = {0};
+    int last_launches[ST_COUNT] = {0};
     bool sort_attr_set = false;
+    // opt-in reuse of the per-video preparation (graph + sorted lists) between d_* calls
+    bool cache_enabled = false;
+    struct PrepKey { const void *boxes = nullptr, *scores = nullptr; int64_t F = 0, B = 0, C = 0; float t32 = 0; int layout = -1, use_thr = 0; float thr = 0; } prep;
+    bool graph_valid = false, lists_valid = false;
     bool atomic_rank = false;     // LDS returning atomics serve same-address lanes in lane order (probed)
     bool no_transpose = false;    // VDET_NO_TRANSPOSE=1 (tests / A-B)
     bool force_general = false;   // VDET_FORCE_GENERAL=1: disable the symmetric fast kernel (tests)
@@ -130,7 +138,7 @@ struct StageTimer {
     }
 };
 
-void timing_reset(vdet_ctx *c) { c->ev_used = 0; }
+void timing_reset(vdet_ctx *c) { if (!c->timing_accumulate) c->ev_used = 0; }
 
 // smallest float32 f with (double)f >= thresh: "(double)ovr_f32 >= thresh" <=> "ovr_f32 >= f"
 float thresh_to_f32(double thresh)
@@ -234,6 +242,7 @@ int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32)
         HIPCHK(c, hipMemcpyAsync(&h0, c->d_cnt, sizeof h0, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (h0.status && !c->latched) c->latched = translate_status(c, h0.status);
+        if (h0.eindex && !c->latched) c->latched = fail(c, VDET_EINDEX, "list index out of range");
     }
     if (c->adj.cap < (size_t)pl.ntot * 32 * 2) HIPCHK(c, c->adj.reserve((size_t)pl.ntot * 32 * 2 + 4096));
 
@@ -302,6 +311,7 @@ int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32)
 // K3 + K4 for P problems.  d_order / d_ncand / keep buffers are caller-provided device pointers.
 struct SortWalkArgs {
     bool sort_only = false;       // tracking: only the per-problem lists are wanted
+    bool walk_only = false;       // the lists of a previous call are still valid
     int mode, P, B, C;
     const float *scores;
     const uint32_t *keys;
@@ -351,12 +361,12 @@ int launch_sort_walk(vdet_ctx *c, const SortWalkArgs &a, int nmax, int64_t order
     SortParams sp{};
     sp.mode = a.mode; sp.P = a.P; sp.B = a.B; sp.C = a.C;
     sp.scores = a.scores; sp.keys = a.keys; sp.excl = a.excl; sp.use_thr = a.use_thr; sp.thr = a.thr;
-    if (a.mode == 0 && !a.keys && !c->no_transpose) {
+    if (a.mode == 0 && !a.keys && !c->no_transpose && !a.walk_only) {
         // class-innermost volume: one coalesced transpose to [F,C,B] keys, then the sort reads rows
         const int64_t F = a.P / a.C;
         HIPCHK(c, c->tkeys.reserve((size_t)a.P * a.B * 4));
         {
-            StageTimer tm(c, ST_OTHER);
+            StageTimer tm(c, ST_TRANSPOSE);
             hipLaunchKernelGGL(transpose_keys_kernel, dim3((a.B + 63) / 64, (a.C + 63) / 64, (unsigned)F), dim3(256), 0,
                                c->stream, a.scores, c->tkeys.as<uint32_t>(), a.B, a.C, a.use_thr, a.thr);
         }
@@ -380,7 +390,7 @@ int launch_sort_walk(vdet_ctx *c, const SortWalkArgs &a, int nmax, int64_t order
     if (!var || lds > c->dyn_lds_max)
         return fail(c, VDET_EINVAL, "a frame with %d boxes needs %zu B of LDS for the in-LDS sort; the limit is %zu B "
                                     "(about 18000 boxes per frame)", nmax, lds, c->dyn_lds_max);
-    {
+    if (!a.walk_only) {
         const int grid = (a.P + 7) & ~7;
         StageTimer tm(c, ST_SORTK);
         void *args[] = {&sp};
@@ -588,7 +598,7 @@ int vdet_destroy(vdet_ctx *c)
     DevBuf *bufs[] = {&c->boxes, &c->scores, &c->keys, &c->excl, &c->frames, &c->groups, &c->tiles, &c->bits,
                       &c->rowz, &c->rowoff, &c->rowdeg, &c->groupz, &c->adj, &c->comp, &c->origidx, &c->out64,
                       &c->trk_frames, &c->trk_boxes, &c->b1, &c->b2, &c->iou_out, &c->order, &c->ncand, &c->keepidx,
-                      &c->keepcnt, &c->gflags, &c->pairs, &c->tkeys, &c->tstate};
+                      &c->keepcnt, &c->gflags, &c->pairs, &c->tkeys, &c->tstate, &c->visited};
     for (DevBuf *b : bufs) b->release();
     for (DevBuf &b : c->tmp) b.release();
     for (auto &e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -614,6 +624,21 @@ int vdet_reset_stream(vdet_ctx *c)
 
 const char *vdet_last_error(vdet_ctx *c) { return c ? c->err.c_str() : "null context"; }
 
+int vdet_set_cache(vdet_ctx *c, int enable)
+{
+    if (!c) return VDET_EINVAL;
+    c->cache_enabled = enable != 0;
+    c->graph_valid = c->lists_valid = false;
+    return VDET_OK;
+}
+
+int vdet_invalidate(vdet_ctx *c)
+{
+    if (!c) return VDET_EINVAL;
+    c->graph_valid = c->lists_valid = false;
+    return VDET_OK;
+}
+
 int vdet_query(vdet_ctx *c, int what)
 {
     if (!c) return VDET_EINVAL;
@@ -626,14 +651,17 @@ int vdet_set_timing(vdet_ctx *c, int enable)
 {
     if (!c) return VDET_EINVAL;
     c->timing = enable != 0;
+    c->timing_accumulate = enable == 2;
+    c->ev_used = 0;
     return VDET_OK;
 }
 
-int vdet_last_timing_ms(vdet_ctx *c, float *out8)
+int vdet_last_timing_ms(vdet_ctx *c, float *out16)
 {
+    float *out8 = out16;
     if (!c || !out8) return VDET_EINVAL;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (int i = 0; i < 8; ++i) { c->last_ms[i] = 0; c->last_launches[i] = 0; }
+    for (int i = 0; i < ST_COUNT; ++i) { c->last_ms[i] = 0; c->last_launches[i] = 0; }
     for (size_t i = 0; i < c->ev_used; ++i) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, c->ev_pool[i].first, c->ev_pool[i].second) == hipSuccess) {
@@ -641,14 +669,15 @@ int vdet_last_timing_ms(vdet_ctx *c, float *out8)
             c->last_launches[c->ev_stage[i]] += 1;
         }
     }
-    for (int i = 0; i < 8; ++i) out8[i] = c->last_ms[i];
+    for (int i = 0; i < ST_COUNT; ++i) out8[i] = c->last_ms[i];
+    c->ev_used = 0;
     return VDET_OK;
 }
 
-int vdet_last_launches(vdet_ctx *c, int *out8)
+int vdet_last_launches(vdet_ctx *c, int *out16)
 {
-    if (!c || !out8) return VDET_EINVAL;
-    for (int i = 0; i < 8; ++i) out8[i] = c->last_launches[i];
+    if (!c || !out16) return VDET_EINVAL;
+    for (int i = 0; i < ST_COUNT; ++i) out16[i] = c->last_launches[i];
     return VDET_OK;
 }
 
@@ -659,9 +688,11 @@ int vdet_sync(vdet_ctx *c)
     HIPCHK(c, hipMemcpyAsync(&h, c->d_cnt, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemsetAsync(&c->d_cnt->status, 0, sizeof(int), c->stream));
+    HIPCHK(c, hipMemsetAsync(&c->d_cnt->eindex, 0, sizeof(int), c->stream));
     const int l = c->latched;
     c->latched = 0;
     if (l) return l;
+    if (h.eindex) return fail(c, VDET_EINDEX, "list index out of range");
     return translate_status(c, h.status);
 }
 
@@ -829,18 +860,36 @@ int vdet_nms_volume(vdet_ctx *c, const float *d_boxes, const float *d_scores, in
         HIPCHK(c, hipMemsetAsync(d_keep_cnt, 0, (size_t)(F * C) * 4, c->stream));
         return VDET_OK;
     }
-    NmsPlan pl;
-    pl.groups.resize((size_t)F);
-    for (int64_t f = 0; f < F; ++f) pl.groups[(size_t)f] = {(int32_t)(f * B), (int32_t)B, 0};
-    make_plan(c, pl);
-    int rc = build_graph(c, reinterpret_cast<const float4 *>(d_boxes), pl, thresh_to_f32(thresh));
-    if (rc) return rc;
+    const float t32 = thresh_to_f32(thresh);
+    const bool same_geo = c->cache_enabled && c->graph_valid && c->prep.boxes == d_boxes && c->prep.F == F &&
+                          c->prep.B == B && memcmp(&c->prep.t32, &t32, 4) == 0;
+    const bool same_lists = same_geo && c->lists_valid && c->prep.scores == d_scores && c->prep.C == C &&
+                            c->prep.layout == layout && c->prep.use_thr == use_score_thresh &&
+                            (!use_score_thresh || c->prep.thr == score_thresh);
+    int rc;
+    if (!same_geo) {
+        c->graph_valid = c->lists_valid = false;
+        NmsPlan pl;
+        pl.groups.resize((size_t)F);
+        for (int64_t f = 0; f < F; ++f) pl.groups[(size_t)f] = {(int32_t)(f * B), (int32_t)B, 0};
+        make_plan(c, pl);
+        rc = build_graph(c, reinterpret_cast<const float4 *>(d_boxes), pl, t32);
+        if (rc) return rc;
+        c->prep.boxes = d_boxes; c->prep.F = F; c->prep.B = B; c->prep.t32 = t32;
+        c->graph_valid = true;
+    }
     SortWalkArgs a{};
+    a.walk_only = same_lists;
     a.mode = layout; a.P = (int)(F * C); a.B = (int)B; a.C = (int)C;
     a.scores = d_scores;
     a.use_thr = use_score_thresh; a.thr = score_thresh;
     a.keep_idx = d_keep_idx; a.keep_cnt = d_keep_cnt; a.cap = cap;
-    return launch_sort_walk(c, a, (int)B, F * C * B);
+    rc = launch_sort_walk(c, a, (int)B, F * C * B);
+    if (rc) return rc;
+    c->prep.scores = d_scores; c->prep.C = C; c->prep.layout = layout; c->prep.use_thr = use_score_thresh;
+    c->prep.thr = score_thresh;
+    c->lists_valid = true;
+    return VDET_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -857,23 +906,36 @@ int vdet_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scores, 
     if (((uintptr_t)d_boxes & 15) != 0) return fail(c, VDET_EINVAL, "d_boxes must be 16-byte aligned");
     HIPCHK(c, hipSetDevice(c->device));
     timing_reset(c);
-    NmsPlan pl;
-    pl.groups.resize((size_t)F);
-    for (int64_t f = 0; f < F; ++f) pl.groups[(size_t)f] = {(int32_t)(f * B), (int32_t)B, 0};
-    make_plan(c, pl);
     const float t32 = thresh_to_f32(nms_thres);
-    int rc = build_graph(c, reinterpret_cast<const float4 *>(d_boxes), pl, t32);
-    if (rc) return rc;
-    // descending lists per (frame, class): always through the transposed keys (pick needs them)
-    const bool saved = c->no_transpose;
-    c->no_transpose = false;
-    SortWalkArgs a{};
-    a.sort_only = true;
-    a.mode = 0; a.P = (int)(F * C); a.B = (int)B; a.C = (int)C;
-    a.scores = d_scores;
-    rc = launch_sort_walk(c, a, (int)B, F * C * B);
-    c->no_transpose = saved;
-    if (rc) return rc;
+    const bool same_geo = c->cache_enabled && c->graph_valid && c->prep.boxes == d_boxes && c->prep.F == F &&
+                          c->prep.B == B && memcmp(&c->prep.t32, &t32, 4) == 0;
+    const bool same_lists = same_geo && c->lists_valid && c->prep.scores == d_scores && c->prep.C == C &&
+                            c->prep.layout == VDET_LAYOUT_FBC && c->prep.use_thr == 0 && !c->no_transpose;
+    int rc;
+    if (!same_geo) {
+        c->graph_valid = c->lists_valid = false;
+        NmsPlan pl;
+        pl.groups.resize((size_t)F);
+        for (int64_t f = 0; f < F; ++f) pl.groups[(size_t)f] = {(int32_t)(f * B), (int32_t)B, 0};
+        make_plan(c, pl);
+        rc = build_graph(c, reinterpret_cast<const float4 *>(d_boxes), pl, t32);
+        if (rc) return rc;
+        c->prep.boxes = d_boxes; c->prep.F = F; c->prep.B = B; c->prep.t32 = t32;
+        c->graph_valid = true;
+    }
+    if (!same_lists) {
+        // descending lists per (frame, class): always through the transposed keys (pick needs them)
+        const bool saved = c->no_transpose;
+        c->no_transpose = false;
+        SortWalkArgs a{};
+        a.sort_only = true;
+        a.mode = 0; a.P = (int)(F * C); a.B = (int)B; a.C = (int)C;
+        a.scores = d_scores;
+        rc = launch_sort_walk(c, a, (int)B, F * C * B);
+        c->no_transpose = saved;
+        if (rc) return rc;
+    }
+    c->lists_valid = false;          // the lists are consumed (compacted in place) below
     HIPCHK(c, c->tstate.reserve((size_t)C * sizeof(TrackState)));
     TrackState *st = c->tstate.as<TrackState>();
     const unsigned cg = (unsigned)((C + 63) / 64);
@@ -888,8 +950,12 @@ int vdet_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scores, 
     sp.row_deg = c->rowdeg.as<uint16_t>();
     sp.adj = c->adj.as<uint16_t>();
     sp.group_z = c->groupz.as<uint32_t>();
+    sp.group_flags = (t32 > 1e-30f && t32 < INFINITY && !c->force_general) ? c->gflags.as<uint32_t>() : nullptr;
     sp.lists = c->order.as<uint16_t>();
     sp.cnt = c->ncand.as<int32_t>();
+    HIPCHK(c, c->visited.reserve((size_t)(F * C)));
+    HIPCHK(c, hipMemsetAsync(c->visited.p, 0, (size_t)(F * C), c->stream));
+    sp.visited = c->visited.as<uint8_t>();
     sp.st = st;
     sp.tracks = d_tracks;
     sp.t32 = t32;
@@ -898,23 +964,53 @@ int vdet_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scores, 
     const float link_t32 = thresh_to_f32(link_thres);
     for (int t = 0; t < max_tracks; ++t) {
         {
-            StageTimer tm(c, ST_OTHER);
+            StageTimer tm(c, ST_TPICK);
             hipLaunchKernelGGL(track_pick_kernel, dim3((unsigned)C), dim3(256), 0, c->stream, c->tkeys.as<uint32_t>(),
                                c->order.as<uint16_t>(), c->ncand.as<int32_t>(), (int)F, (int)B, (int)C, d_scores, thres,
                                max_tracks, st, d_anchors);
         }
         {
-            StageTimer tm(c, ST_IOU_GEN);
-            hipLaunchKernelGGL(track_link_kernel, dim3((unsigned)C), dim3(256), 0, c->stream,
+            StageTimer tm(c, ST_TLINK);
+            hipLaunchKernelGGL(track_link_kernel, dim3((unsigned)C, 2), dim3(1024), 0, c->stream,
                                reinterpret_cast<const float4 *>(d_boxes), (int)F, (int)B, max_tracks, link_t32, reach, st,
                                d_tracks);
         }
         {
-            StageTimer tm(c, ST_WALK);
+            StageTimer tm(c, ST_TSUPP);
             hipLaunchKernelGGL(track_suppress_kernel, dim3((unsigned)((F * C + 3) / 4)), dim3(256),
                                (size_t)sp.mask_words * 16, c->stream, sp);
         }
         hipLaunchKernelGGL(track_commit_kernel, dim3(cg), dim3(64), 0, c->stream, st, (int)C, d_ntracks);
+    }
+    HIPCHK(c, hipGetLastError());
+    return VDET_OK;
+}
+
+int vdet_rescore_tracks(vdet_ctx *c, const float *d_tracks, const int32_t *d_ntracks, const float *d_boxes,
+                        const float *d_scores, int64_t F, int64_t B, int64_t C, int max_tracks, double overlap_thres,
+                        int window, double *d_det_score, double *d_pooled, float *d_boxes_out)
+{
+    if (!c) return VDET_EINVAL;
+    if (F <= 0 || B <= 0 || C <= 0 || max_tracks < 0) return fail(c, VDET_EINVAL, "bad shape");
+    if (window < 1 || window % 2 != 1) return fail(c, VDET_EINVAL, "Window size must be odd!");
+    if (max_tracks == 0) return VDET_OK;
+    if (!d_tracks || !d_ntracks || !d_boxes || !d_scores || !d_det_score || !d_pooled || !d_boxes_out)
+        return fail(c, VDET_EINVAL, "null buffer");
+    const int64_t nb = C * max_tracks * F;
+    if (nb > 0x7FFFFFF0ll) return fail(c, VDET_EINVAL, "too many tubelet boxes");
+    HIPCHK(c, hipSetDevice(c->device));
+    timing_reset(c);
+    {
+        StageTimer tm(c, ST_RSPATIAL);
+        hipLaunchKernelGGL(rescore_spatial_kernel, dim3((unsigned)nb), dim3(256), 0, c->stream, d_tracks, d_ntracks,
+                           reinterpret_cast<const float4 *>(d_boxes), d_scores, (int)F, (int)B, (int)C, max_tracks,
+                           overlap_thres, d_det_score, d_boxes_out);
+    }
+    {
+        StageTimer tm(c, ST_RSERIES);
+        const int n = (int)(C * max_tracks);
+        hipLaunchKernelGGL(rescore_series_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, d_det_score,
+                           d_pooled, d_ntracks, (int)F, (int)C, max_tracks, window, &c->d_cnt->eindex);
     }
     HIPCHK(c, hipGetLastError());
     return VDET_OK;

@@ -157,3 +157,25 @@ def tracks_to_proto(video_name, tracks, anchors, ntracks, method='iou_link_track
                              'score': float(row[4]), 'anchor': int(f + 1 - anchor_frame)})
         out.append(tracklet)
     return {'video': video_name, 'method': method, 'tracks': out}
+
+
+def rescore_tracks(tracks, ntracks, boxes, scores, overlap_thres=0.7, window=3, sync=True):
+    """Re-score device tracks: spatial max-pooling of the detection scores onto the tubelet boxes
+    (raw_dets_spatial_max_pooling, vdet/tubelet_cls.py:493-535 -- also replaces each box by the
+    best-scoring overlapping detection), gap completion (:284-303) and temporal max-pooling
+    (:386-414).  Returns (det_score f64 [C,T,F], pooled f64 [C,T,F], boxes f32 [C,T,F,4])."""
+    if window % 2 != 1:
+        raise ValueError('Window size must be odd!')
+    C, T, F = tracks.shape[0], tracks.shape[1], tracks.shape[2]
+    B = boxes.shape[1]
+    ctx = _ctx_for(boxes)
+    det = torch.empty((C, T, F), dtype=torch.float64, device=boxes.device)
+    pooled = torch.empty((C, T, F), dtype=torch.float64, device=boxes.device)
+    ob = torch.empty((C, T, F, 4), dtype=torch.float32, device=boxes.device)
+    ctx.check(ctx.lib.vdet_rescore_tracks(ctx.h, tracks.contiguous().data_ptr(), ntracks.data_ptr(),
+                                          boxes.contiguous().data_ptr(), scores.contiguous().data_ptr(), F, B, C, T,
+                                          float(overlap_thres), int(window), det.data_ptr(), pooled.data_ptr(),
+                                          ob.data_ptr()))
+    if sync:
+        ctx.sync()
+    return det, pooled, ob
