@@ -129,10 +129,12 @@ __device__ __forceinline__ float4 trunc4(float4 b)   // int(cor) of utils/protoc
 // buffered LDS slot, every thread finishes the reduction redundantly.
 __global__ __launch_bounds__(1024) void track_link_kernel(const float4 *__restrict__ boxes, int F, int B, int max_tracks,
                                                           float link_t32, int reach, const TrackState *__restrict__ st,
-                                                          float *__restrict__ tracks)
+                                                          float *__restrict__ tracks,
+                                                          const uint32_t *__restrict__ group_flags)
 {
     __shared__ float sv[2][16];
     __shared__ int si[2][16];
+    __shared__ float4 sb[2][16];          // the winning box travels with its score: no dependent global load
     const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int dir = blockIdx.y == 0 ? 1 : -1;
     const TrackState s = st[c];
@@ -149,6 +151,16 @@ __global__ __launch_bounds__(1024) void track_link_kernel(const float4 *__restri
         r[0] = anchor.x; r[1] = anchor.y; r[2] = anchor.z; r[3] = anchor.w; r[4] = 1.0f;
     }
     float4 cur = anchor;
+    // software pipeline: the NEXT frame's boxes do not depend on this frame's result, so they are
+    // loaded (up to LB per thread) before this frame's reduction / barrier
+    constexpr int LB = 10;                               // covers B <= 10240 from registers
+    float4 nb[LB];
+    {
+        const int f1 = s.anchor_frame + dir;
+        const float4 *fb1 = boxes + (int64_t)min(max(f1, 0), F - 1) * B;
+#pragma unroll
+        for (int i = 0; i < LB; ++i) nb[i] = fb1[min(tid + i * 1024, B - 1)];
+    }
     for (int step = 1; step <= reach; ++step) {
         const int f = s.anchor_frame + dir * step;
         if (f < 0 || f >= F) break;
@@ -157,9 +169,40 @@ __global__ __launch_bounds__(1024) void track_link_kernel(const float4 *__restri
         const float4 *fb = boxes + (int64_t)f * B;
         float bv = -1.0f;
         int bi = -1;
-        for (int b = tid; b < B; b += 1024) {
-            const float v = link_iou(cur, carea, fb[b]);
-            if (v > bv) { bv = v; bi = b; }              // NaN never wins; lowest index on ties
+        float4 bb = cur;
+        // Regular frame (finite boxes, positive areas) and a regular current box: only candidates
+        // with IoU >= link_t32 can be linked, and that test is exact WITHOUT a divide
+        // (pred_regular); the IEEE quotient is computed only in the rare wave iteration where some
+        // lane passes.  Same result as the plain argmax below.
+        const bool fast = group_flags && (group_flags[f] & kFlagRegular) && link_t32 > 1e-30f &&
+                          carea > 0.0f && carea < __uint_as_float(0x7F800000u);
+        const float t32e = link_t32 * 4.76837158203125e-7f;
+#pragma unroll
+        for (int i = 0; i < LB; ++i) {
+            const int b = tid + i * 1024;
+            if (fast) {
+                bool border;
+                const bool pass = pred_regular(cur, carea, nb[i], box_area(nb[i]), link_t32, t32e, border);
+                if (__ballot((pass || border) && b < B)) {
+                    const float v = link_iou(cur, carea, nb[i]);
+                    if (b < B && v >= link_t32 && v > bv) { bv = v; bi = b; bb = nb[i]; }
+                }
+            } else {
+                const float v = link_iou(cur, carea, nb[i]);
+                if (b < B && v > bv) { bv = v; bi = b; bb = nb[i]; }     // NaN never wins; lowest index on ties
+            }
+        }
+        for (int b = tid + LB * 1024; b < B; b += 1024) {
+            const float4 x = fb[b];
+            const float v = link_iou(cur, carea, x);
+            if (v > bv) { bv = v; bi = b; bb = x; }
+        }
+        const int my_bi = bi;
+        {   // prefetch frame f + dir
+            const int f2 = f + dir;
+            const float4 *fb2 = boxes + (int64_t)min(max(f2, 0), F - 1) * B;
+#pragma unroll
+            for (int i = 0; i < LB; ++i) nb[i] = fb2[min(tid + i * 1024, B - 1)];
         }
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) {
@@ -168,17 +211,19 @@ __global__ __launch_bounds__(1024) void track_link_kernel(const float4 *__restri
             if (i2 >= 0 && (bi < 0 || v2 > bv || (v2 == bv && i2 < bi))) { bv = v2; bi = i2; }
         }
         if (lane == 0) { sv[par][w] = bv; si[par][w] = bi; }
+        if (bi >= 0 && my_bi == bi) sb[par][w] = bb;     // exactly one lane of the wave owns the winner
         __syncthreads();
         float best = sv[par][0];
         int bidx = si[par][0];
+        int bw = 0;
 #pragma unroll
         for (int k = 1; k < 16; ++k) {
             const float v2 = sv[par][k];
             const int i2 = si[par][k];
-            if (i2 >= 0 && (bidx < 0 || v2 > best || (v2 == best && i2 < bidx))) { best = v2; bidx = i2; }
+            if (i2 >= 0 && (bidx < 0 || v2 > best || (v2 == best && i2 < bidx))) { best = v2; bidx = i2; bw = k; }
         }
         if (bidx < 0 || !(best >= link_t32)) break;
-        cur = trunc4(fb[bidx]);
+        cur = trunc4(sb[par][bw]);
         if (tid == 0) {
             float *r = trk + (int64_t)f * 5;
             r[0] = cur.x; r[1] = cur.y; r[2] = cur.z; r[3] = cur.w; r[4] = best;

@@ -973,7 +973,7 @@ int vdet_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scores, 
             StageTimer tm(c, ST_TLINK);
             hipLaunchKernelGGL(track_link_kernel, dim3((unsigned)C, 2), dim3(1024), 0, c->stream,
                                reinterpret_cast<const float4 *>(d_boxes), (int)F, (int)B, max_tracks, link_t32, reach, st,
-                               d_tracks);
+                               d_tracks, sp.group_flags);
         }
         {
             StageTimer tm(c, ST_TSUPP);
