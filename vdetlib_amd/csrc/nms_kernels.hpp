@@ -309,8 +309,7 @@ __global__ __launch_bounds__(256) void adj_build_kernel(const float4 *__restrict
                                                         const TileDesc *__restrict__ tiles,
                                                         const uint64_t *__restrict__ bits,
                                                         const uint32_t *__restrict__ row_z,
-                                                        uint32_t *__restrict__ row_off,
-                                                        uint16_t *__restrict__ row_deg,
+                                                        uint2 *__restrict__ row_meta,
                                                         uint16_t *__restrict__ adj,
                                                         unsigned long long *__restrict__ pool_used,
                                                         unsigned long long pool_cap, int *__restrict__ status)
@@ -348,13 +347,11 @@ __global__ __launch_bounds__(256) void adj_build_kernel(const float4 *__restrict
     if (v >= B) return;
     if (base + tile_total > pool_cap || base + tile_total > 0xFFFFFFFFull) {
         if (tid == 0) atomicOr(status, kStPool);
-        row_off[gd.box_off + v] = 0;
-        row_deg[gd.box_off + v] = 0;
+        row_meta[gd.box_off + v] = make_uint2(0u, 0u);
         return;
     }
     uint32_t p = (uint32_t)base + (incl - tot);
-    row_off[gd.box_off + v] = p;
-    row_deg[gd.box_off + v] = (uint16_t)tot;
+    row_meta[gd.box_off + v] = make_uint2(p, tot);
     for (int w = 0; w < W; ++w) {
         uint64_t m = col[(int64_t)w * B];
         while (m) {
@@ -629,8 +626,7 @@ struct WalkParams {
     const GroupDesc *groups;
     const uint16_t *order;
     const int32_t *ncand;
-    const uint32_t *row_off;
-    const uint16_t *row_deg;
+    const uint2 *row_meta;         // per box: x = offset of its adjacency list, y = its length
     const uint16_t *adj;
     const uint32_t *group_z;
     int32_t *keep_idx;        // mode 0/1: [P,cap]; mode 2: flat [Ntot] at box_off (cap = nbox)
@@ -679,8 +675,10 @@ __global__ __launch_bounds__(256) void walk_kernel(const WalkParams prm)
         const bool alive = valid && !((mask[c >> 5] >> (c & 31)) & 1u);
         unsigned long long am = __ballot(alive);
         if (!am) continue;
-        const uint32_t off = alive ? prm.row_off[rb + c] : 0u;
-        const int deg = alive ? (int)prm.row_deg[rb + c] : 0;
+        uint2 meta = make_uint2(0u, 0u);
+        if (alive) meta = prm.row_meta[rb + c];      // ONE 8-B gather, alive lanes only (a 64-lane gather
+        const uint32_t off = meta.x;                 // is 64 transactions; doing it for the ~85 % dead
+        const int deg = (int)meta.y;                 // candidates made the walk 1.5-1.8x slower, measured)
         while (am) {
             int ls[kWalkGrp];
             int ng = 0;

@@ -238,8 +238,7 @@ struct SuppressParams {
     const float4 *boxes;
     int F, B, C, max_tracks;
     const GroupDesc *groups;       // one group per frame
-    const uint32_t *row_off;
-    const uint16_t *row_deg;
+    const uint2 *row_meta;         // per box: x = offset of its adjacency list, y = its length
     const uint16_t *adj;
     const uint32_t *group_z;
     const uint32_t *group_flags;   // kFlagRegular per frame, or null
@@ -318,10 +317,14 @@ __global__ __launch_bounds__(256) void track_suppress_kernel(const SuppressParam
     }
     // (regular frame: every det area is > 0, so no union with the track box can be zero)
     const bool swept = !has_z && n > 2048 && prm.group_flags && (prm.group_flags[f] & kFlagRegular);
+    const int last = n - 1;
+    int c_cur = (int)list[min(lane, last)];
+    int stage = 0;
     for (int q0 = 0; q0 < n; q0 += 64) {
         const int q = q0 + lane;
         const bool valid = q < n;
-        const int cidx = (int)list[min(q, n - 1)];          // unconditional loads: no vmcnt drain at joins
+        const int cidx = c_cur;
+        const int c_nn = (int)list[min(q0 + 64 + lane, last)];       // next chunk's ids, one iteration ahead
         bool r1 = false;
         if (!swept) {
             // round 1 (utils/nms.pyx:163-183): the DET is the "i" box, the track the "j" box
@@ -333,9 +336,10 @@ __global__ __launch_bounds__(256) void track_suppress_kernel(const SuppressParam
         }
         const bool alive = valid && !r1 && !((mask[cidx >> 5] >> (cidx & 31)) & 1u);
         unsigned long long am = __ballot(alive);
-        if (!am) continue;
-        const uint32_t off = alive ? prm.row_off[rb + cidx] : 0u;
-        const int deg = alive ? (int)prm.row_deg[rb + cidx] : 0;
+        uint2 meta = make_uint2(0u, 0u);
+        if (alive) meta = prm.row_meta[rb + cidx];                   // alive lanes only (see walk_kernel)
+        const uint32_t off = meta.x;
+        const int deg = (int)meta.y;
         while (am) {
             int ls[kWalkGrp];
             int ng = 0;
@@ -358,8 +362,10 @@ __global__ __launch_bounds__(256) void track_suppress_kernel(const SuppressParam
                 if (k >= ng) break;
                 const int cu = __builtin_amdgcn_readlane(cidx, ls[k]);
                 if ((mask[cu >> 5] >> (cu & 31)) & 1u) continue;
-                if (lane == 0) { list[nk] = (uint16_t)cu; atomicOr(const_cast<uint32_t *>(&mask[cu >> 5]), 1u << (cu & 31)); }
+                if ((nk & 63) == lane) stage = cu;
                 ++nk;
+                if ((nk & 63) == 0) list[nk - 64 + lane] = (uint16_t)stage;   // coalesced; positions < q0 + 64, all read already
+                if (lane == 0) atomicOr(const_cast<uint32_t *>(&mask[cu >> 5]), 1u << (cu & 31));
                 const uint32_t o = __builtin_amdgcn_readlane(off, ls[k]);
                 const int d = __builtin_amdgcn_readlane(deg, ls[k]);
                 for (int e0 = 0; e0 < d; e0 += 64) {
@@ -375,9 +381,9 @@ __global__ __launch_bounds__(256) void track_suppress_kernel(const SuppressParam
                 }
             }
         }
-        // NOTE on the in-place compaction: list[nk] is written only after list[q0..q0+63] was read
-        // (nk <= q0 + 64), by this wave, in program order.
+        c_cur = c_nn;
     }
+    if (lane < (nk & 63)) list[(nk & ~63) + lane] = (uint16_t)stage;         // tail
     if (lane == 0) prm.visited[p] = 1;
     if (lane == 0) prm.cnt[p] = nk;
     if (__ballot(bad != 0) && lane == 0) atomicOr(prm.status, kStDivZero);

@@ -74,7 +74,7 @@ struct vdet_ctx {
     size_t max_lds = 160 * 1024;
     int n_cu = 256;
     // scratch
-    DevBuf boxes, scores, keys, excl, frames, groups, tiles, bits, rowz, rowoff, rowdeg, groupz, adj, comp, origidx,
+    DevBuf boxes, scores, keys, excl, frames, groups, tiles, bits, rowz, rowmeta, groupz, adj, comp, origidx,
         out64, trk_frames, trk_boxes, b1, b2, iou_out, order, ncand, keepidx, keepcnt, gflags, pairs, tkeys, tstate, visited, tmp[8];
     // timing
     bool timing = false;
@@ -223,8 +223,7 @@ int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32)
     HIPCHK(c, c->tiles.reserve(std::max<size_t>(pl.tiles.size(), 1) * sizeof(TileDesc)));
     HIPCHK(c, c->bits.reserve(std::max<size_t>(pl.bits_words_max, 1) * 8));
     HIPCHK(c, c->rowz.reserve((size_t)pl.ntot * 4));
-    HIPCHK(c, c->rowoff.reserve((size_t)pl.ntot * 4));
-    HIPCHK(c, c->rowdeg.reserve((size_t)pl.ntot * 2));
+    HIPCHK(c, c->rowmeta.reserve((size_t)pl.ntot * 8));
     HIPCHK(c, c->groupz.reserve(G * 4));
     HIPCHK(c, c->gflags.reserve(G * 4));
     HIPCHK(c, c->pairs.reserve(std::max<size_t>(pl.pairs.size(), 1) * sizeof(TilePair)));
@@ -248,8 +247,7 @@ int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32)
 
     for (int attempt = 0; attempt < 2; ++attempt) {
         HIPCHK(c, hipMemsetAsync(c->rowz.p, 0, (size_t)pl.ntot * 4, c->stream));
-        HIPCHK(c, hipMemsetAsync(c->rowoff.p, 0, (size_t)pl.ntot * 4, c->stream));
-        HIPCHK(c, hipMemsetAsync(c->rowdeg.p, 0, (size_t)pl.ntot * 2, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->rowmeta.p, 0, (size_t)pl.ntot * 8, c->stream));
         HIPCHK(c, hipMemsetAsync(c->groupz.p, 0, G * 4, c->stream));
         HIPCHK(c, hipMemsetAsync(c->d_cnt, 0, sizeof(Counters), c->stream));
         const unsigned long long pool_cap = c->adj.cap / 2;
@@ -291,8 +289,8 @@ int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32)
                 StageTimer tm(c, ST_ADJ);
                 hipLaunchKernelGGL(adj_build_kernel, dim3(nt), dim3(256), 0, c->stream, d_boxes,
                                    c->groups.as<GroupDesc>(), c->tiles.as<TileDesc>() + bt.first,
-                                   c->bits.as<uint64_t>(), c->rowz.as<uint32_t>(), c->rowoff.as<uint32_t>(),
-                                   c->rowdeg.as<uint16_t>(), c->adj.as<uint16_t>(), &c->d_cnt->pool_used, pool_cap,
+                                   c->bits.as<uint64_t>(), c->rowz.as<uint32_t>(), c->rowmeta.as<uint2>(),
+                                   c->adj.as<uint16_t>(), &c->d_cnt->pool_used, pool_cap,
                                    &c->d_cnt->status);
             }
         }
@@ -403,8 +401,7 @@ int launch_sort_walk(vdet_ctx *c, const SortWalkArgs &a, int nmax, int64_t order
     wp.groups = c->groups.as<GroupDesc>();
     wp.order = c->order.as<uint16_t>();
     wp.ncand = c->ncand.as<int32_t>();
-    wp.row_off = c->rowoff.as<uint32_t>();
-    wp.row_deg = c->rowdeg.as<uint16_t>();
+    wp.row_meta = c->rowmeta.as<uint2>();
     wp.adj = c->adj.as<uint16_t>();
     wp.group_z = c->groupz.as<uint32_t>();
     wp.keep_idx = a.keep_idx;
@@ -596,7 +593,7 @@ int vdet_destroy(vdet_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->boxes, &c->scores, &c->keys, &c->excl, &c->frames, &c->groups, &c->tiles, &c->bits,
-                      &c->rowz, &c->rowoff, &c->rowdeg, &c->groupz, &c->adj, &c->comp, &c->origidx, &c->out64,
+                      &c->rowz, &c->rowmeta, &c->groupz, &c->adj, &c->comp, &c->origidx, &c->out64,
                       &c->trk_frames, &c->trk_boxes, &c->b1, &c->b2, &c->iou_out, &c->order, &c->ncand, &c->keepidx,
                       &c->keepcnt, &c->gflags, &c->pairs, &c->tkeys, &c->tstate, &c->visited};
     for (DevBuf *b : bufs) b->release();
@@ -946,8 +943,7 @@ int vdet_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scores, 
     sp.boxes = reinterpret_cast<const float4 *>(d_boxes);
     sp.F = (int)F; sp.B = (int)B; sp.C = (int)C; sp.max_tracks = max_tracks;
     sp.groups = c->groups.as<GroupDesc>();
-    sp.row_off = c->rowoff.as<uint32_t>();
-    sp.row_deg = c->rowdeg.as<uint16_t>();
+    sp.row_meta = c->rowmeta.as<uint2>();
     sp.adj = c->adj.as<uint16_t>();
     sp.group_z = c->groupz.as<uint32_t>();
     sp.group_flags = (t32 > 1e-30f && t32 < INFINITY && !c->force_general) ? c->gflags.as<uint32_t>() : nullptr;
