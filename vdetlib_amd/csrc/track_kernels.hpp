@@ -119,22 +119,103 @@ __device__ __forceinline__ float4 trunc4(float4 b)   // int(cor) of utils/protoc
 }
 
 // ------------------------------------------------------------------------------------------------
+// Per-frame proposal index (class-independent, built once per video): the frame's boxes sorted by
+// x1 ascending (xbox / xord = original index) plus a 256-bucket cumulative table over
+// [xmin, xmax] and the frame's largest width.  A box b can only reach IoU >= t with a box c if
+//     x1c - (1-t) * Wmax  <=  x1b  <=  x1c + (1-t) * w_c         (+1 convention, real arithmetic:
+// IoU <= iw / w_c and IoU <= iw / w_b, iw <= x2c - x1b + 1, iw <= x2b - x1c + 1), so linking,
+// spatial max-pooling and the round-1 sweep only read that window (widened by 1 px + 0.1 %, far
+// more than any rounding of the f32/f64 IoU).  Used for regular frames only.
+// ------------------------------------------------------------------------------------------------
+struct FrameIndex {
+    const float4 *xbox;      // [F*B] boxes in x1-ascending order per frame
+    const uint16_t *xord;    // [F*B] original index of each sorted box
+    const uint32_t *cum;     // [F*257] cum[k] = #boxes with bucket < k
+    const float *info;       // [F*4] xmin, scale (= 256 / (xmax - xmin)), wmax, unused
+};
+
+__device__ __forceinline__ int xbucket(float x, float xmin, float scale)
+{
+    const float t = (x - xmin) * scale;
+    return t <= 0.0f ? 0 : (t >= 255.0f ? 255 : (int)t);
+}
+
+// keys for the x1 sort: k = ~score_key(x1)  (sort_kernel sorts by descending key => ascending x1)
+__global__ void xkey_kernel(const float4 *__restrict__ boxes, uint32_t *__restrict__ keys, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) keys[i] = ~score_key(boxes[i].x);
+}
+
+// one block per frame: gather the sorted copy, frame extrema, bucket table
+__global__ __launch_bounds__(256) void frame_index_kernel(const float4 *__restrict__ boxes, const uint16_t *__restrict__ xord,
+                                                          int B, float4 *__restrict__ xbox, uint32_t *__restrict__ cum,
+                                                          float *__restrict__ info)
+{
+    __shared__ float smin[256], smax[256], swm[256];
+    __shared__ uint32_t hist[257];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const float4 *fb = boxes + (int64_t)f * B;
+    float mn = 3.0e38f, mx = -3.0e38f, wm = 0.0f;
+    for (int r = tid; r < B; r += 256) {
+        const float4 b = fb[xord[(int64_t)f * B + r]];
+        xbox[(int64_t)f * B + r] = b;
+        mn = fminf(mn, b.x); mx = fmaxf(mx, b.x); wm = fmaxf(wm, (b.z - b.x) + 1.0f);
+    }
+    smin[tid] = mn; smax[tid] = mx; swm[tid] = wm;
+    for (int i = tid; i < 257; i += 256) hist[i] = 0;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) {
+        if (tid < d) { smin[tid] = fminf(smin[tid], smin[tid + d]); smax[tid] = fmaxf(smax[tid], smax[tid + d]); swm[tid] = fmaxf(swm[tid], swm[tid + d]); }
+        __syncthreads();
+    }
+    const float xmin = smin[0], xmax = smax[0];
+    const float scale = xmax > xmin ? 256.0f / (xmax - xmin) : 0.0f;
+    for (int r = tid; r < B; r += 256) atomicAdd(&hist[xbucket(fb[r].x, xmin, scale) + 1], 1u);
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (int k = 0; k <= 256; ++k) { run += hist[k]; cum[(int64_t)f * 257 + k] = run; }
+        info[f * 4 + 0] = xmin; info[f * 4 + 1] = scale; info[f * 4 + 2] = swm[0]; info[f * 4 + 3] = 0.0f;
+    }
+}
+
+// rank range [r0, r1) of the boxes of frame f whose x1 lies in the IoU >= t window of box c
+__device__ __forceinline__ void xwindow(const FrameIndex &ix, int f, float x1c, float wc, double t, int &r0, int &r1)
+{
+    const float xmin = ix.info[f * 4 + 0], scale = ix.info[f * 4 + 1], wmax = ix.info[f * 4 + 2];
+    const double lo = (double)x1c - (1.0 - t) * (double)wmax * 1.001 - 1.0;
+    const double hi = (double)x1c + (1.0 - t) * (double)wc * 1.001 + 1.0;
+    const int b0 = xbucket((float)fmax(lo, -3.0e38), xmin, scale);
+    const int b1 = xbucket((float)fmin(hi, 3.0e38), xmin, scale);
+    // (float) rounding of lo/hi moves them by < 1 ulp of a pixel coordinate, covered by the margin;
+    // a bucket holds every x1 that maps to it, so [cum[b0], cum[b1 + 1]) is a superset of the window
+    r0 = (int)ix.cum[(int64_t)f * 257 + b0];
+    r1 = (int)ix.cum[(int64_t)f * 257 + b1 + 1];
+}
+
+// ------------------------------------------------------------------------------------------------
 // built-in tracker: tracks [C, max_tracks, F, 5] rows (x1,y1,x2,y2,score), NaN where the track has
 // no box.  The anchor row is the int-truncated anchor box with score 1; a neighbour frame gets the
 // (int-truncated) proposal with the highest f32 IoU with the current box, first index on ties,
 // while that IoU >= link_t32; at most `reach` frames to each side.
 // ------------------------------------------------------------------------------------------------
-// grid = (C, 2): blockIdx.y = 0 links forward (and writes the anchor row), 1 backward; block = 1024.
-// One barrier per frame: wave-level argmax by shuffles, 16 partial results in a parity-double-
-// buffered LDS slot, every thread finishes the reduction redundantly.
-__global__ __launch_bounds__(1024) void track_link_kernel(const float4 *__restrict__ boxes, int F, int B, int max_tracks,
+// grid = (C, 2): blockIdx.y = 0 links forward (and writes the anchor row), 1 backward; block = LT.
+// One barrier per frame: wave-level argmax by shuffles, LT/64 partial results in a parity-double-
+// buffered LDS slot, every thread finishes the reduction redundantly.  The step is a serial chain
+// executed by every wave, so a SMALL block wins: with 1024 threads the replicated serial part cost
+// ~7 us per frame (measured), the x-window leaves only ~2 000 candidates per frame anyway.
+constexpr int LT = 256;
+__global__ __launch_bounds__(LT) void track_link_kernel(const float4 *__restrict__ boxes, int F, int B, int max_tracks,
                                                           float link_t32, int reach, const TrackState *__restrict__ st,
                                                           float *__restrict__ tracks,
-                                                          const uint32_t *__restrict__ group_flags)
+                                                          const uint32_t *__restrict__ group_flags,
+                                                          const FrameIndex ix, double link_thres)
 {
-    __shared__ float sv[2][16];
-    __shared__ int si[2][16];
-    __shared__ float4 sb[2][16];          // the winning box travels with its score: no dependent global load
+    __shared__ float sv[2][LT / 64];
+    __shared__ int si[2][LT / 64];
+    __shared__ float4 sb[2][LT / 64];          // the winning box travels with its score: no dependent global load
+    __shared__ uint32_t scum[2][260];     // next frame's bucket table + (xmin, scale, wmax), prefetched
     const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int dir = blockIdx.y == 0 ? 1 : -1;
     const TrackState s = st[c];
@@ -142,8 +223,8 @@ __global__ __launch_bounds__(1024) void track_link_kernel(const float4 *__restri
     float *trk = tracks + ((int64_t)c * max_tracks + s.ntracks) * F * 5;
     const float qnan = __uint_as_float(0x7FC00000u);
     // my half of the track starts empty
-    if (dir > 0) { for (int i = s.anchor_frame * 5 + tid; i < F * 5; i += 1024) trk[i] = qnan; }
-    else { for (int i = tid; i < s.anchor_frame * 5; i += 1024) trk[i] = qnan; }
+    if (dir > 0) { for (int i = s.anchor_frame * 5 + tid; i < F * 5; i += LT) trk[i] = qnan; }
+    else { for (int i = tid; i < s.anchor_frame * 5; i += LT) trk[i] = qnan; }
     __syncthreads();
     const float4 anchor = trunc4(boxes[(int64_t)s.anchor_frame * B + s.anchor_box]);
     if (dir > 0 && tid == 0) {
@@ -151,15 +232,24 @@ __global__ __launch_bounds__(1024) void track_link_kernel(const float4 *__restri
         r[0] = anchor.x; r[1] = anchor.y; r[2] = anchor.z; r[3] = anchor.w; r[4] = 1.0f;
     }
     float4 cur = anchor;
+    if (ix.xbox) {   // bucket table of the first frame to visit (parity 1 = step 1)
+        const int f1 = min(max(s.anchor_frame + dir, 0), F - 1);
+        for (int i = tid; i < 260; i += LT)
+            scum[1][i] = i < 257 ? ix.cum[(int64_t)f1 * 257 + i] : __float_as_uint(ix.info[f1 * 4 + (i - 257)]);
+        __syncthreads();
+    }
     // software pipeline: the NEXT frame's boxes do not depend on this frame's result, so they are
     // loaded (up to LB per thread) before this frame's reduction / barrier
-    constexpr int LB = 10;                               // covers B <= 10240 from registers
+    constexpr int LB = 8;                                // fallback path (no index): first 8*LT boxes from registers
+    const bool use_ix = ix.xbox != nullptr;              // kernel-uniform
     float4 nb[LB];
-    {
+#pragma unroll
+    for (int i = 0; i < LB; ++i) nb[i] = anchor;
+    if (!use_ix) {
         const int f1 = s.anchor_frame + dir;
         const float4 *fb1 = boxes + (int64_t)min(max(f1, 0), F - 1) * B;
 #pragma unroll
-        for (int i = 0; i < LB; ++i) nb[i] = fb1[min(tid + i * 1024, B - 1)];
+        for (int i = 0; i < LB; ++i) nb[i] = fb1[min(tid + i * LT, B - 1)];
     }
     for (int step = 1; step <= reach; ++step) {
         const int f = s.anchor_frame + dir * step;
@@ -177,9 +267,49 @@ __global__ __launch_bounds__(1024) void track_link_kernel(const float4 *__restri
         const bool fast = group_flags && (group_flags[f] & kFlagRegular) && link_t32 > 1e-30f &&
                           carea > 0.0f && carea < __uint_as_float(0x7F800000u);
         const float t32e = link_t32 * 4.76837158203125e-7f;
+        if (fast && use_ix) {
+            // indexed frame: only the x-window that can reach IoU >= link_thres is read
+            int r0, r1;
+            {   // window from the LDS copy of this frame's table (prefetched during the previous step)
+                const float xmin = __uint_as_float(scum[par][257]), scale = __uint_as_float(scum[par][258]);
+                const float wmax = __uint_as_float(scum[par][259]);
+                const float wc = (cur.z - cur.x) + 1.0f;
+                const double lo = (double)cur.x - (1.0 - link_thres) * (double)wmax * 1.001 - 1.0;
+                const double hi = (double)cur.x + (1.0 - link_thres) * (double)wc * 1.001 + 1.0;
+                r0 = (int)scum[par][xbucket((float)fmax(lo, -3.0e38), xmin, scale)];
+                r1 = (int)scum[par][xbucket((float)fmin(hi, 3.0e38), xmin, scale) + 1];
+                // prefetch the table of the next frame into the other parity slot (read after the
+                // barrier of this step; the slot was last read one full step ago)
+                const int f2 = min(max(f + dir, 0), F - 1);
+                for (int i = tid; i < 260; i += LT)
+                    scum[par ^ 1][i] = i < 257 ? ix.cum[(int64_t)f2 * 257 + i] : __float_as_uint(ix.info[f2 * 4 + (i - 257)]);
+            }
+            const float4 *xb = ix.xbox + (int64_t)f * B;
+            const uint16_t *xo = ix.xord + (int64_t)f * B;
+            const int iters = (r1 - r0 + LT - 1) / LT;
+            for (int it = 0; it < iters; ++it) {
+                const int r = r0 + it * LT + tid;
+                const bool inb = r < r1;
+                const float4 x = xb[min(r, B - 1)];
+                bool border;
+                const bool pass = pred_regular(cur, carea, x, box_area(x), link_t32, t32e, border);
+                if (__ballot((pass || border) && inb)) {
+                    const float v = link_iou(cur, carea, x);
+                    const int b = (int)xo[min(r, B - 1)];
+                    if (inb && v >= link_t32 && (v > bv || (v == bv && b < bi))) { bv = v; bi = b; bb = x; }
+                }
+            }
+        } else if (use_ix) {
+            // irregular frame while an index exists: plain scan, no prefetch
+            for (int b = tid; b < B; b += LT) {
+                const float4 x = fb[b];
+                const float v = link_iou(cur, carea, x);
+                if (v > bv) { bv = v; bi = b; bb = x; }
+            }
+        } else
 #pragma unroll
         for (int i = 0; i < LB; ++i) {
-            const int b = tid + i * 1024;
+            const int b = tid + i * LT;
             if (fast) {
                 bool border;
                 const bool pass = pred_regular(cur, carea, nb[i], box_area(nb[i]), link_t32, t32e, border);
@@ -192,17 +322,18 @@ __global__ __launch_bounds__(1024) void track_link_kernel(const float4 *__restri
                 if (b < B && v > bv) { bv = v; bi = b; bb = nb[i]; }     // NaN never wins; lowest index on ties
             }
         }
-        for (int b = tid + LB * 1024; b < B; b += 1024) {
-            const float4 x = fb[b];
-            const float v = link_iou(cur, carea, x);
-            if (v > bv) { bv = v; bi = b; bb = x; }
-        }
+        if (!use_ix)
+            for (int b = tid + LB * LT; b < B; b += LT) {
+                const float4 x = fb[b];
+                const float v = link_iou(cur, carea, x);
+                if (v > bv) { bv = v; bi = b; bb = x; }
+            }
         const int my_bi = bi;
-        {   // prefetch frame f + dir
+        if (!use_ix) {   // prefetch frame f + dir
             const int f2 = f + dir;
             const float4 *fb2 = boxes + (int64_t)min(max(f2, 0), F - 1) * B;
 #pragma unroll
-            for (int i = 0; i < LB; ++i) nb[i] = fb2[min(tid + i * 1024, B - 1)];
+            for (int i = 0; i < LB; ++i) nb[i] = fb2[min(tid + i * LT, B - 1)];
         }
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) {
@@ -217,7 +348,7 @@ __global__ __launch_bounds__(1024) void track_link_kernel(const float4 *__restri
         int bidx = si[par][0];
         int bw = 0;
 #pragma unroll
-        for (int k = 1; k < 16; ++k) {
+        for (int k = 1; k < LT / 64; ++k) {
             const float v2 = sv[par][k];
             const int i2 = si[par][k];
             if (i2 >= 0 && (bidx < 0 || v2 > best || (v2 == best && i2 < bidx))) { best = v2; bidx = i2; bw = k; }
@@ -242,6 +373,8 @@ struct SuppressParams {
     const uint16_t *adj;
     const uint32_t *group_z;
     const uint32_t *group_flags;   // kFlagRegular per frame, or null
+    FrameIndex ix;                 // x-sorted proposal index (xbox == null: none)
+    double thres;                  // the NMS threshold as given (window computation)
     uint16_t *lists;               // [F*C, B] in/out
     int32_t *cnt;                  // [F*C]   in/out
     uint8_t *visited;              // [F*C]   1 once a list went through round 2 (it is an independent set)
@@ -307,6 +440,20 @@ __global__ __launch_bounds__(256) void track_suppress_kernel(const SuppressParam
         // long list (first visit of a full frame): round 1 as ONE coalesced sweep over the frame's
         // boxes by index (sets the dead bit), instead of a 16-B gather per list entry.  Boxes that
         // are not in the list get a bit too -- harmless, they are never visited.
+        const float tw = (tb.z - tb.x) + 1.0f;
+        if (prm.ix.xbox && prm.thres > 1e-6 && tw > 0.0f && tw < 3.0e38f) {
+            // only the x-window of the frame that can reach IoU >= thres with the track box
+            int r0, r1;
+            xwindow(prm.ix, f, tb.x, tw, prm.thres, r0, r1);
+            for (int r = r0 + lane; r < r1; r += 64) {
+                const float4 bd = prm.ix.xbox[(int64_t)f * B + r];
+                const uint32_t pp = pair_pred(bd, box_area(bd), tb, tarea, prm.t32);
+                if (pp & 1u) {
+                    const int b = prm.ix.xord[(int64_t)f * B + r];
+                    atomicOr(const_cast<uint32_t *>(&mask[b >> 5]), 1u << (b & 31));
+                }
+            }
+        } else
         for (int b0 = 0; b0 < B; b0 += 64) {
             const int b = min(b0 + lane, B - 1);
             const float4 bd = prm.boxes[rb + b];
@@ -419,7 +566,8 @@ __global__ __launch_bounds__(256) void rescore_spatial_kernel(const float *__res
                                                               const float4 *__restrict__ boxes,
                                                               const float *__restrict__ scores, int F, int B, int C, int T,
                                                               double thres, double *__restrict__ out_score,
-                                                              float *__restrict__ out_box)
+                                                              float *__restrict__ out_box, const FrameIndex ix,
+                                                              const uint32_t *__restrict__ group_flags)
 {
     __shared__ double ss[256];
     __shared__ long long si[256];
@@ -437,6 +585,20 @@ __global__ __launch_bounds__(256) void rescore_spatial_kernel(const float *__res
     const double p[4] = {(double)row[0], (double)row[1], (double)row[2], (double)row[3]};
     double bs = 0.0;
     int64_t bi = -1;
+    const float wc = (row[2] - row[0]) + 1.0f;
+    if (ix.xbox && group_flags && (group_flags[f] & kFlagRegular) && thres > 1e-6 && wc > 0.0f && wc < 3.0e38f) {
+        int r0, r1;
+        xwindow(ix, f, row[0], wc, thres, r0, r1);
+        for (int r = r0 + tid; r < r1; r += 256) {
+            const float4 bb = ix.xbox[(int64_t)f * B + r];
+            const double q[4] = {(double)bb.x, (double)bb.y, (double)bb.z, (double)bb.w};
+            if (iou_f64_pair(p, q) > thres) {
+                const int64_t j = ix.xord[(int64_t)f * B + r];
+                const double s = (double)scores[((int64_t)f * B + j) * C + c];
+                if (argmax_better(s, j, bs, bi)) { bs = s; bi = j; }
+            }
+        }
+    } else
     for (int j = tid; j < B; j += 256) {
         const float4 bb = boxes[(int64_t)f * B + j];
         const double q[4] = {(double)bb.x, (double)bb.y, (double)bb.z, (double)bb.w};

@@ -75,7 +75,7 @@ struct vdet_ctx {
     int n_cu = 256;
     // scratch
     DevBuf boxes, scores, keys, excl, frames, groups, tiles, bits, rowz, rowmeta, groupz, adj, comp, origidx,
-        out64, trk_frames, trk_boxes, b1, b2, iou_out, order, ncand, keepidx, keepcnt, gflags, pairs, tkeys, tstate, visited, tmp[8];
+        out64, trk_frames, trk_boxes, b1, b2, iou_out, order, ncand, keepidx, keepcnt, gflags, pairs, tkeys, tstate, visited, xkeys, xord, xncand, xbox, xcum, xinfo, tmp[8];
     // timing
     bool timing = false;
     bool timing_accumulate = false;   // vdet_set_timing(ctx, 2): keep events across calls until read
@@ -89,6 +89,8 @@ struct vdet_ctx {
     bool cache_enabled = false;
     struct PrepKey { const void *boxes = nullptr, *scores = nullptr; int64_t F = 0, B = 0, C = 0; float t32 = 0; int layout = -1, use_thr = 0; float thr = 0; } prep;
     bool graph_valid = false, lists_valid = false;
+    bool index_valid = false; const void *index_boxes = nullptr; int64_t index_F = 0, index_B = 0;
+    bool no_index = false;        // VDET_NO_INDEX=1: disable the x-sorted proposal index (tests / A-B)
     bool atomic_rank = false;     // LDS returning atomics serve same-address lanes in lane order (probed)
     bool no_transpose = false;    // VDET_NO_TRANSPOSE=1 (tests / A-B)
     bool force_general = false;   // VDET_FORCE_GENERAL=1: disable the symmetric fast kernel (tests)
@@ -310,6 +312,8 @@ int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32)
 struct SortWalkArgs {
     bool sort_only = false;       // tracking: only the per-problem lists are wanted
     bool walk_only = false;       // the lists of a previous call are still valid
+    uint16_t *order_out = nullptr;   // default: ctx scratch (c->order / c->ncand)
+    int32_t *ncand_out = nullptr;
     int mode, P, B, C;
     const float *scores;
     const uint32_t *keys;
@@ -325,8 +329,10 @@ int launch_sort_walk(vdet_ctx *c, const SortWalkArgs &a, int nmax, int64_t order
 {
     if (a.P <= 0) return VDET_OK;
     auto r16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
-    HIPCHK(c, c->order.reserve((size_t)std::max<int64_t>(order_elems, 1) * 2));
-    HIPCHK(c, c->ncand.reserve((size_t)a.P * 4));
+    if (!a.order_out) {
+        HIPCHK(c, c->order.reserve((size_t)std::max<int64_t>(order_elems, 1) * 2));
+        HIPCHK(c, c->ncand.reserve((size_t)a.P * 4));
+    }
     const int block = nmax > 1024 ? 1024 : 256;
     const int nw = block / 64;
     const int nchunks = (std::max(nmax, 1) + 63) / 64;
@@ -375,8 +381,8 @@ int launch_sort_walk(vdet_ctx *c, const SortWalkArgs &a, int nmax, int64_t order
         sp.use_thr = 0;
     }
     sp.groups = c->groups.as<GroupDesc>();
-    sp.order = c->order.as<uint16_t>();
-    sp.ncand = c->ncand.as<int32_t>();
+    sp.order = a.order_out ? a.order_out : c->order.as<uint16_t>();
+    sp.ncand = a.order_out ? a.ncand_out : c->ncand.as<int32_t>();
     sp.npass = 4;
     if (const char *e = getenv("VDET_SORT_PASSES")) sp.npass = atoi(e);
     const size_t keysB = r16((size_t)4 * std::max(nmax, 1));
@@ -552,6 +558,7 @@ int vdet_create(vdet_ctx **out, int device)
     c->stream = c->own_stream;
     (void)hipMemsetAsync(c->d_cnt, 0, sizeof(Counters), c->stream);
     if (const char *e = getenv("VDET_NO_TRANSPOSE")) c->no_transpose = atoi(e) != 0;
+    if (const char *e = getenv("VDET_NO_INDEX")) c->no_index = atoi(e) != 0;
     {   // probe: do returning LDS atomics resolve same-address lanes in ascending lane order?
         const int npat = 4096;
         std::vector<uint8_t> pats((size_t)npat * 64);
@@ -595,7 +602,8 @@ int vdet_destroy(vdet_ctx *c)
     DevBuf *bufs[] = {&c->boxes, &c->scores, &c->keys, &c->excl, &c->frames, &c->groups, &c->tiles, &c->bits,
                       &c->rowz, &c->rowmeta, &c->groupz, &c->adj, &c->comp, &c->origidx, &c->out64,
                       &c->trk_frames, &c->trk_boxes, &c->b1, &c->b2, &c->iou_out, &c->order, &c->ncand, &c->keepidx,
-                      &c->keepcnt, &c->gflags, &c->pairs, &c->tkeys, &c->tstate, &c->visited};
+                      &c->keepcnt, &c->gflags, &c->pairs, &c->tkeys, &c->tstate, &c->visited, &c->xkeys, &c->xord, &c->xncand,
+                      &c->xbox, &c->xcum, &c->xinfo};
     for (DevBuf *b : bufs) b->release();
     for (DevBuf &b : c->tmp) b.release();
     for (auto &e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -625,14 +633,14 @@ int vdet_set_cache(vdet_ctx *c, int enable)
 {
     if (!c) return VDET_EINVAL;
     c->cache_enabled = enable != 0;
-    c->graph_valid = c->lists_valid = false;
+    c->graph_valid = c->lists_valid = c->index_valid = false;
     return VDET_OK;
 }
 
 int vdet_invalidate(vdet_ctx *c)
 {
     if (!c) return VDET_EINVAL;
-    c->graph_valid = c->lists_valid = false;
+    c->graph_valid = c->lists_valid = c->index_valid = false;
     return VDET_OK;
 }
 
@@ -889,6 +897,47 @@ int vdet_nms_volume(vdet_ctx *c, const float *d_boxes, const float *d_scores, in
     return VDET_OK;
 }
 
+// x-sorted proposal index of every frame (see track_kernels.hpp).  Needs c->groups (one group per
+// frame) and c->gflags from the graph build of the same boxes.  Returns a null index when the fast
+// path is unavailable.
+static int build_frame_index(vdet_ctx *c, const float *d_boxes, int64_t F, int64_t B, bool flags_valid, FrameIndex &ix)
+{
+    ix = FrameIndex{nullptr, nullptr, nullptr, nullptr};
+    if (!flags_valid || c->no_index) return VDET_OK;
+    if (c->cache_enabled && c->index_valid && c->index_boxes == d_boxes && c->index_F == F && c->index_B == B) {
+        ix = FrameIndex{c->xbox.as<float4>(), c->xord.as<uint16_t>(), c->xcum.as<uint32_t>(), c->xinfo.as<float>()};
+        return VDET_OK;
+    }
+    const int64_t n = F * B;
+    HIPCHK(c, c->xkeys.reserve((size_t)n * 4));
+    HIPCHK(c, c->xord.reserve((size_t)n * 2));
+    HIPCHK(c, c->xncand.reserve((size_t)F * 4));
+    HIPCHK(c, c->xbox.reserve((size_t)n * 16));
+    HIPCHK(c, c->xcum.reserve((size_t)F * 257 * 4));
+    HIPCHK(c, c->xinfo.reserve((size_t)F * 16));
+    StageTimer tm(c, ST_OTHER);
+    hipLaunchKernelGGL(xkey_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
+                       reinterpret_cast<const float4 *>(d_boxes), c->xkeys.as<uint32_t>(), n);
+    SortWalkArgs a{};
+    a.sort_only = true;
+    a.mode = 2; a.P = (int)F;
+    a.keys = c->xkeys.as<uint32_t>();
+    a.order_out = c->xord.as<uint16_t>();
+    a.ncand_out = c->xncand.as<int32_t>();
+    const bool st = c->timing;
+    c->timing = false;                       // keep the per-(frame,class) sort stage clean
+    int rc = launch_sort_walk(c, a, (int)B, n);
+    c->timing = st;
+    if (rc) return rc;
+    hipLaunchKernelGGL(frame_index_kernel, dim3((unsigned)F), dim3(256), 0, c->stream,
+                       reinterpret_cast<const float4 *>(d_boxes), c->xord.as<uint16_t>(), (int)B, c->xbox.as<float4>(),
+                       c->xcum.as<uint32_t>(), c->xinfo.as<float>());
+    HIPCHK(c, hipGetLastError());
+    c->index_valid = true; c->index_boxes = d_boxes; c->index_F = F; c->index_B = B;
+    ix = FrameIndex{c->xbox.as<float4>(), c->xord.as<uint16_t>(), c->xcum.as<uint32_t>(), c->xinfo.as<float>()};
+    return VDET_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 int vdet_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scores, int64_t F, int64_t B, int64_t C,
                       double nms_thres, double thres, int max_tracks, double link_thres, int max_frames,
@@ -947,6 +996,9 @@ int vdet_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scores, 
     sp.adj = c->adj.as<uint16_t>();
     sp.group_z = c->groupz.as<uint32_t>();
     sp.group_flags = (t32 > 1e-30f && t32 < INFINITY && !c->force_general) ? c->gflags.as<uint32_t>() : nullptr;
+    rc = build_frame_index(c, d_boxes, F, B, sp.group_flags != nullptr, sp.ix);
+    if (rc) return rc;
+    sp.thres = nms_thres;
     sp.lists = c->order.as<uint16_t>();
     sp.cnt = c->ncand.as<int32_t>();
     HIPCHK(c, c->visited.reserve((size_t)(F * C)));
@@ -967,9 +1019,9 @@ int vdet_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scores, 
         }
         {
             StageTimer tm(c, ST_TLINK);
-            hipLaunchKernelGGL(track_link_kernel, dim3((unsigned)C, 2), dim3(1024), 0, c->stream,
+            hipLaunchKernelGGL(track_link_kernel, dim3((unsigned)C, 2), dim3(LT), 0, c->stream,
                                reinterpret_cast<const float4 *>(d_boxes), (int)F, (int)B, max_tracks, link_t32, reach, st,
-                               d_tracks, sp.group_flags);
+                               d_tracks, sp.group_flags, sp.ix, link_thres);
         }
         {
             StageTimer tm(c, ST_TSUPP);
@@ -996,11 +1048,31 @@ int vdet_rescore_tracks(vdet_ctx *c, const float *d_tracks, const int32_t *d_ntr
     if (nb > 0x7FFFFFF0ll) return fail(c, VDET_EINVAL, "too many tubelet boxes");
     HIPCHK(c, hipSetDevice(c->device));
     timing_reset(c);
+    FrameIndex ix{nullptr, nullptr, nullptr, nullptr};
+    const uint32_t *flags = nullptr;
+    if (!c->no_index && !c->force_general && B <= 32767 && B <= 18000) {
+        // per-frame regular flags + x-sorted index (reused from vdet_track_volume when cached)
+        HIPCHK(c, c->groups.reserve((size_t)F * sizeof(GroupDesc)));
+        HIPCHK(c, c->gflags.reserve((size_t)F * 4));
+        const bool have = c->cache_enabled && c->index_valid && c->index_boxes == d_boxes && c->index_F == F && c->index_B == B;
+        if (!have) {
+            std::vector<GroupDesc> g((size_t)F);
+            for (int64_t f = 0; f < F; ++f) g[(size_t)f] = {(int32_t)(f * B), (int32_t)B, 0};
+            HIPCHK(c, hipMemcpyAsync(c->groups.p, g.data(), (size_t)F * sizeof(GroupDesc), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            c->graph_valid = c->lists_valid = false;       // c->groups was rewritten
+            hipLaunchKernelGGL(frame_flags_kernel, dim3((unsigned)F), dim3(256), 0, c->stream,
+                               reinterpret_cast<const float4 *>(d_boxes), c->groups.as<GroupDesc>(), c->gflags.as<uint32_t>());
+        }
+        int rc = build_frame_index(c, d_boxes, F, B, true, ix);
+        if (rc) return rc;
+        flags = c->gflags.as<uint32_t>();
+    }
     {
         StageTimer tm(c, ST_RSPATIAL);
         hipLaunchKernelGGL(rescore_spatial_kernel, dim3((unsigned)nb), dim3(256), 0, c->stream, d_tracks, d_ntracks,
                            reinterpret_cast<const float4 *>(d_boxes), d_scores, (int)F, (int)B, (int)C, max_tracks,
-                           overlap_thres, d_det_score, d_boxes_out);
+                           overlap_thres, d_det_score, d_boxes_out, ix, flags);
     }
     {
         StageTimer tm(c, ST_RSERIES);
