@@ -119,82 +119,6 @@ __device__ __forceinline__ float4 trunc4(float4 b)   // int(cor) of utils/protoc
 }
 
 // ------------------------------------------------------------------------------------------------
-// Per-frame proposal index (class-independent, built once per video): the frame's boxes sorted by
-// x1 ascending (xbox / xord = original index) plus a 256-bucket cumulative table over
-// [xmin, xmax] and the frame's largest width.  A box b can only reach IoU >= t with a box c if
-//     x1c - (1-t) * Wmax  <=  x1b  <=  x1c + (1-t) * w_c         (+1 convention, real arithmetic:
-// IoU <= iw / w_c and IoU <= iw / w_b, iw <= x2c - x1b + 1, iw <= x2b - x1c + 1), so linking,
-// spatial max-pooling and the round-1 sweep only read that window (widened by 1 px + 0.1 %, far
-// more than any rounding of the f32/f64 IoU).  Used for regular frames only.
-// ------------------------------------------------------------------------------------------------
-struct FrameIndex {
-    const float4 *xbox;      // [F*B] boxes in x1-ascending order per frame
-    const uint16_t *xord;    // [F*B] original index of each sorted box
-    const uint32_t *cum;     // [F*257] cum[k] = #boxes with bucket < k
-    const float *info;       // [F*4] xmin, scale (= 256 / (xmax - xmin)), wmax, unused
-};
-
-__device__ __forceinline__ int xbucket(float x, float xmin, float scale)
-{
-    const float t = (x - xmin) * scale;
-    return t <= 0.0f ? 0 : (t >= 255.0f ? 255 : (int)t);
-}
-
-// keys for the x1 sort: k = ~score_key(x1)  (sort_kernel sorts by descending key => ascending x1)
-__global__ void xkey_kernel(const float4 *__restrict__ boxes, uint32_t *__restrict__ keys, int64_t n)
-{
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) keys[i] = ~score_key(boxes[i].x);
-}
-
-// one block per frame: gather the sorted copy, frame extrema, bucket table
-__global__ __launch_bounds__(256) void frame_index_kernel(const float4 *__restrict__ boxes, const uint16_t *__restrict__ xord,
-                                                          int B, float4 *__restrict__ xbox, uint32_t *__restrict__ cum,
-                                                          float *__restrict__ info)
-{
-    __shared__ float smin[256], smax[256], swm[256];
-    __shared__ uint32_t hist[257];
-    const int f = blockIdx.x, tid = threadIdx.x;
-    const float4 *fb = boxes + (int64_t)f * B;
-    float mn = 3.0e38f, mx = -3.0e38f, wm = 0.0f;
-    for (int r = tid; r < B; r += 256) {
-        const float4 b = fb[xord[(int64_t)f * B + r]];
-        xbox[(int64_t)f * B + r] = b;
-        mn = fminf(mn, b.x); mx = fmaxf(mx, b.x); wm = fmaxf(wm, (b.z - b.x) + 1.0f);
-    }
-    smin[tid] = mn; smax[tid] = mx; swm[tid] = wm;
-    for (int i = tid; i < 257; i += 256) hist[i] = 0;
-    __syncthreads();
-    for (int d = 128; d > 0; d >>= 1) {
-        if (tid < d) { smin[tid] = fminf(smin[tid], smin[tid + d]); smax[tid] = fmaxf(smax[tid], smax[tid + d]); swm[tid] = fmaxf(swm[tid], swm[tid + d]); }
-        __syncthreads();
-    }
-    const float xmin = smin[0], xmax = smax[0];
-    const float scale = xmax > xmin ? 256.0f / (xmax - xmin) : 0.0f;
-    for (int r = tid; r < B; r += 256) atomicAdd(&hist[xbucket(fb[r].x, xmin, scale) + 1], 1u);
-    __syncthreads();
-    if (tid == 0) {
-        uint32_t run = 0;
-        for (int k = 0; k <= 256; ++k) { run += hist[k]; cum[(int64_t)f * 257 + k] = run; }
-        info[f * 4 + 0] = xmin; info[f * 4 + 1] = scale; info[f * 4 + 2] = swm[0]; info[f * 4 + 3] = 0.0f;
-    }
-}
-
-// rank range [r0, r1) of the boxes of frame f whose x1 lies in the IoU >= t window of box c
-__device__ __forceinline__ void xwindow(const FrameIndex &ix, int f, float x1c, float wc, double t, int &r0, int &r1)
-{
-    const float xmin = ix.info[f * 4 + 0], scale = ix.info[f * 4 + 1], wmax = ix.info[f * 4 + 2];
-    const double lo = (double)x1c - (1.0 - t) * (double)wmax * 1.001 - 1.0;
-    const double hi = (double)x1c + (1.0 - t) * (double)wc * 1.001 + 1.0;
-    const int b0 = xbucket((float)fmax(lo, -3.0e38), xmin, scale);
-    const int b1 = xbucket((float)fmin(hi, 3.0e38), xmin, scale);
-    // (float) rounding of lo/hi moves them by < 1 ulp of a pixel coordinate, covered by the margin;
-    // a bucket holds every x1 that maps to it, so [cum[b0], cum[b1 + 1]) is a superset of the window
-    r0 = (int)ix.cum[(int64_t)f * 257 + b0];
-    r1 = (int)ix.cum[(int64_t)f * 257 + b1 + 1];
-}
-
-// ------------------------------------------------------------------------------------------------
 // built-in tracker: tracks [C, max_tracks, F, 5] rows (x1,y1,x2,y2,score), NaN where the track has
 // no box.  The anchor row is the int-truncated anchor box with score 1; a neighbour frame gets the
 // (int-truncated) proposal with the highest f32 IoU with the current box, first index on ties,

@@ -217,9 +217,41 @@ int make_plan(vdet_ctx *c, NmsPlan &pl)
     return VDET_OK;
 }
 
-// K1 + K2 for every batch; retries once with a larger adjacency pool.  Synchronizes the stream.
-int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32)
+int sort_groups_by_keys(vdet_ctx *c, int G, int nmax, int64_t ntot);
+
+// x1-sorted proposal index of every group (frame), see nms_kernels.hpp.  Needs c->groups uploaded.
+// Used by the fast K1 (rank space + tile skipping) and by the LINK kernels (IoU windows).
+int build_frame_index(vdet_ctx *c, const float4 *d_boxes, int64_t ntot, int64_t G, int nmax)
 {
+    if (c->cache_enabled && c->index_valid && c->index_boxes == d_boxes && c->index_F == G && c->index_B == ntot) return VDET_OK;
+    c->index_valid = false;
+    HIPCHK(c, c->xkeys.reserve((size_t)ntot * 4));
+    HIPCHK(c, c->xord.reserve((size_t)ntot * 2));
+    HIPCHK(c, c->xncand.reserve((size_t)G * 4));
+    HIPCHK(c, c->xbox.reserve((size_t)ntot * 16));
+    HIPCHK(c, c->xcum.reserve((size_t)G * 257 * 4));
+    HIPCHK(c, c->xinfo.reserve((size_t)G * 16));
+    StageTimer tm(c, ST_OTHER);
+    hipLaunchKernelGGL(xkey_kernel, dim3((unsigned)((ntot + 255) / 256)), dim3(256), 0, c->stream, d_boxes,
+                       c->xkeys.as<uint32_t>(), ntot);
+    int rc = sort_groups_by_keys(c, (int)G, nmax, ntot);
+    if (rc) return rc;
+    hipLaunchKernelGGL(frame_index_kernel, dim3((unsigned)G), dim3(256), 0, c->stream, d_boxes, c->groups.as<GroupDesc>(),
+                       c->xord.as<uint16_t>(), c->xbox.as<float4>(), c->xcum.as<uint32_t>(), c->xinfo.as<float>());
+    HIPCHK(c, hipGetLastError());
+    c->index_valid = true; c->index_boxes = d_boxes; c->index_F = G; c->index_B = ntot;
+    return VDET_OK;
+}
+
+FrameIndex frame_index_of(vdet_ctx *c)
+{
+    return FrameIndex{c->xbox.as<float4>(), c->xord.as<uint16_t>(), c->xcum.as<uint32_t>(), c->xinfo.as<float>()};
+}
+
+// K1 + K2 for every batch; retries once with a larger adjacency pool.  Synchronizes the stream.
+int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32, double thresh)
+{
+    const float one_minus_t = (float)std::max(0.0, 1.0 - (thresh == thresh ? thresh : 0.0));
     const size_t G = pl.groups.size();
     HIPCHK(c, c->groups.reserve(G * sizeof(GroupDesc)));
     HIPCHK(c, c->tiles.reserve(std::max<size_t>(pl.tiles.size(), 1) * sizeof(TileDesc)));
@@ -256,9 +288,13 @@ int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32)
         // fast symmetric kernel for regular frames needs 0 < t32 < inf (exact divide-free test)
         const bool use_sym = t32 > 1e-30f && t32 < INFINITY && !c->force_general;
         if (use_sym) {
-            StageTimer tm(c, ST_OTHER);
-            hipLaunchKernelGGL(frame_flags_kernel, dim3((unsigned)G), dim3(256), 0, c->stream, d_boxes,
-                               c->groups.as<GroupDesc>(), c->gflags.as<uint32_t>());
+            {
+                StageTimer tm(c, ST_OTHER);
+                hipLaunchKernelGGL(frame_flags_kernel, dim3((unsigned)G), dim3(256), 0, c->stream, d_boxes,
+                                   c->groups.as<GroupDesc>(), c->gflags.as<uint32_t>());
+            }
+            const int rci = build_frame_index(c, d_boxes, pl.ntot, (int64_t)G, pl.nmax);
+            if (rci) return rci;
         }
         for (size_t bi = 0; bi < pl.batch_tiles.size(); ++bi) {
             const auto bt = pl.batch_tiles[bi];
@@ -267,9 +303,9 @@ int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32)
             if (nt <= 0) continue;
             if (use_sym && bp.second > bp.first) {
                 StageTimer tm(c, ST_IOU_BITS);
-                hipLaunchKernelGGL(iou_bits_sym_kernel, dim3(bp.second - bp.first), dim3(256), 0, c->stream, d_boxes,
-                                   c->groups.as<GroupDesc>(), c->gflags.as<uint32_t>(),
-                                   c->pairs.as<TilePair>() + bp.first, t32, c->bits.as<uint64_t>());
+                hipLaunchKernelGGL(iou_bits_sym_kernel, dim3(bp.second - bp.first), dim3(256), 0, c->stream,
+                                   c->xbox.as<float4>(), c->groups.as<GroupDesc>(), c->gflags.as<uint32_t>(),
+                                   c->pairs.as<TilePair>() + bp.first, t32, one_minus_t, c->bits.as<uint64_t>());
             }
             // enough column splits to fill the chip when there are few row tiles
             int splits = 1;
@@ -293,7 +329,8 @@ int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32)
                                    c->groups.as<GroupDesc>(), c->tiles.as<TileDesc>() + bt.first,
                                    c->bits.as<uint64_t>(), c->rowz.as<uint32_t>(), c->rowmeta.as<uint2>(),
                                    c->adj.as<uint16_t>(), &c->d_cnt->pool_used, pool_cap,
-                                   &c->d_cnt->status);
+                                   &c->d_cnt->status, use_sym ? c->gflags.as<uint32_t>() : (const uint32_t *)nullptr,
+                                   c->xord.as<uint16_t>());
             }
         }
         HIPCHK(c, hipGetLastError());
@@ -422,6 +459,21 @@ int launch_sort_walk(vdet_ctx *c, const SortWalkArgs &a, int nmax, int64_t order
     }
     HIPCHK(c, hipGetLastError());
     return VDET_OK;
+}
+
+int sort_groups_by_keys(vdet_ctx *c, int G, int nmax, int64_t ntot)
+{
+    SortWalkArgs a{};
+    a.sort_only = true;
+    a.mode = 2; a.P = G;
+    a.keys = c->xkeys.as<uint32_t>();
+    a.order_out = c->xord.as<uint16_t>();
+    a.ncand_out = c->xncand.as<int32_t>();
+    const bool st = c->timing;
+    c->timing = false;                       // keep the per-(frame,class) sort stage clean
+    const int rc = launch_sort_walk(c, a, nmax, ntot);
+    c->timing = st;
+    return rc;
 }
 
 // descending sort of n composites held in c->comp (zero padded to a power of two)
@@ -759,7 +811,7 @@ int vdet_nms_f32(vdet_ctx *c, const float *h_dets, int64_t n, int64_t ld, int nc
         d_keys = c->keys.as<uint32_t>();
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    int rc = build_graph(c, c->boxes.as<float4>(), pl, thresh_to_f32(thresh));
+    int rc = build_graph(c, c->boxes.as<float4>(), pl, thresh_to_f32(thresh), thresh);
     if (rc) return rc;
     return nms_grouped_tail(c, pl, c->scores.as<float>(), d_keys, nullptr, h_keep, n_keep);
 }
@@ -810,7 +862,7 @@ int vdet_track_det_nms_f32(vdet_ctx *c, const float *h_tracks, int64_t t, int64_
     HIPCHK(c, hipMemcpyAsync(c->trk_frames.p, tf.data(), tf.size() * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     // build_graph clears the status word, so round 1 runs after it (inside the same stream order):
-    rc = build_graph(c, c->boxes.as<float4>(), pl, t32);
+    rc = build_graph(c, c->boxes.as<float4>(), pl, t32, thresh);
     if (rc) return rc;
     {
         StageTimer tm(c, ST_OTHER);
@@ -878,7 +930,7 @@ int vdet_nms_volume(vdet_ctx *c, const float *d_boxes, const float *d_scores, in
         pl.groups.resize((size_t)F);
         for (int64_t f = 0; f < F; ++f) pl.groups[(size_t)f] = {(int32_t)(f * B), (int32_t)B, 0};
         make_plan(c, pl);
-        rc = build_graph(c, reinterpret_cast<const float4 *>(d_boxes), pl, t32);
+        rc = build_graph(c, reinterpret_cast<const float4 *>(d_boxes), pl, t32, thresh);
         if (rc) return rc;
         c->prep.boxes = d_boxes; c->prep.F = F; c->prep.B = B; c->prep.t32 = t32;
         c->graph_valid = true;
@@ -894,47 +946,6 @@ int vdet_nms_volume(vdet_ctx *c, const float *d_boxes, const float *d_scores, in
     c->prep.scores = d_scores; c->prep.C = C; c->prep.layout = layout; c->prep.use_thr = use_score_thresh;
     c->prep.thr = score_thresh;
     c->lists_valid = true;
-    return VDET_OK;
-}
-
-// x-sorted proposal index of every frame (see track_kernels.hpp).  Needs c->groups (one group per
-// frame) and c->gflags from the graph build of the same boxes.  Returns a null index when the fast
-// path is unavailable.
-static int build_frame_index(vdet_ctx *c, const float *d_boxes, int64_t F, int64_t B, bool flags_valid, FrameIndex &ix)
-{
-    ix = FrameIndex{nullptr, nullptr, nullptr, nullptr};
-    if (!flags_valid || c->no_index) return VDET_OK;
-    if (c->cache_enabled && c->index_valid && c->index_boxes == d_boxes && c->index_F == F && c->index_B == B) {
-        ix = FrameIndex{c->xbox.as<float4>(), c->xord.as<uint16_t>(), c->xcum.as<uint32_t>(), c->xinfo.as<float>()};
-        return VDET_OK;
-    }
-    const int64_t n = F * B;
-    HIPCHK(c, c->xkeys.reserve((size_t)n * 4));
-    HIPCHK(c, c->xord.reserve((size_t)n * 2));
-    HIPCHK(c, c->xncand.reserve((size_t)F * 4));
-    HIPCHK(c, c->xbox.reserve((size_t)n * 16));
-    HIPCHK(c, c->xcum.reserve((size_t)F * 257 * 4));
-    HIPCHK(c, c->xinfo.reserve((size_t)F * 16));
-    StageTimer tm(c, ST_OTHER);
-    hipLaunchKernelGGL(xkey_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
-                       reinterpret_cast<const float4 *>(d_boxes), c->xkeys.as<uint32_t>(), n);
-    SortWalkArgs a{};
-    a.sort_only = true;
-    a.mode = 2; a.P = (int)F;
-    a.keys = c->xkeys.as<uint32_t>();
-    a.order_out = c->xord.as<uint16_t>();
-    a.ncand_out = c->xncand.as<int32_t>();
-    const bool st = c->timing;
-    c->timing = false;                       // keep the per-(frame,class) sort stage clean
-    int rc = launch_sort_walk(c, a, (int)B, n);
-    c->timing = st;
-    if (rc) return rc;
-    hipLaunchKernelGGL(frame_index_kernel, dim3((unsigned)F), dim3(256), 0, c->stream,
-                       reinterpret_cast<const float4 *>(d_boxes), c->xord.as<uint16_t>(), (int)B, c->xbox.as<float4>(),
-                       c->xcum.as<uint32_t>(), c->xinfo.as<float>());
-    HIPCHK(c, hipGetLastError());
-    c->index_valid = true; c->index_boxes = d_boxes; c->index_F = F; c->index_B = B;
-    ix = FrameIndex{c->xbox.as<float4>(), c->xord.as<uint16_t>(), c->xcum.as<uint32_t>(), c->xinfo.as<float>()};
     return VDET_OK;
 }
 
@@ -964,7 +975,7 @@ int vdet_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scores, 
         pl.groups.resize((size_t)F);
         for (int64_t f = 0; f < F; ++f) pl.groups[(size_t)f] = {(int32_t)(f * B), (int32_t)B, 0};
         make_plan(c, pl);
-        rc = build_graph(c, reinterpret_cast<const float4 *>(d_boxes), pl, t32);
+        rc = build_graph(c, reinterpret_cast<const float4 *>(d_boxes), pl, t32, nms_thres);
         if (rc) return rc;
         c->prep.boxes = d_boxes; c->prep.F = F; c->prep.B = B; c->prep.t32 = t32;
         c->graph_valid = true;
@@ -996,8 +1007,8 @@ int vdet_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scores, 
     sp.adj = c->adj.as<uint16_t>();
     sp.group_z = c->groupz.as<uint32_t>();
     sp.group_flags = (t32 > 1e-30f && t32 < INFINITY && !c->force_general) ? c->gflags.as<uint32_t>() : nullptr;
-    rc = build_frame_index(c, d_boxes, F, B, sp.group_flags != nullptr, sp.ix);
-    if (rc) return rc;
+    sp.ix = FrameIndex{nullptr, nullptr, nullptr, nullptr};
+    if (sp.group_flags && c->index_valid && !c->no_index) sp.ix = frame_index_of(c);   // built by build_graph
     sp.thres = nms_thres;
     sp.lists = c->order.as<uint16_t>();
     sp.cnt = c->ncand.as<int32_t>();
@@ -1050,22 +1061,25 @@ int vdet_rescore_tracks(vdet_ctx *c, const float *d_tracks, const int32_t *d_ntr
     timing_reset(c);
     FrameIndex ix{nullptr, nullptr, nullptr, nullptr};
     const uint32_t *flags = nullptr;
-    if (!c->no_index && !c->force_general && B <= 32767 && B <= 18000) {
-        // per-frame regular flags + x-sorted index (reused from vdet_track_volume when cached)
-        HIPCHK(c, c->groups.reserve((size_t)F * sizeof(GroupDesc)));
-        HIPCHK(c, c->gflags.reserve((size_t)F * 4));
-        const bool have = c->cache_enabled && c->index_valid && c->index_boxes == d_boxes && c->index_F == F && c->index_B == B;
+    if (!c->no_index && !c->force_general && B <= 18000) {
+        // per-frame regular flags + x-sorted index: reused from the graph build of the same boxes
+        // when the cache is on, else rebuilt here (cheap: one 3 M-key sort)
+        const bool have = c->cache_enabled && c->graph_valid && c->index_valid && c->prep.boxes == d_boxes &&
+                          c->prep.F == F && c->prep.B == B && c->index_boxes == d_boxes;
         if (!have) {
+            c->graph_valid = c->lists_valid = c->index_valid = false;       // c->groups is rewritten
+            HIPCHK(c, c->groups.reserve((size_t)F * sizeof(GroupDesc)));
+            HIPCHK(c, c->gflags.reserve((size_t)F * 4));
             std::vector<GroupDesc> g((size_t)F);
             for (int64_t f = 0; f < F; ++f) g[(size_t)f] = {(int32_t)(f * B), (int32_t)B, 0};
             HIPCHK(c, hipMemcpyAsync(c->groups.p, g.data(), (size_t)F * sizeof(GroupDesc), hipMemcpyHostToDevice, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
-            c->graph_valid = c->lists_valid = false;       // c->groups was rewritten
             hipLaunchKernelGGL(frame_flags_kernel, dim3((unsigned)F), dim3(256), 0, c->stream,
                                reinterpret_cast<const float4 *>(d_boxes), c->groups.as<GroupDesc>(), c->gflags.as<uint32_t>());
+            const int rc = build_frame_index(c, reinterpret_cast<const float4 *>(d_boxes), F * B, F, (int)B);
+            if (rc) return rc;
         }
-        int rc = build_frame_index(c, d_boxes, F, B, true, ix);
-        if (rc) return rc;
+        ix = frame_index_of(c);
         flags = c->gflags.as<uint32_t>();
     }
     {
