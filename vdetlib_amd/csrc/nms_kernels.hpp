@@ -427,6 +427,8 @@ __global__ __launch_bounds__(256) void iou_bits_sym_kernel(const float4 *__restr
 // Each tile reserves one contiguous slab of the u16 pool with a single atomicAdd; the slab layout
 // is irrelevant to the result (lists are sets).  Zero-union partners are appended with kZTag.
 // ------------------------------------------------------------------------------------------------
+constexpr int kAdjStage = 24576;     // u16 entries staged in LDS per 256-row tile (48 KB)
+
 __global__ __launch_bounds__(256) void adj_build_kernel(const float4 *__restrict__ boxes,
                                                         const GroupDesc *__restrict__ groups,
                                                         const TileDesc *__restrict__ tiles,
@@ -437,10 +439,11 @@ __global__ __launch_bounds__(256) void adj_build_kernel(const float4 *__restrict
                                                         unsigned long long *__restrict__ pool_used,
                                                         unsigned long long pool_cap, int *__restrict__ status,
                                                         const uint32_t *__restrict__ group_flags,
-                                                        const uint16_t *__restrict__ xord)
+                                                        const FrameIndex ix, float one_minus_t)
 {
     __shared__ uint32_t sscan[256];
     __shared__ unsigned long long sbase;
+    __shared__ uint16_t sstage[kAdjStage];
     const TileDesc td = tiles[blockIdx.x];
     const GroupDesc gd = groups[td.group];
     const int B = gd.nbox;
@@ -449,12 +452,25 @@ __global__ __launch_bounds__(256) void adj_build_kernel(const float4 *__restrict
     const int W = (B + 63) >> 6;
     const uint64_t *col = bits + gd.bits_off + v;
     // regular groups were evaluated in x1-rank space (iou_bits_sym_kernel): translate back
-    const uint16_t *tr = (group_flags && (group_flags[td.group] & kFlagRegular)) ? xord + gd.box_off : nullptr;
+    const uint16_t *tr = (group_flags && (group_flags[td.group] & kFlagRegular)) ? ix.xord + gd.box_off : nullptr;
     const int vo = (tr && v < B) ? (int)tr[v] : v;       // the box this row belongs to
+    // ... and only the words inside the row's IoU >= t window can be non-zero (the rest was
+    // zero-filled by the tile skipping or is zero anyway): read just those
+    int w0 = 0, w1 = W;
+    if (tr && v < B) {
+        const float4 bx = ix.xbox[gd.box_off + v];
+        const float xmin = ix.info[td.group * 4 + 0], scale = ix.info[td.group * 4 + 1], wmax = ix.info[td.group * 4 + 2];
+        const float lo = bx.x - one_minus_t * wmax * 1.001f - 2.0f;
+        const float hi = bx.x + one_minus_t * ((bx.z - bx.x) + 1.0f) * 1.001f + 2.0f;
+        const int r0 = (int)ix.cum[(int64_t)td.group * 257 + xbucket(lo, xmin, scale)];
+        const int r1 = (int)ix.cum[(int64_t)td.group * 257 + xbucket(hi, xmin, scale) + 1];
+        w0 = r0 >> 6;
+        w1 = min(W, (r1 + 63) >> 6);
+    }
 
     uint32_t deg = 0, zc = 0;
     if (v < B) {
-        for (int w = 0; w < W; ++w) deg += __popcll(col[(int64_t)w * B]);
+        for (int w = w0; w < w1; ++w) deg += __popcll(col[(int64_t)w * B]);
         zc = tr ? 0u : row_z[gd.box_off + v];
     }
     const uint32_t tot = deg + zc;
@@ -472,30 +488,42 @@ __global__ __launch_bounds__(256) void adj_build_kernel(const float4 *__restrict
     __syncthreads();
     const unsigned long long base = sbase;
     const uint32_t tile_total = sscan[255];
-    if (v >= B) return;
     if (base + tile_total > pool_cap || base + tile_total > 0xFFFFFFFFull) {
         if (tid == 0) atomicOr(status, kStPool);
-        row_meta[gd.box_off + vo] = make_uint2(0u, 0u);
+        if (v < B) row_meta[gd.box_off + vo] = make_uint2(0u, 0u);
         return;
     }
-    uint32_t p = (uint32_t)base + (incl - tot);
-    row_meta[gd.box_off + vo] = make_uint2(p, tot);
-    for (int w = 0; w < W; ++w) {
-        uint64_t m = col[(int64_t)w * B];
-        while (m) {
-            const int k = __ffsll((unsigned long long)m) - 1;
-            adj[p++] = tr ? tr[w * 64 + k] : (uint16_t)(w * 64 + k);
-            m &= m - 1;
+    const bool staged = tile_total <= (uint32_t)kAdjStage;     // block-uniform
+    const uint32_t lofs = incl - tot;                           // my list's offset inside the tile slab
+    if (v < B) {
+        uint32_t p = (uint32_t)base + lofs;
+        row_meta[gd.box_off + vo] = make_uint2(p, tot);
+        uint32_t q = lofs;
+        for (int w = w0; w < w1; ++w) {
+            uint64_t m = col[(int64_t)w * B];
+            while (m) {
+                const int k = __ffsll((unsigned long long)m) - 1;
+                const uint16_t e = tr ? tr[w * 64 + k] : (uint16_t)(w * 64 + k);
+                if (staged) sstage[q++] = e; else adj[p++] = e;
+                m &= m - 1;
+            }
+        }
+        if (zc) {  // rare: degenerate boxes.  Recompute which partners have a zero union.
+            const float4 brow = boxes[gd.box_off + v];
+            const float rarea = box_area(brow);
+            for (int u = 0; u < B; ++u) {
+                if (u == v) continue;
+                const float4 bu = boxes[gd.box_off + u];
+                if (pair_pred(brow, rarea, bu, box_area(bu), 0.0f) & 2u) {
+                    const uint16_t e = (uint16_t)u | kZTag;
+                    if (staged) sstage[q++] = e; else adj[p++] = e;
+                }
+            }
         }
     }
-    if (zc) {  // rare: degenerate boxes.  Recompute which partners have a zero union.
-        const float4 brow = boxes[gd.box_off + v];
-        const float rarea = box_area(brow);
-        for (int u = 0; u < B; ++u) {
-            if (u == v) continue;
-            const float4 bu = boxes[gd.box_off + u];
-            if (pair_pred(brow, rarea, bu, box_area(bu), 0.0f) & 2u) adj[p++] = (uint16_t)u | kZTag;
-        }
+    if (staged) {   // one coalesced copy of the tile's slab instead of 256 interleaved 2-byte streams
+        __syncthreads();
+        for (uint32_t i = tid; i < tile_total; i += 256) adj[base + i] = sstage[i];
     }
 }
 

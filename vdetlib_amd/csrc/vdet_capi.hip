@@ -330,7 +330,7 @@ int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32, doub
                                    c->bits.as<uint64_t>(), c->rowz.as<uint32_t>(), c->rowmeta.as<uint2>(),
                                    c->adj.as<uint16_t>(), &c->d_cnt->pool_used, pool_cap,
                                    &c->d_cnt->status, use_sym ? c->gflags.as<uint32_t>() : (const uint32_t *)nullptr,
-                                   c->xord.as<uint16_t>());
+                                   use_sym ? frame_index_of(c) : FrameIndex{nullptr, nullptr, nullptr, nullptr}, one_minus_t);
             }
         }
         HIPCHK(c, hipGetLastError());
