@@ -824,17 +824,27 @@ __global__ __launch_bounds__(256) void walk_kernel(const WalkParams prm)
 
     int nk = 0;
     int bad = 0;
+    // Two-deep software pipeline over the chunks of 64 candidates: the ids of chunk i+2 (one
+    // coalesced load) and the row meta of chunk i+1 (an 8-B gather, issued only for the lanes that
+    // are still alive NOW -- a dead candidate never revives, so this is a superset of what will be
+    // needed) are in flight while chunk i is walked.  Per chunk only the adjacency-list loads of
+    // its survivor groups remain on the critical path.
+    const int last = max(ncand - 1, 0);
+    int c_cur = (int)order[min(lane, last)];
+    int c_nxt = (int)order[min(64 + lane, last)];
+    uint2 m_cur = make_uint2(0u, 0u);
+    if (lane < ncand) m_cur = prm.row_meta[rb + c_cur];       // chunk 0: everything is alive
     for (int q0 = 0; q0 < ncand; q0 += 64) {
         const int q = q0 + lane;
         const bool valid = q < ncand;
-        const int c = valid ? (int)order[q] : 0;
+        const int c = c_cur;
+        const int c_nn = (int)order[min(q0 + 128 + lane, last)];
+        uint2 m_nxt = make_uint2(0u, 0u);
+        if ((q + 64) < ncand && !((mask[c_nxt >> 5] >> (c_nxt & 31)) & 1u)) m_nxt = prm.row_meta[rb + c_nxt];
         const bool alive = valid && !((mask[c >> 5] >> (c & 31)) & 1u);
         unsigned long long am = __ballot(alive);
-        if (!am) continue;
-        uint2 meta = make_uint2(0u, 0u);
-        if (alive) meta = prm.row_meta[rb + c];      // ONE 8-B gather, alive lanes only (a 64-lane gather
-        const uint32_t off = meta.x;                 // is 64 transactions; doing it for the ~85 % dead
-        const int deg = (int)meta.y;                 // candidates made the walk 1.5-1.8x slower, measured)
+        const uint32_t off = m_cur.x;
+        const int deg = (int)m_cur.y;
         while (am) {
             int ls[kWalkGrp];
             int ng = 0;
@@ -881,6 +891,7 @@ __global__ __launch_bounds__(256) void walk_kernel(const WalkParams prm)
                 // accesses are volatile / atomic on possibly-aliasing words, so hipcc keeps them ordered
             }
         }
+        c_cur = c_nxt; c_nxt = c_nn; m_cur = m_nxt;
     }
     if (lane == 0) prm.keep_cnt[p] = nk;
     if ((int64_t)nk > cap && lane == 0) atomicOr(prm.status, kStCap);

@@ -130,6 +130,7 @@ __device__ __forceinline__ float4 trunc4(float4 b)   // int(cor) of utils/protoc
 // executed by every wave, so a SMALL block wins: with 1024 threads the replicated serial part cost
 // ~7 us per frame (measured), the x-window leaves only ~2 000 candidates per frame anyway.
 constexpr int LT = 256;
+static_assert(LT == 256, "the bucket-table prefetch of track_link_kernel assumes 256 threads");
 __global__ __launch_bounds__(LT) void track_link_kernel(const float4 *__restrict__ boxes, int F, int B, int max_tracks,
                                                           float link_t32, int reach, const TrackState *__restrict__ st,
                                                           float *__restrict__ tracks,
@@ -202,27 +203,39 @@ __global__ __launch_bounds__(LT) void track_link_kernel(const float4 *__restrict
                 const double hi = (double)cur.x + (1.0 - link_thres) * (double)wc * 1.001 + 1.0;
                 r0 = (int)scum[par][xbucket((float)fmax(lo, -3.0e38), xmin, scale)];
                 r1 = (int)scum[par][xbucket((float)fmin(hi, 3.0e38), xmin, scale) + 1];
-                // prefetch the table of the next frame into the other parity slot (read after the
-                // barrier of this step; the slot was last read one full step ago)
-                const int f2 = min(max(f + dir, 0), F - 1);
-                for (int i = tid; i < 260; i += LT)
-                    scum[par ^ 1][i] = i < 257 ? ix.cum[(int64_t)f2 * 257 + i] : __float_as_uint(ix.info[f2 * 4 + (i - 257)]);
             }
+            // prefetch the table of the next frame: the loads are issued here, together with the box
+            // loads below, and stored to the other parity slot only after the boxes were processed
+            // (the slot is read after this step's barrier; it was last read one full step ago)
+            const int f2 = min(max(f + dir, 0), F - 1);
+            const uint32_t pf0 = ix.cum[(int64_t)f2 * 257 + tid];
+            const uint32_t pf1 = tid == 0 ? ix.cum[(int64_t)f2 * 257 + 256]
+                                          : __float_as_uint(ix.info[f2 * 4 + min(tid - 1, 2)]);
             const float4 *xb = ix.xbox + (int64_t)f * B;
             const uint16_t *xo = ix.xord + (int64_t)f * B;
-            const int iters = (r1 - r0 + LT - 1) / LT;
-            for (int it = 0; it < iters; ++it) {
-                const int r = r0 + it * LT + tid;
-                const bool inb = r < r1;
-                const float4 x = xb[min(r, B - 1)];
-                bool border;
-                const bool pass = pred_regular(cur, carea, x, box_area(x), link_t32, t32e, border);
-                if (__ballot((pass || border) && inb)) {
-                    const float v = link_iou(cur, carea, x);
-                    const int b = (int)xo[min(r, B - 1)];
-                    if (inb && v >= link_t32 && (v > bv || (v == bv && b < bi))) { bv = v; bi = b; bb = x; }
+            // batches of WB boxes per thread: all WB loads are issued before the first use (a load
+            // inside the ballot-branching loop body is waited for immediately: one full memory
+            // latency per box, ~7 us per frame measured)
+            constexpr int WB = 8;
+            for (int rb0 = r0; rb0 < r1; rb0 += WB * LT) {
+                float4 xs[WB];
+#pragma unroll
+                for (int i = 0; i < WB; ++i) xs[i] = xb[min(rb0 + i * LT + tid, B - 1)];
+#pragma unroll
+                for (int i = 0; i < WB; ++i) {
+                    const int r = rb0 + i * LT + tid;
+                    const bool inb = r < r1;
+                    bool border;
+                    const bool pass = pred_regular(cur, carea, xs[i], box_area(xs[i]), link_t32, t32e, border);
+                    if (__ballot((pass || border) && inb)) {
+                        const float v = link_iou(cur, carea, xs[i]);
+                        const int b = (int)xo[min(r, B - 1)];
+                        if (inb && v >= link_t32 && (v > bv || (v == bv && b < bi))) { bv = v; bi = b; bb = xs[i]; }
+                    }
                 }
             }
+            scum[par ^ 1][tid] = pf0;                           // LT == 256: entries 0..255
+            if (tid < 4) scum[par ^ 1][tid == 0 ? 256 : 256 + tid] = pf1;   // 256, then xmin/scale/wmax
         } else if (use_ix) {
             // irregular frame while an index exists: plain scan, no prefetch
             for (int b = tid; b < B; b += LT) {
