@@ -173,14 +173,32 @@ def main():
             oracle.temporal_maxpool(hs, args.window)
             cdt = time.perf_counter() - t1
             cpu_boxes = nf * B * (nc / C)
-            cpu = {"value": cpu_boxes / cdt, "unit": "boxes/s", "cores": 1, "kind": "port",
-                   "sample": "NMS+TEMP stages on %d frames x %d classes x %d boxes (%d nms problems + temporal "
-                             "max-pool) in %.1f s, oracle/vdet_oracle.c single thread; LINK not included (the C "
-                             "oracle's track_det_nms loop is exercised in tests/)" % (nf, nc, B, nf * nc, cdt)}
-            # and use the sample as a last parity check of this very run
+            t_nms_per_box = cdt / cpu_boxes                 # seconds per box (all C classes), NMS + TEMP
+            sample = ("NMS+TEMP on %d frames x %d classes x %d boxes (%d nms problems + temporal max-pool) in %.1f s"
+                      % (nf, nc, B, nf * nc, cdt))
             gi = out[0][:nf, :nc].cpu().numpy()
             gc = out[1][:nf, :nc].cpu().numpy()
-            cpu["parity_checked"] = bool(np.array_equal(gc, wcnt) and np.array_equal(gi, widx))
+            parity = bool(np.array_equal(gc, wcnt) and np.array_equal(gi, widx))
+            t_link_per_box = 0.0
+            if not args.no_link:
+                # LINK on a bounded sample: the first frames of the video, one class, same options
+                fl = min(F, 30)
+                sb, ss = boxes[:fl].contiguous(), scores[:fl, :, :1].contiguous()
+                t2 = time.perf_counter()
+                wt, wa, wn = oracle.greedy_track_volume(sb.cpu().numpy(), ss[:, :, 0].cpu().numpy(), args.thresh,
+                                                        args.track_thres, args.max_tracks, args.link_thres, 0)
+                ldt = time.perf_counter() - t2
+                t_link_per_box = ldt / (fl * B * (1.0 / C))
+                sample += "; LINK (greedy tubelets, %d tracks) on %d frames x 1 class x %d boxes in %.1f s" % (wn, fl, B, ldt)
+                ctx.invalidate()
+                gt, ga, gn = ops.track_volume(sb, ss, nms_thres=args.thresh, thres=args.track_thres,
+                                              max_tracks=args.max_tracks, link_thres=args.link_thres)
+                ctx.invalidate()
+                parity = parity and int(gn[0]) == wn and bool(np.array_equal(gt[0, :wn].cpu().numpy(), wt[:wn], equal_nan=True))
+            cpu = {"value": 1.0 / (t_nms_per_box + t_link_per_box), "unit": "boxes/s", "cores": 1, "kind": "port",
+                   "sample": sample + "; oracle/vdet_oracle.c + oracle/oracle.py, single thread; per-box times of the "
+                                      "stages are added (value = boxes/s through the same stages as the GPU step)",
+                   "nms_temp_boxes_per_s": 1.0 / t_nms_per_box, "parity_checked": parity}
 
         result = {
             "metric": "boxes/sec whole-node (NMS+temporal-conv+link), 300fx10k-box synth",
