@@ -201,3 +201,17 @@ def test_iou_f64(oracle, nms_golden):
     with np.errstate(all='ignore'):
         assert np.array_equal(ops.iou(b1, b2), oracle.iou(b1, b2), equal_nan=True)
     assert np.array_equal(ops.iou([[1, 2, 3, 4]], [[1, 2, 3, 4]]), [[1.0]])
+
+
+@pytest.mark.parametrize("n", [17000, 20000, 32767])
+def test_nms_large_single_problem(cnms, oracle, n):
+    """Beyond the in-LDS sort (~18k boxes) the host entry points fall back to a global bitonic sort;
+    the u16 index limit is 32767."""
+    d = synth.dets5(5000 + n, n, degenerate=n // 3, kind='randn')
+    assert cnms.nms(d, 0.4) == oracle.nms(d, 0.4)
+    if n == 20000:
+        d6 = np.hstack([np.ones((n, 1), np.float32), d])
+        d6[::3, 0] = 2
+        assert cnms.vid_nms(d6, 0.3) == oracle.vid_nms(d6, 0.3)
+    with pytest.raises(ValueError):
+        cnms.nms(np.zeros((32768, 5), np.float32), 0.3)

@@ -118,3 +118,56 @@ def test_temporal_conv(torch_cuda, oracle):
         want = oracle.temporal_conv(v, taps, bias=0.25, pad=-1.0)
         assert np.array_equal(got, want), (shape, k)      # same op order, no contraction: bit-exact
         assert np.allclose(got, want, rtol=0, atol=1e-5)  # north-star tolerance for float scores
+
+
+def test_volume_edge_shapes(torch_cuda, oracle):
+    """Empty / minimal / ragged-in-content inputs of the device-resident entry points."""
+    torch = torch_cuda
+    from vdetlib_amd import ops
+    # one frame, one box, one class
+    b = torch.tensor([[[10., 10., 20., 20.]]], device='cuda')
+    s = torch.tensor([[[0.5]]], device='cuda')
+    idx, cnt = ops.nms_volume(b, s, 0.3)
+    assert idx.tolist() == [[[0]]] and cnt.tolist() == [[1]]
+    # no boxes at all
+    idx, cnt = ops.nms_volume(torch.zeros(3, 0, 4, device='cuda'), torch.zeros(3, 0, 2, device='cuda'), 0.3, cap=4)
+    assert cnt.tolist() == [[0, 0]] * 3 and idx.shape == (3, 2, 4)
+    # all boxes identical: exactly one survivor (the best score), everything below threshold: none
+    b = torch.tensor([5., 5., 50., 60.], device='cuda').repeat(2, 300, 1)
+    s = torch.rand(2, 300, 3, device='cuda')
+    idx, cnt = ops.nms_volume(b, s, 0.3)
+    assert cnt.tolist() == [[1, 1, 1]] * 2
+    assert torch.equal(idx[:, :, 0].long(), s.argmax(1))
+    idx, cnt = ops.nms_volume(b, s, 0.3, score_thresh=2.0)
+    assert int(cnt.sum()) == 0
+    # thresholds at the edges: thresh > 1 keeps everything, thresh 0 keeps one per connected "all" graph
+    boxes, scores = synth.video(31, 2, 120, 2)
+    for thr in (1.5, 1.0, 0.0, 1e-12):
+        tb, ts = torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda()
+        i1, c1 = ops.nms_volume(tb, ts, thr)
+        i2, c2 = oracle.nms_volume(boxes, scores, thr)
+        assert np.array_equal(c1.cpu().numpy(), c2) and np.array_equal(i1.cpu().numpy(), i2), thr
+    # per-frame limit of the volume path
+    with pytest.raises(ValueError):
+        ops.nms_volume(torch.zeros(1, 19000, 4, device='cuda'), torch.zeros(1, 19000, 1, device='cuda'), 0.3, cap=8)
+    # temporal ops on a single frame / single series
+    v = torch.rand(1, 8, device='cuda')
+    assert torch.equal(ops.temporal_maxpool(v, 3), v)
+    assert ops.temporal_maxpool(torch.zeros(0, 8, device='cuda'), 3).shape == (0, 8)
+    # tracking: nothing above the stop threshold / no tracks requested
+    tr, an, nt = ops.track_volume(torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda(), thres=2.0, max_tracks=3)
+    assert nt.tolist() == [0, 0] and bool(torch.isnan(tr).all())
+    tr, an, nt = ops.track_volume(torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda(), max_tracks=0)
+    assert nt.tolist() == [0, 0] and tr.shape == (2, 0, 2, 5)
+
+
+def test_volume_nan_inf_boxes_take_general_path(torch_cuda, oracle):
+    """A frame with NaN/inf/degenerate boxes is 'irregular': it must go through the general kernel
+    while its regular neighbours use the symmetric fast one -- same results as the oracle."""
+    torch = torch_cuda
+    boxes, scores = synth.video(32, 4, 500, 3, frac=True)
+    boxes[1, 7, 0] = np.nan
+    boxes[1, 9, 3] = np.inf
+    boxes[2, 100:110, 2] = boxes[2, 100:110, 0] - 5      # negative widths
+    _check_volume(torch, oracle, boxes, scores, 0.3)
+    _check_volume(torch, oracle, boxes, scores, 0.5, score_thresh=0.2)

@@ -968,6 +968,39 @@ __global__ __launch_bounds__(1024) void bitonic_lds_kernel(unsigned long long *_
         if (base + i < n2) data[base + i] = s[i];
 }
 
+// Large-group fallback of the per-problem argsort (groups that do not fit the in-LDS sort, up to the
+// 32 767 boxes a u16 index can address): composites key << 32 | index, sorted by the global bitonic
+// network, then unpacked.  Same order as sort_kernel: descending key, ties by descending index;
+// non-candidates (key 0) at the tail.
+__global__ void fill_comp_kernel(const float *__restrict__ scores, const uint32_t *__restrict__ keys,
+                                 const uint8_t *__restrict__ excl, int use_thr, float thr, int64_t base, int n,
+                                 uint32_t n2, unsigned long long *__restrict__ comp, int32_t *__restrict__ ncand_p)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n2) return;
+    unsigned long long c = 0ull;
+    if ((int)i < n) {
+        uint32_t k;
+        bool x = false;
+        if (keys) { k = keys[base + i]; x = (k == 0u); }
+        else {
+            const float sc = scores[base + i];
+            k = score_key(sc);
+            if (use_thr && !(sc > thr)) x = true;
+        }
+        if (excl && excl[base + i]) x = true;
+        if (x) k = 0u; else atomicAdd(ncand_p, 1);
+        c = ((unsigned long long)k << 32) | i;
+    }
+    comp[i] = c;
+}
+
+__global__ void comp_to_order_kernel(const unsigned long long *__restrict__ comp, int n, uint16_t *__restrict__ order)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) order[i] = (uint16_t)(comp[i] & 0xFFFFull);
+}
+
 // composites -> int64 indices
 __global__ void comp_to_index_kernel(const unsigned long long *__restrict__ comp, uint32_t n, int64_t *__restrict__ out)
 {

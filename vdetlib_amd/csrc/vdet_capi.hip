@@ -91,6 +91,7 @@ struct vdet_ctx {
     bool graph_valid = false, lists_valid = false;
     bool index_valid = false; const void *index_boxes = nullptr; int64_t index_F = 0, index_B = 0;
     bool no_index = false;        // VDET_NO_INDEX=1: disable the x-sorted proposal index (tests / A-B)
+    const std::vector<GroupDesc> *host_groups = nullptr;   // group table of the call in flight (mode 2)
     bool atomic_rank = false;     // LDS returning atomics serve same-address lanes in lane order (probed)
     bool no_transpose = false;    // VDET_NO_TRANSPOSE=1 (tests / A-B)
     bool force_general = false;   // VDET_FORCE_GENERAL=1: disable the symmetric fast kernel (tests)
@@ -253,6 +254,7 @@ int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32, doub
 {
     const float one_minus_t = (float)std::max(0.0, 1.0 - (thresh == thresh ? thresh : 0.0));
     const size_t G = pl.groups.size();
+    c->host_groups = &pl.groups;
     HIPCHK(c, c->groups.reserve(G * sizeof(GroupDesc)));
     HIPCHK(c, c->tiles.reserve(std::max<size_t>(pl.tiles.size(), 1) * sizeof(TileDesc)));
     HIPCHK(c, c->bits.reserve(std::max<size_t>(pl.bits_words_max, 1) * 8));
@@ -286,7 +288,9 @@ int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32, doub
         HIPCHK(c, hipMemsetAsync(c->d_cnt, 0, sizeof(Counters), c->stream));
         const unsigned long long pool_cap = c->adj.cap / 2;
         // fast symmetric kernel for regular frames needs 0 < t32 < inf (exact divide-free test)
-        const bool use_sym = t32 > 1e-30f && t32 < INFINITY && !c->force_general;
+        // ... and the x1 index, whose sort must fit the LDS (8 B per box + tables)
+        const bool use_sym = t32 > 1e-30f && t32 < INFINITY && !c->force_general &&
+                             (size_t)8 * pl.nmax + 24 * 1024 <= c->max_lds;
         if (use_sym) {
             {
                 StageTimer tm(c, ST_OTHER);
@@ -362,6 +366,8 @@ struct SortWalkArgs {
     int64_t cap;
 };
 
+int sort_comp_desc(vdet_ctx *c, uint32_t n);
+
 int launch_sort_walk(vdet_ctx *c, const SortWalkArgs &a, int nmax, int64_t order_elems)
 {
     if (a.P <= 0) return VDET_OK;
@@ -428,10 +434,31 @@ int launch_sort_walk(vdet_ctx *c, const SortWalkArgs &a, int nmax, int64_t order
     sp.lds_idxb_off = (int)(keysB + idxB);
     sp.lds_base_off = (int)(keysB + 2 * idxB);
     const size_t lds = keysB + 2 * idxB + (size_t)4 * (nw * 256 + 256 + 4);
-    if (!var || lds > c->dyn_lds_max)
+    const bool big = !var || lds > c->dyn_lds_max;
+    if (big && a.mode != 2)
         return fail(c, VDET_EINVAL, "a frame with %d boxes needs %zu B of LDS for the in-LDS sort; the limit is %zu B "
                                     "(about 18000 boxes per frame)", nmax, lds, c->dyn_lds_max);
-    if (!a.walk_only) {
+    if (big && !a.walk_only) {
+        // flat groups (host-buffer entry points) beyond the LDS limit: one global bitonic sort per
+        // group.  Slow path for rare, very large single problems (<= 32767 boxes).
+        if (!c->host_groups || (int)c->host_groups->size() != a.P) return fail(c, VDET_EINVAL, "internal: group table missing");
+        HIPCHK(c, hipMemsetAsync(sp.ncand, 0, (size_t)a.P * 4, c->stream));
+        StageTimer tm(c, ST_SORTK);
+        for (int g = 0; g < a.P; ++g) {
+            const GroupDesc &gd = (*c->host_groups)[(size_t)g];
+            const int n = gd.nbox;
+            if (n <= 0) continue;
+            const uint32_t n2 = pow2ceil((uint32_t)n);
+            HIPCHK(c, c->comp.reserve((size_t)n2 * 8));
+            hipLaunchKernelGGL(fill_comp_kernel, dim3((n2 + 255) / 256), dim3(256), 0, c->stream, a.scores, a.keys, a.excl,
+                               a.use_thr, a.thr, (int64_t)gd.box_off, n, n2, c->comp.as<unsigned long long>(), sp.ncand + g);
+            const int rc = sort_comp_desc(c, n2);
+            if (rc) return rc;
+            hipLaunchKernelGGL(comp_to_order_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream,
+                               c->comp.as<unsigned long long>(), n, sp.order + gd.box_off);
+        }
+        HIPCHK(c, hipGetLastError());
+    } else if (!a.walk_only) {
         const int grid = (a.P + 7) & ~7;
         StageTimer tm(c, ST_SORTK);
         void *args[] = {&sp};
