@@ -159,6 +159,17 @@ int vdet_series_interp_f64(vdet_ctx *ctx, const double *h_x, const double *h_y, 
 int vdet_threshold_topk(vdet_ctx *ctx, const void *h_scores, int is_f64, int64_t B, int64_t ld, int col0,
                         int ncls, double thresh, int k, int32_t *h_idx, int32_t *h_cnt);
 
+/*
+ * One temporal-convolution layer of the tubelet TCN (the build's stand-in for the external Caffe
+ * net that score_conv_cls feeds, vdet/tubelet_cls.py:15-51; parity unpinned):
+ *   out[co,l] = act(b[co] + sum_ci sum_k w[co,ci,k] * in[ci, l+k-K/2]), zero padded, f32,
+ * accumulated ci-outer / k-inner without contraction.  h_in [Cin,L], h_w [Cout,Cin,K], h_b [Cout],
+ * h_out [Cout,L]; K odd.  act: 0 none, 1 ReLU, 2 softmax over the Cout channels (applied after the
+ * affine part, like Caffe's SoftmaxLayer).
+ */
+int vdet_conv1d_f32(vdet_ctx *ctx, const float *h_in, int Cin, int L, const float *h_w, const float *h_b,
+                    int Cout, int K, int act, float *h_out);
+
 /* ---- device-resident array forms (asynchronous; see vdet_sync) ------------------------------- */
 
 #define VDET_LAYOUT_FBC 0 /* scores [F,B,C], class innermost (zs[B,C], utils/protocol.py:538) */

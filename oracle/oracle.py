@@ -380,3 +380,31 @@ def greedy_track_volume(boxes, scores_c, nms_thres=0.3, thres=0.0, max_tracks=10
                 if i not in kp:
                     keep[det_id] = False
     return tracks, anchors, nt
+
+
+def tcn_forward(x, layers):
+    """The build's tubelet TCN (vdetlib_amd/vdet/tcn.py) on the CPU, same accumulation order:
+    x [Cin,L] f32; layers = [(W [Cout,Cin,K], b [Cout])...]; ReLU between layers, channel softmax at
+    the end.  Parity unpinned (the reference's net is external)."""
+    f = np.float32
+    x = np.asarray(x, dtype=f)
+    for li, (w, b) in enumerate(layers):
+        w = np.asarray(w, dtype=f); b = np.asarray(b, dtype=f)
+        Cout, Cin, K = w.shape
+        L = x.shape[1]
+        h = K // 2
+        xp = np.zeros((Cin, L + 2 * h), dtype=f)
+        xp[:, h:h + L] = x
+        out = np.repeat(b[:, None], L, 1).astype(f)
+        for ci in range(Cin):
+            for k in range(K):
+                out = (out + (w[:, ci, k][:, None] * xp[ci, k:k + L][None, :]).astype(f)).astype(f)
+        if li < len(layers) - 1:
+            out = np.where(out > 0, out, f(0)).astype(f)
+        x = out
+    m = x.max(0)
+    e = np.exp((x - m).astype(f)).astype(f)
+    ssum = np.zeros(x.shape[1], dtype=f)
+    for c in range(x.shape[0]):
+        ssum = (ssum + e[c]).astype(f)
+    return (e / ssum).astype(f)

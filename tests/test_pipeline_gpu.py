@@ -191,3 +191,26 @@ def test_overlap_anchor_and_conv_cls(case, proto_golden):
         res = T.score_conv_cls(copy.deepcopy(sc['inp']), net)
     _close(net.calls, sc['blobs'], tol=1e-7)
     _close(_py(res), sc['out'], tol=1e-6)
+
+
+def test_tcn_net_with_score_conv_cls(oracle, proto_golden):
+    """score_conv_cls driving the gfx950 TCN (pycaffe calling convention) == the oracle's numpy TCN
+    on the same channel assembly.  Tolerance 1e-5 on the probabilities (expf differs in the last
+    ulp between libm and the GPU)."""
+    from vdetlib_amd.vdet import tubelet_cls as T
+    from vdetlib_amd.vdet.tcn import TCNNet
+    sc = proto_golden['score_conv_cls']
+    names = ['det_scores', 'track_scores', 'anchors', 'abs_anchors']
+    net = TCNNet.random([(n, 1) for n in names], hidden=(8, 8), kernel=5, seed=3)
+    with contextlib.redirect_stdout(io.StringIO()):
+        res = T.score_conv_cls(copy.deepcopy(sc['inp']), net)
+    for tub_in, tub_out in zip(sc['inp']['tubelets'], res['tubelets']):
+        boxes = tub_in['boxes']
+        L = len(boxes)
+        x = np.asarray([[b['det_score'] for b in boxes], [b['track_score'] for b in boxes],
+                        [b['anchor'] * 1. / L for b in boxes], [abs(b['anchor'] * 1. / L) for b in boxes]], dtype=np.float32)
+        want = oracle.tcn_forward(x, net.layers)[1]
+        got = np.asarray([b['conv_score'] for b in tub_out['boxes']])
+        assert got.shape == want.shape and np.allclose(got, want, rtol=0, atol=1e-5)
+    with pytest.raises(ValueError):
+        TCNNet([('det_scores', 1)], [(np.zeros((3, 1, 3), np.float32), np.zeros(3, np.float32))])

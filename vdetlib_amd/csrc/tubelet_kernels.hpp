@@ -219,4 +219,42 @@ __global__ __launch_bounds__(256) void threshold_topk_kernel(const T *__restrict
     if (tid == 0) out_cnt[cls] = k;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Temporal convolution layer of the tubelet TCN (stand-in for the external Caffe net behind
+// score_conv_cls, vdet/tubelet_cls.py:15-51; parity UNPINNED: no prototxt/weights in the reference).
+//   out[co, l] = act( b[co] + sum_ci sum_k w[co, ci, k] * in[ci, l + k - K/2] )   ("same" zero padding)
+// accumulated in exactly that order (ci outer, k inner) in f32 without contraction.
+// act: 0 none, 1 ReLU.  One thread per output element.
+// ------------------------------------------------------------------------------------------------
+__global__ void conv1d_kernel(const float *__restrict__ in, int Cin, int L, const float *__restrict__ w,
+                              const float *__restrict__ b, int Cout, int K, int act, float *__restrict__ out)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= Cout * L) return;
+    const int co = e / L, l = e - co * L;
+    const int h = K / 2;
+    float acc = b[co];
+    for (int ci = 0; ci < Cin; ++ci)
+        for (int k = 0; k < K; ++k) {
+            const int g = l + k - h;
+            const float x = (g >= 0 && g < L) ? in[ci * L + min(max(g, 0), L - 1)] : 0.0f;
+            const float p = w[(co * Cin + ci) * K + k] * x;
+            acc = acc + p;
+        }
+    if (act == 1) acc = acc > 0.0f ? acc : 0.0f;
+    out[e] = acc;
+}
+
+// softmax over the channel axis of [Cout, L] (Caffe SoftmaxLayer: subtract the max, exp, normalise)
+__global__ void softmax_channels_kernel(const float *__restrict__ in, int Cout, int L, float *__restrict__ out)
+{
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= L) return;
+    float m = in[l];
+    for (int c = 1; c < Cout; ++c) m = fmaxf(m, in[c * L + l]);
+    float sum = 0.0f;
+    for (int c = 0; c < Cout; ++c) sum = sum + expf(in[c * L + l] - m);
+    for (int c = 0; c < Cout; ++c) out[c * L + l] = expf(in[c * L + l] - m) / sum;
+}
+
 }  // namespace vdet

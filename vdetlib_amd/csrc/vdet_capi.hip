@@ -1300,6 +1300,36 @@ int vdet_threshold_topk(vdet_ctx *c, const void *h_scores, int is_f64, int64_t B
     return VDET_OK;
 }
 
+int vdet_conv1d_f32(vdet_ctx *c, const float *h_in, int Cin, int L, const float *h_w, const float *h_b, int Cout, int K,
+                    int act, float *h_out)
+{
+    if (!c || Cin < 1 || Cout < 1 || L < 0 || K < 1 || K % 2 != 1 || act < 0 || act > 2)
+        return c ? fail(c, VDET_EINVAL, "bad conv1d arguments") : VDET_EINVAL;
+    if (L == 0) return VDET_OK;
+    if (!h_in || !h_w || !h_b || !h_out) return fail(c, VDET_EINVAL, "null buffer");
+    HIPCHK(c, hipSetDevice(c->device));
+    timing_reset(c);
+    int rc;
+    if ((rc = upload(c, c->tmp[0], h_in, (size_t)Cin * L * 4))) return rc;
+    if ((rc = upload(c, c->tmp[1], h_w, (size_t)Cout * Cin * K * 4))) return rc;
+    if ((rc = upload(c, c->tmp[2], h_b, (size_t)Cout * 4))) return rc;
+    HIPCHK(c, c->tmp[3].reserve((size_t)Cout * L * 4));
+    HIPCHK(c, c->tmp[4].reserve((size_t)Cout * L * 4));
+    const int n = Cout * L;
+    hipLaunchKernelGGL(conv1d_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->tmp[0].as<float>(), Cin, L,
+                       c->tmp[1].as<float>(), c->tmp[2].as<float>(), Cout, K, act == 1 ? 1 : 0, c->tmp[3].as<float>());
+    float *res = c->tmp[3].as<float>();
+    if (act == 2) {
+        hipLaunchKernelGGL(softmax_channels_kernel, dim3((L + 255) / 256), dim3(256), 0, c->stream, c->tmp[3].as<float>(),
+                           Cout, L, c->tmp[4].as<float>());
+        res = c->tmp[4].as<float>();
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(h_out, res, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VDET_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 static int temporal_launch(vdet_ctx *c, int mode, const float *d_in, float *d_out, int64_t F, int64_t S, int W,
                            float pad, float bias, const Taps &taps)
