@@ -794,6 +794,54 @@ struct WalkParams {
 
 constexpr int kWalkGrp = 8;
 
+// One 64-entry slice of a survivor's adjacency list -> dead bits.  HASZ = false (every regular
+// frame): entries are plain indices, nothing to test -- this is the instruction-issue hot spot of
+// the walk (one wave does ~1 400 survivors x 2 slices per problem), so it is kept to the bone.
+template <bool HASZ>
+__device__ __forceinline__ void walk_apply_slice(volatile uint32_t *mask, uint16_t e, bool in_range, int &bad)
+{
+    if (in_range) {
+        if (HASZ) {
+            const int v = e & 0x7FFF;
+            if (e & kZTag) { if (!((mask[v >> 5] >> (v & 31)) & 1u)) bad = 1; }
+            else atomicOr(const_cast<uint32_t *>(&mask[v >> 5]), 1u << (v & 31));
+        } else {
+            atomicOr(const_cast<uint32_t *>(&mask[e >> 5]), 1u << (e & 31));
+        }
+    }
+}
+
+// the survivors of one group of up to kWalkGrp alive candidates (lanes ls[0..ng) of c / off / deg)
+template <bool HASZ>
+__device__ __forceinline__ void walk_group(volatile uint32_t *mask, const uint16_t *__restrict__ adj, int lane, int c,
+                                           uint32_t off, int deg, const int (&ls)[kWalkGrp], int ng,
+                                           const uint16_t (&pre0)[kWalkGrp], const uint16_t (&pre1)[kWalkGrp],
+                                           int32_t *__restrict__ out, int64_t cap, int &nk, int &bad)
+{
+#pragma unroll
+    for (int k = 0; k < kWalkGrp; ++k) {
+        if (k >= ng) break;
+        const int cu = __builtin_amdgcn_readlane(c, ls[k]);
+        if ((mask[cu >> 5] >> (cu & 31)) & 1u) continue;    // suppressed by an earlier survivor of this chunk
+        const int d = __builtin_amdgcn_readlane(deg, ls[k]);
+        if (lane == 0) {
+            if ((int64_t)nk < cap) out[nk] = cu;
+            atomicOr(const_cast<uint32_t *>(&mask[cu >> 5]), 1u << (cu & 31));
+        }
+        ++nk;
+        walk_apply_slice<HASZ>(mask, pre0[k], lane < d, bad);
+        if (d > 64) {
+            walk_apply_slice<HASZ>(mask, pre1[k], lane + 64 < d, bad);
+            if (d > 128) {   // rare: long lists
+                const uint32_t o = __builtin_amdgcn_readlane(off, ls[k]);
+                for (int e0 = 128; e0 < d; e0 += 64)
+                    walk_apply_slice<HASZ>(mask, adj[o + min(e0 + lane, d - 1)], e0 + lane < d, bad);
+            }
+        }
+    }
+}
+
+
 __global__ __launch_bounds__(256) void walk_kernel(const WalkParams prm)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -866,30 +914,8 @@ __global__ __launch_bounds__(256) void walk_kernel(const WalkParams prm)
                 pre0[k] = prm.adj[o + min(lane, dm)];
                 pre1[k] = prm.adj[o + min(lane + 64, dm)];
             }
-#pragma unroll
-            for (int k = 0; k < kWalkGrp; ++k) {
-                if (k >= ng) break;
-                const int cu = __builtin_amdgcn_readlane(c, ls[k]);
-                if ((mask[cu >> 5] >> (cu & 31)) & 1u) continue;    // suppressed by an earlier survivor of this chunk
-                if ((int64_t)nk < cap) { if (lane == 0) out[nk] = cu; }
-                ++nk;
-                const uint32_t o = __builtin_amdgcn_readlane(off, ls[k]);
-                const int d = __builtin_amdgcn_readlane(deg, ls[k]);
-                if (lane == 0) atomicOr(const_cast<uint32_t *>(&mask[cu >> 5]), 1u << (cu & 31));
-                for (int e0 = 0; e0 < d; e0 += 64) {
-                    uint16_t e;
-                    if (e0 == 0) e = pre0[k];
-                    else if (e0 == 64) e = pre1[k];
-                    else e = (e0 + lane < d) ? prm.adj[o + e0 + lane] : (uint16_t)0;
-                    if (e0 + lane < d) {
-                        const int v = e & 0x7FFF;
-                        if (e & kZTag) { if (!((mask[v >> 5] >> (v & 31)) & 1u)) bad = 1; }
-                        else atomicOr(const_cast<uint32_t *>(&mask[v >> 5]), 1u << (v & 31));
-                    }
-                }
-                // no fence needed: the LDS executes one wave's operations in order, the mask
-                // accesses are volatile / atomic on possibly-aliasing words, so hipcc keeps them ordered
-            }
+            if (has_z) walk_group<true>(mask, prm.adj, lane, c, off, deg, ls, ng, pre0, pre1, out, cap, nk, bad);
+            else walk_group<false>(mask, prm.adj, lane, c, off, deg, ls, ng, pre0, pre1, out, cap, nk, bad);
         }
         c_cur = c_nxt; c_nxt = c_nn; m_cur = m_nxt;
     }

@@ -450,18 +450,18 @@ __global__ __launch_bounds__(256) void track_suppress_kernel(const SuppressParam
                 ++nk;
                 if ((nk & 63) == 0) list[nk - 64 + lane] = (uint16_t)stage;   // coalesced; positions < q0 + 64, all read already
                 if (lane == 0) atomicOr(const_cast<uint32_t *>(&mask[cu >> 5]), 1u << (cu & 31));
-                const uint32_t o = __builtin_amdgcn_readlane(off, ls[k]);
                 const int d = __builtin_amdgcn_readlane(deg, ls[k]);
-                for (int e0 = 0; e0 < d; e0 += 64) {
-                    uint16_t e;
-                    if (e0 == 0) e = pre0[k];
-                    else if (e0 == 64) e = pre1[k];
-                    else e = prm.adj[o + min(e0 + lane, d - 1)];
-                    if (e0 + lane < d) {
-                        const int v = e & 0x7FFF;
-                        if (e & kZTag) { if (!((mask[v >> 5] >> (v & 31)) & 1u)) bad = 1; }
-                        else atomicOr(const_cast<uint32_t *>(&mask[v >> 5]), 1u << (v & 31));
-                    }
+                if (has_z) {
+                    walk_apply_slice<true>(mask, pre0[k], lane < d, bad);
+                    if (d > 64) walk_apply_slice<true>(mask, pre1[k], lane + 64 < d, bad);
+                } else {
+                    walk_apply_slice<false>(mask, pre0[k], lane < d, bad);
+                    if (d > 64) walk_apply_slice<false>(mask, pre1[k], lane + 64 < d, bad);
+                }
+                if (d > 128) {   // rare: long lists
+                    const uint32_t o = __builtin_amdgcn_readlane(off, ls[k]);
+                    for (int e0 = 128; e0 < d; e0 += 64)
+                        walk_apply_slice<true>(mask, prm.adj[o + min(e0 + lane, d - 1)], e0 + lane < d, bad);
                 }
             }
         }
