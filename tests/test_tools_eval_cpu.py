@@ -1,0 +1,91 @@
+"""CPU-only: the 'next rows' of SURVEY 8f -- VID annotation tooling, array transport, AP evaluator."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import synth
+from vdetlib_amd import io as vio
+from vdetlib_amd import eval as vev
+from vdetlib_amd.tools import imagenet_annotation_processor as iap
+from vdetlib_amd.tools import gen_vid_proto_file as gvp
+from vdetlib_amd.utils import protocol as P
+
+XML = """<annotation><folder>v</folder><filename>{fn}</filename><source><database>ILSVRC_2015</database></source>
+<size><width>1280</width><height>720</height></size>{objs}</annotation>"""
+OBJ = """<object><trackid>{tid}</trackid><name>{wnid}</name><bndbox><xmax>{x2}</xmax><xmin>{x1}</xmin>
+<ymax>{y2}</ymax><ymin>{y1}</ymin></bndbox><occluded>{occ}</occluded><generated>0</generated></object>"""
+
+
+def test_annotation_processor(tmp_path):
+    d = tmp_path / 'ILSVRC2015_val_00000001'
+    d.mkdir()
+    for f in range(3):
+        objs = OBJ.format(tid=0, wnid='n02691156', x1=10 + f, y1=20, x2=110 + f, y2=140, occ=0)
+        if f >= 1:
+            objs += OBJ.format(tid=1, wnid='n02391049', x1=300, y1=200, x2=420, y2=330, occ=1)
+        (d / ('%06d.xml' % f)).write_text(XML.format(fn='%06d' % f, objs=objs))
+    (d / '000003.xml').write_text(XML.format(fn='000003', objs=''))       # a frame without objects
+    a = iap.annot_proto_from_dir(str(d))
+    assert a['video'] == 'ILSVRC2015_val_00000001' and [t['id'] for t in a['annotations']] == ['0', '1']
+    t0, t1 = a['annotations']
+    assert [b['frame'] for b in t0['track']] == [1, 2, 3] and [b['frame'] for b in t1['track']] == [2, 3]
+    assert t0['track'][2] == {'frame': 3, 'bbox': [12, 20, 112, 140], 'name': 'n02691156', 'class': 'airplane',
+                              'class_index': 1, 'generated': 0, 'occluded': 0, 'frame_size': [720, 1280]}
+    assert t1['track'][0]['class'] == 'zebra' and t1['track'][0]['class_index'] == 30 and t1['track'][0]['occluded'] == 1
+    assert len(iap.name_map) == 30 and iap.name_map['n02084071'] == (9, 'dog')
+    out = tmp_path / 'o' / 'a.annot'
+    assert iap.main([str(d), str(out)]) == 0 and json.load(open(out)) == a
+    assert iap.main([str(d), str(out)]) == 0                              # exists -> early exit
+    # the gt tracks feed the rest of the API
+    tp = P.track_proto_from_annot_proto(a)
+    assert tp['method'] == 'gt' and len(tp['tracks']) == 2
+
+
+def test_gen_vid_proto_cli(tmp_path):
+    d = tmp_path / 'frames'
+    d.mkdir()
+    for n in ('2.JPEG', '10.JPEG', '1.JPEG'):
+        (d / n).write_text('x')
+    out = tmp_path / 'p' / 'v.vid'
+    assert gvp.main(['myvid', str(d), str(out)]) == 0
+    v = P.proto_load(str(out))
+    assert v['video'] == 'myvid' and [f['path'] for f in v['frames']] == ['1.JPEG', '2.JPEG', '10.JPEG']
+
+
+def test_array_transport_roundtrip(tmp_path):
+    case = synth.proto_case()
+    vid, f2d = case['vid'], case['frame_to_det']
+    boxes, scores, counts = vio.arrays_from_frame_to_det(vid, f2d)
+    assert boxes.shape == (6, 40, 4) and scores.shape == (6, 40, 4) and counts.tolist() == [40, 40, 40, 0, 0, 40]
+    assert np.isneginf(scores[3]).all() and (boxes[3, :, 0] < -1e5).all()        # padded frames
+    back = vio.frame_to_det_from_arrays(vid, boxes, scores, counts)
+    assert sorted(back) == [1, 2, 3, 6]
+    for f in back:
+        assert np.array_equal(back[f][0], f2d[f][0].astype(np.float32)) and np.array_equal(back[f][1], f2d[f][1])
+    di = vio.det_info_from_arrays(vid, boxes, scores, counts)
+    assert di.shape == (160, 9) and di[0, 0] == 1 and di[-1, 0] == 6
+    vio.save_video_npz(str(tmp_path / 'v.npz'), boxes, scores, counts)
+    b2, s2, c2 = vio.load_video_npz(str(tmp_path / 'v.npz'))
+    assert np.array_equal(b2, boxes) and np.array_equal(s2, scores) and np.array_equal(c2, counts)
+    pads = vio.pad_boxes(5)
+    assert ((pads[:, 2] - pads[:, 0] + 1) == 1).all() and len(set(pads[:, 0])) == 5
+
+
+def test_average_precision_evaluator():
+    annot = {'video': 'v', 'annotations': [
+        {'id': '0', 'track': [{'frame': f, 'bbox': [10, 10, 60, 60], 'class_index': 1} for f in (1, 2)]},
+        {'id': '1', 'track': [{'frame': 1, 'bbox': [200, 200, 260, 280], 'class_index': 2}]}]}
+    gt = vev.ground_truth_from_annots([annot])
+    perfect = [('v', 1, 1, [10, 10, 60, 60], .9), ('v', 2, 1, [11, 10, 60, 60], .8), ('v', 1, 2, [200, 200, 260, 280], .7)]
+    aps, m = vev.evaluate(perfect, gt)
+    assert aps == {1: 1.0, 2: 1.0} and m == 1.0
+    # class 1: TP(.9), FP(.85, duplicate of the same gt), TP(.8): precision envelope 1, 2/3 -> AP = .5*1 + .5*(2/3)
+    dets = [('v', 1, 1, [10, 10, 60, 60], .9), ('v', 1, 1, [12, 10, 60, 60], .85), ('v', 2, 1, [11, 10, 60, 60], .8),
+            ('v', 1, 2, [0, 0, 5, 5], .99)]
+    aps, m = vev.evaluate(dets, gt)
+    assert abs(aps[1] - (0.5 + 0.5 * 2 / 3)) < 1e-12 and aps[2] == 0.0 and abs(m - (aps[1] / 2)) < 1e-12
+    assert np.isnan(vev.average_precision([], 0))
+    sp = {'video': 'v', 'tubelets': [{'class_index': 1, 'boxes': [{'frame': 1, 'bbox': [10, 10, 60, 60], 'det_score': .5}]}]}
+    assert vev.detections_from_score_protos([sp]) == [('v', 1, 1, [10, 10, 60, 60], .5)]
