@@ -59,6 +59,8 @@ def main():
     ap.add_argument("--link-thres", type=float, default=0.5)
     ap.add_argument("--pool-thres", type=float, default=0.7)
     ap.add_argument("--no-link", action="store_true", help="NMS + temporal only")
+    ap.add_argument("--separate", action="store_true", help="vdet_nms_volume + vdet_track_volume instead of the fused call")
+    ap.add_argument("--streams", type=int, default=4, help="videos in flight per GPU (one HIP stream + context each)")
     ap.add_argument("--cpu-problems", type=int, default=1200, help="(frame,class) problems timed on the CPU oracle")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -79,29 +81,48 @@ def main():
     boxes, scores = synth_video_cuda(torch, 2000 + rank, F, B, C, dev)
     ctx = _lib.get_context(local)
     gathered = None
-
-    ctx.set_cache(True)      # NMS and LINK of one step share the suppression graph and the sorted lists
+    # Consecutive videos are independent units of work: keep `--streams` of them in flight, each on its
+    # own HIP stream with its own context (scratch buffers), so the latency-bound LINK kernels of one
+    # video overlap the VALU-bound graph build / walk of the next.  All results of all K steps are
+    # complete before the timed region ends (fence() synchronises the device).
+    nstreams = max(1, args.streams)
+    ctxs = [ctx] + [_lib.Context(local) for _ in range(nstreams - 1)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
+    for cx in ctxs:
+        cx.set_cache(True)   # NMS and LINK of one step share the suppression graph and the sorted lists
+    step_no = [0]
 
     def step():
         nonlocal gathered
-        ctx.invalidate()     # a new video: nothing may be reused from the previous step
-        keep_idx, keep_cnt = ops.nms_volume(boxes, scores, args.thresh, cap=args.cap, sync=False)
-        pooled = ops.temporal_maxpool(scores, args.window)
-        tub = None
-        if not args.no_link:
-            tracks, anchors, ntracks = ops.track_volume(boxes, scores, nms_thres=args.thresh, thres=args.track_thres,
-                                                        max_tracks=args.max_tracks, link_thres=args.link_thres,
-                                                        sync=False)
-            det, tpool, tboxes = ops.rescore_tracks(tracks, ntracks, boxes, scores, overlap_thres=args.pool_thres,
-                                                    window=args.window, sync=False)
-            tub = (tracks, ntracks, tpool, tboxes)
-        if world > 1:   # the one exchange step: RCCL all-gather of the per-video results over xGMI
-            if tub is not None:
-                payload = torch.cat([tub[3].reshape(C, -1), tub[2].to(torch.float32).reshape(C, -1)], 1)
-                gathered = (vdist.all_gather_ragged(payload[None]), vdist.all_gather_ragged(keep_cnt[None]))
-            else:
-                top = keep_idx[:, :, :TOPK].contiguous()
-                gathered = vdist.gather_video_results([rank], top[None], torch.clamp(keep_cnt, max=TOPK)[None])
+        k = step_no[0] % nstreams
+        step_no[0] += 1
+        cx = ctxs[k]
+        with torch.cuda.stream(streams[k]):
+            cx.invalidate()     # a new video: nothing may be reused from the previous step
+            tub = None
+            if args.no_link:
+                keep_idx, keep_cnt = ops.nms_volume(boxes, scores, args.thresh, cap=args.cap, sync=False, ctx=cx)
+            elif args.separate:
+                keep_idx, keep_cnt = ops.nms_volume(boxes, scores, args.thresh, cap=args.cap, sync=False, ctx=cx)
+                tracks, anchors, ntracks = ops.track_volume(boxes, scores, nms_thres=args.thresh, thres=args.track_thres,
+                                                            max_tracks=args.max_tracks, link_thres=args.link_thres,
+                                                            sync=False, ctx=cx)
+            else:   # NMS survivors + tubelets from one call (one fused walk serves both greedy runs)
+                keep_idx, keep_cnt, tracks, anchors, ntracks = ops.nms_track_volume(
+                    boxes, scores, nms_thres=args.thresh, thres=args.track_thres, max_tracks=args.max_tracks,
+                    link_thres=args.link_thres, cap=args.cap, sync=False, ctx=cx)
+            pooled = ops.temporal_maxpool(scores, args.window, ctx=cx)
+            if not args.no_link:
+                det, tpool, tboxes = ops.rescore_tracks(tracks, ntracks, boxes, scores, overlap_thres=args.pool_thres,
+                                                        window=args.window, sync=False, ctx=cx)
+                tub = (tracks, ntracks, tpool, tboxes)
+            if world > 1:   # the one exchange step: RCCL all-gather of the per-video results over xGMI
+                if tub is not None:
+                    payload = torch.cat([tub[3].reshape(C, -1), tub[2].to(torch.float32).reshape(C, -1)], 1)
+                    gathered = (vdist.all_gather_ragged(payload[None]), vdist.all_gather_ragged(keep_cnt[None]))
+                else:
+                    top = keep_idx[:, :, :TOPK].contiguous()
+                    gathered = vdist.gather_video_results([rank], top[None], torch.clamp(keep_cnt, max=TOPK)[None])
         return keep_idx, keep_cnt, pooled, tub
 
     def fence():
@@ -109,16 +130,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, nstreams)):
         out = step()
-    ctx.sync()
+    fence()
+    for cx in ctxs:
+        cx.sync()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     fence()
     dt = time.perf_counter() - t0
-    ctx.sync()          # surfaces latched device-side failures (capacity / zero union)
+    for cx in ctxs:
+        cx.sync()       # surfaces latched device-side failures (capacity / zero union)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -129,10 +153,14 @@ def main():
     # ---- per-kernel timing (HIP events on the kernels' stream), outside the timed region
     result = None
     if rank == 0:
+        torch.cuda.synchronize()
+        step_no[0] = 0
         ctx.set_timing(2)
         reps = 3
         for _ in range(reps):
+            step_no[0] = 0          # per-kernel timing: one video at a time on stream 0
             step()
+            torch.cuda.synchronize()
         ctx.sync()
         agg = {k: [ms, n] for k, (ms, n) in ctx.last_timing().items()}
         ctx.set_timing(0)
@@ -212,7 +240,7 @@ def main():
                                     ">= %.2f, spatial max-pool IoU > %.2f + completion + temporal max-pool" %
                                     (args.max_tracks, args.track_thres, args.link_thres, args.pool_thres),
                                     "; RCCL all-gather of the final tubelets + kept counts" if world > 1 else ""),
-                       "frames": F, "boxes": B, "classes": C, "parallelism": "video-per-gpu x%d" % world},
+                       "frames": F, "boxes": B, "classes": C, "parallelism": "video-per-gpu x%d, %d videos in flight per GPU" % (world, nstreams)},
             "roofline": roofline, "cpu_baseline": cpu,
         }
     if world > 1:

@@ -81,7 +81,9 @@ int vdet_set_cache(vdet_ctx *ctx, int enable);
 int vdet_invalidate(vdet_ctx *ctx);
 /* Introspection: what = 0 -> 1 if the per-(frame,class) sort uses the returning-LDS-atomic rank
  * (selected by a hardware self-test at vdet_create), 0 if it uses the ballot match;
- * what = 1 -> number of compute units. */
+ * what = 1 -> number of compute units;
+ * what = 2 -> 1 if every frame of the last suppression-graph build was "regular" (finite boxes,
+ * positive width / height / area). */
 int vdet_query(vdet_ctx *ctx, int what);
 /* Per-stage HIP-event timing: 0 off (default), 1 on (events of the most recent call), 2 on and
  * accumulating over calls until vdet_last_timing_ms reads them. */
@@ -227,6 +229,21 @@ int vdet_temporal_conv_f32(vdet_ctx *ctx, const float *d_in, float *d_out, int64
 int vdet_track_volume(vdet_ctx *ctx, const float *d_boxes, const float *d_scores, int64_t F, int64_t B,
                       int64_t C, double nms_thres, double thres, int max_tracks, double link_thres,
                       int max_frames, float *d_tracks, float *d_anchors, int32_t *d_ntracks);
+
+/*
+ * vdet_track_volume that also returns the per-(frame, class) NMS survivors of vdet_nms_volume
+ * (layout FBC, no score threshold, capacity `cap`: d_keep_idx [F,C,cap] int32 in descending score
+ * order, d_keep_cnt [F,C]; VDET_ECAP latched like vdet_nms_volume) -- the detections
+ * apply_image_nms (vdet/image_det.py:117-123) keeps for every frame next to the tubelets
+ * greedily_track_from_raw_dets (vdet/track.py:189-252) builds from the same raw detections.
+ * One call because both consume the same per-(frame, class) sorted lists and the same suppression
+ * graph, which are built once.  Results are bit-identical to
+ * calling vdet_nms_volume and vdet_track_volume separately.  d_keep_cnt == NULL: no NMS output.
+ */
+int vdet_nms_track_volume(vdet_ctx *ctx, const float *d_boxes, const float *d_scores, int64_t F, int64_t B,
+                          int64_t C, double nms_thres, double thres, int max_tracks, double link_thres,
+                          int max_frames, float *d_tracks, float *d_anchors, int32_t *d_ntracks, int64_t cap,
+                          int32_t *d_keep_idx, int32_t *d_keep_cnt);
 
 /*
  * Re-scoring of the device tracks: raw_dets_spatial_max_pooling (vdet/tubelet_cls.py:493-535: for

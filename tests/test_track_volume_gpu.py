@@ -104,3 +104,83 @@ def test_rescore_tracks_vs_oracle(oracle):
                 assert np.array_equal(pooled[c, t].cpu().numpy()[frames], pool), (thr, c, t)
                 assert np.array_equal(ob[c, t].cpu().numpy()[frames], np.asarray(bx, dtype=np.float32)), (thr, c, t)
         assert failed == want_fail
+
+
+def _fused_case(seed, F, B, C, irregular=False):
+    boxes, scores = _coherent_video(seed, F, B, C, jitter=4)
+    if irregular:
+        boxes[F // 2, 3] = [10, 10, 9, 30]            # zero-width box: that frame is not "regular"
+        boxes[1, 5] = [np.inf, 0, np.inf, 4]
+    if irregular == 2:                                # regular and irregular frames alternate
+        for f in range(0, F, 2):
+            boxes[f, f] = [5, 5, 4, 9]
+    return boxes, scores
+
+
+@pytest.mark.parametrize("cfg", [dict(seed=31, F=9, B=400, C=6, max_tracks=3, thres=0.0, max_frames=0, cap=None, irr=False),
+                                 dict(seed=32, F=7, B=700, C=4, max_tracks=2, thres=0.9995, max_frames=3, cap=None, irr=False),
+                                 dict(seed=33, F=6, B=300, C=3, max_tracks=0, thres=0.0, max_frames=0, cap=None, irr=False),
+                                 dict(seed=34, F=8, B=350, C=4, max_tracks=3, thres=0.0, max_frames=0, cap=None, irr=True),
+                                 dict(seed=35, F=5, B=2600, C=2, max_tracks=2, thres=0.0, max_frames=0, cap=1500, irr=False),
+                                 dict(seed=36, F=10, B=300, C=5, max_tracks=4, thres=0.0, max_frames=0, cap=None, irr=2)])
+def test_nms_track_volume_equals_separate_calls(oracle, cfg):
+    """The combined call (shared graph + lists; lazy lists on regular frames, eager track_det_nms on
+    irregular ones) must be bit-identical to vdet_nms_volume + vdet_track_volume and to the oracle."""
+    import torch
+    from vdetlib_amd import ops
+    boxes, scores = _fused_case(cfg['seed'], cfg['F'], cfg['B'], cfg['C'], cfg['irr'])
+    if cfg['seed'] == 32:
+        scores[:, :, 1] *= 0.5                         # class 1 never reaches thres: NMS output only
+    tb, ts = torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda()
+    kw = dict(nms_thres=0.3, thres=cfg['thres'], max_tracks=cfg['max_tracks'], link_thres=0.5, max_frames=cfg['max_frames'])
+    ki, kc, tr, an, nt = ops.nms_track_volume(tb, ts, cap=cfg['cap'], **kw)
+    ki0, kc0 = ops.nms_volume(tb, ts, 0.3, cap=cfg['cap'])
+    assert torch.equal(kc, kc0)
+    assert torch.equal(ki, ki0)
+    if cfg['max_tracks'] > 0:
+        tr0, an0, nt0 = ops.track_volume(tb, ts, **kw)
+        assert torch.equal(nt, nt0)
+        assert torch.equal(an, an0)
+        assert np.array_equal(tr.cpu().numpy(), tr0.cpu().numpy(), equal_nan=True)
+    # and directly against the oracle
+    want_idx, want_cnt = oracle.nms_volume(boxes, scores, 0.3, cap=cfg['cap'])
+    assert np.array_equal(kc.cpu().numpy(), want_cnt)
+    assert np.array_equal(ki.cpu().numpy(), want_idx)
+    trn, ann, ntn = tr.cpu().numpy(), an.cpu().numpy(), nt.cpu().numpy()
+    for c in range(cfg['C']):
+        wt, wa, wn = oracle.greedy_track_volume(boxes, scores[:, :, c], 0.3, cfg['thres'], cfg['max_tracks'], 0.5,
+                                                cfg['max_frames'])
+        assert ntn[c] == wn, (c, ntn[c], wn)
+        assert np.array_equal(ann[c, :wn], wa[:wn]), c
+        assert np.array_equal(trn[c, :wn], wt[:wn], equal_nan=True), c
+
+
+def test_nms_track_volume_capacity_error():
+    import torch
+    from vdetlib_amd import ops
+    boxes, scores = _fused_case(41, 4, 900, 2)
+    with pytest.raises(Exception) as ei:
+        ops.nms_track_volume(torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda(), cap=8, max_tracks=2)
+    assert 'cap' in str(ei.value).lower()
+
+
+def test_eager_and_lazy_list_maintenance_agree(monkeypatch):
+    """A VDET_NO_LAZY context (eager track_det_nms of every crossed list) == the default (lazy lists)."""
+    import torch
+    from vdetlib_amd import ops, _lib
+    boxes, scores = _fused_case(51, 10, 500, 5)
+    tb, ts = torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda()
+    ref = ops.nms_track_volume(tb, ts, max_tracks=5, thres=0.3)
+    monkeypatch.setenv('VDET_NO_LAZY', '1')
+    cx = _lib.Context(torch.cuda.current_device())
+    got = ops.nms_track_volume(tb, ts, max_tracks=5, thres=0.3, ctx=cx)
+    for a, b in zip(ref, got):
+        assert np.array_equal(a.cpu().numpy(), b.cpu().numpy(), equal_nan=True)
+    # ties + many tracks: the lazy tie scan against the eager lists
+    scores2 = np.round(scores * 8) / 8
+    ts2 = torch.from_numpy(scores2.astype(np.float32)).cuda()
+    monkeypatch.delenv('VDET_NO_LAZY')
+    ref2 = ops.track_volume(tb, ts2, max_tracks=30, thres=0.0)
+    got2 = ops.track_volume(tb, ts2, max_tracks=30, thres=0.0, ctx=cx)
+    for a, b in zip(ref2, got2):
+        assert np.array_equal(a.cpu().numpy(), b.cpu().numpy(), equal_nan=True)

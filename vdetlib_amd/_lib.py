@@ -41,6 +41,8 @@ SYMBOLS = {
     "vdet_conv1d_f32": (_ci, [_vp, _vp, _ci, _ci, _vp, _vp, _ci, _ci, _ci, _vp]),
     "vdet_nms_volume": (_ci, [_vp, _vp, _vp, _ci, _i64, _i64, _i64, _f64, _ci, _f32, _vp, _vp, _i64]),
     "vdet_track_volume": (_ci, [_vp, _vp, _vp, _i64, _i64, _i64, _f64, _f64, _ci, _f64, _ci, _vp, _vp, _vp]),
+    "vdet_nms_track_volume": (_ci, [_vp, _vp, _vp, _i64, _i64, _i64, _f64, _f64, _ci, _f64, _ci, _vp, _vp, _vp,
+                                    _i64, _vp, _vp]),
     "vdet_rescore_tracks": (_ci, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _ci, _f64, _ci, _vp, _vp, _vp]),
     "vdet_temporal_maxpool_f32": (_ci, [_vp, _vp, _vp, _i64, _i64, _ci, _f32]),
     "vdet_temporal_conv_f32": (_ci, [_vp, _vp, _vp, _i64, _i64, _vp, _ci, _f32, _f32]),

@@ -264,7 +264,8 @@ __device__ __forceinline__ void xwindow(const FrameIndex &ix, int f, float x1c, 
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void frame_flags_kernel(const float4 *__restrict__ boxes,
                                                           const GroupDesc *__restrict__ groups,
-                                                          uint32_t *__restrict__ group_flags)
+                                                          uint32_t *__restrict__ group_flags,
+                                                          int *__restrict__ n_irregular)
 {
     const GroupDesc gd = groups[blockIdx.x];
     int bad = 0;
@@ -278,7 +279,10 @@ __global__ __launch_bounds__(256) void frame_flags_kernel(const float4 *__restri
         bad |= ok ? 0 : 1;
     }
     const int any_bad = __syncthreads_or(bad);
-    if (threadIdx.x == 0) group_flags[blockIdx.x] = any_bad ? 0u : kFlagRegular;
+    if (threadIdx.x == 0) {
+        group_flags[blockIdx.x] = any_bad ? 0u : kFlagRegular;
+        if (any_bad) atomicAdd(n_irregular, 1);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -474,8 +478,11 @@ __global__ __launch_bounds__(256) void adj_build_kernel(const float4 *__restrict
         zc = tr ? 0u : row_z[gd.box_off + v];
     }
     const uint32_t tot = deg + zc;
+    // every list starts at an even pool offset (slabs are sums of even sizes): the walks read two
+    // u16 entries with one 4-byte load
+    const uint32_t tot_al = (tot + 1u) & ~1u;
     // block exclusive scan (Hillis-Steele over 256 entries)
-    sscan[tid] = tot;
+    sscan[tid] = tot_al;
     __syncthreads();
     for (int d = 1; d < 256; d <<= 1) {
         const uint32_t t = (tid >= d) ? sscan[tid - d] : 0u;
@@ -494,7 +501,7 @@ __global__ __launch_bounds__(256) void adj_build_kernel(const float4 *__restrict
         return;
     }
     const bool staged = tile_total <= (uint32_t)kAdjStage;     // block-uniform
-    const uint32_t lofs = incl - tot;                           // my list's offset inside the tile slab
+    const uint32_t lofs = incl - tot_al;                        // my list's offset inside the tile slab
     if (v < B) {
         uint32_t p = (uint32_t)base + lofs;
         row_meta[gd.box_off + vo] = make_uint2(p, tot);

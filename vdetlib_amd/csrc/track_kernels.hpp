@@ -45,11 +45,63 @@ __device__ __forceinline__ bool at_or_before(uint32_t k, int flat, uint32_t ka, 
 // (score desc, flat index asc) == the stable descending sort of vdet/track.py:200.
 // keys: [F*C, B] sortable keys (transpose_keys_kernel);  lists: [F*C, B] u16;  cnt: [F*C].
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void track_pick_kernel(const uint32_t *__restrict__ keys,
-                                                         const uint16_t *__restrict__ lists,
+// Lazy lists (regular frames: finite boxes with positive areas, so no union can be zero and skipping
+// the evaluation of a pair can not hide a ZeroDivisionError).  The only thing ever read from a
+// (frame, class) list is its best live entry, at most once per track -- so track_det_nms
+// (utils/nms.pyx:128-189) is never materialised for these lists:
+//   * the first track that crosses the list (t1) defines round 1: entries overlapping its box are
+//     not part of the list any more;
+//   * round 2 (vid_nms of the rest) is a greedy walk in list order, evaluated only as far as needed:
+//     list[0 .. nkp) holds the kept prefix found so far (in place: nkp <= pos), list[pos .. n) is
+//     the unexamined tail; an entry is kept iff it does not overlap t1's box and no earlier kept
+//     entry suppresses it (pair_pred on the boxes == the suppression-graph edge);
+//   * later tracks only remove kept entries (the survivors of a vid_nms are an independent set, a
+//     second vid_nms keeps them all), and a removed entry still suppresses what it suppressed:
+//     the persistent head skips kept entries that overlap any track box of this class on this frame.
+struct LazyLists {
+    const float4 *boxes;            // [F*B]
+    const float *tracks;            // [C, max_tracks, F, 5]
+    const uint32_t *group_flags;    // per frame, or null (= never lazy)
+    int32_t *t1;                    // [F*C] 0: no track crossed the list yet, else first track + 1
+    int32_t *head, *nkp, *pos;      // [F*C]
+    float t32;
+};
+
+__device__ __forceinline__ bool lazy_dead(const LazyLists &lz, int f, int e, int F, int B, int c, int max_tracks, int nt)
+{
+    const float4 bd = lz.boxes[(int64_t)f * B + e];
+    const float darea = box_area(bd);
+    for (int t = 0; t < nt; ++t) {
+        const float *row = lz.tracks + (((int64_t)c * max_tracks + t) * F + f) * 5;
+        const float tx1 = row[0];
+        if (tx1 != tx1) continue;
+        const float4 tb = make_float4(tx1, row[1], row[2], row[3]);
+        if (pair_pred(bd, darea, tb, box_area(tb), lz.t32) & 1u) return true;      // the DET is the "i" box
+    }
+    return false;
+}
+
+// examine list[pos]: true if it joins the kept prefix
+__device__ __forceinline__ bool lazy_examine(const LazyLists &lz, uint16_t *l, int f, int B, float4 t1b, float t1area,
+                                             int &np, int &ps)
+{
+    const int e = l[ps++];
+    const float4 bd = lz.boxes[(int64_t)f * B + e];
+    const float darea = box_area(bd);
+    if (pair_pred(bd, darea, t1b, t1area, lz.t32) & 1u) return false;              // round 1
+    for (int i = 0; i < np; ++i) {
+        const float4 bk = lz.boxes[(int64_t)f * B + l[i]];
+        if (pair_pred(bk, box_area(bk), bd, darea, lz.t32) & 1u) return false;     // round 2: kept box "i", candidate "j"
+    }
+    l[np++] = (uint16_t)e;
+    return true;
+}
+
+__global__ __launch_bounds__(256) void track_pick_kernel(const uint32_t *__restrict__ keys, uint16_t *lists,
                                                          const int32_t *__restrict__ cnt, int F, int B, int C,
                                                          const float *__restrict__ scores, double thres, int max_tracks,
-                                                         TrackState *__restrict__ st, float *__restrict__ anchors)
+                                                         TrackState *__restrict__ st, float *__restrict__ anchors,
+                                                         const LazyLists lz)
 {
     __shared__ uint32_t sk[256];
     __shared__ int sf[256];
@@ -61,19 +113,69 @@ __global__ __launch_bounds__(256) void track_pick_kernel(const uint32_t *__restr
     for (int f = tid; f < F; f += 256) {
         const int p = f * C + c;
         const int n = cnt[p];
-        const uint16_t *l = lists + (int64_t)p * B;
+        uint16_t *l = lists + (int64_t)p * B;
         const uint32_t *kk = keys + (int64_t)p * B;
-        // skip entries at/before the cursor (only the previous anchor itself can be there)
-        int q = 0;
-        while (q < n && at_or_before(kk[l[q]], f * B + l[q], s.last_key, s.last_flat)) ++q;
-        if (q >= n) continue;
-        // ties inside the frame are listed by DESCENDING index; the global rule wants the lowest
-        uint32_t k0 = kk[l[q]];
-        int best = l[q];
-        for (int r = q + 1; r < n && kk[l[r]] == k0; ++r)
-            if (!at_or_before(k0, f * B + l[r], s.last_key, s.last_flat)) best = l[r];
-        const int flat = f * B + best;
-        if (bflat < 0 || k0 > bk || (k0 == bk && flat < bflat)) { bk = k0; bflat = flat; }
+        int t1 = 0;
+        if (lz.group_flags && (lz.group_flags[f] & kFlagRegular)) {
+            t1 = lz.t1[p];
+            if (t1 == 0 && s.ntracks > 0) {    // did the newest track cross this list?  (older ones were checked before)
+                const float r0 = lz.tracks[(((int64_t)c * max_tracks + (s.ntracks - 1)) * F + f) * 5];
+                if (r0 == r0) { t1 = s.ntracks; lz.t1[p] = t1; }
+            }
+        }
+        if (t1 == 0) {
+            // full list (or an eagerly compacted one): skip entries at/before the cursor (only the
+            // previous anchor itself can be there)
+            int q = 0;
+            while (q < n && at_or_before(kk[l[q]], f * B + l[q], s.last_key, s.last_flat)) ++q;
+            if (q >= n) continue;
+            // ties inside the frame are listed by DESCENDING index; the global rule wants the lowest
+            const uint32_t k0 = kk[l[q]];
+            int best = l[q];
+            for (int r = q + 1; r < n && kk[l[r]] == k0; ++r)
+                if (!at_or_before(k0, f * B + l[r], s.last_key, s.last_flat)) best = l[r];
+            const int flat = f * B + best;
+            if (bflat < 0 || k0 > bk || (k0 == bk && flat < bflat)) { bk = k0; bflat = flat; }
+            continue;
+        }
+        const float *row1 = lz.tracks + (((int64_t)c * max_tracks + (t1 - 1)) * F + f) * 5;
+        const float4 t1b = make_float4(row1[0], row1[1], row1[2], row1[3]);
+        const float t1area = box_area(t1b);
+        int h = lz.head[p], np = lz.nkp[p], ps = lz.pos[p];
+        int found = -1;
+        for (;;) {
+            if (h >= np) {                      // extend the kept prefix by one entry
+                bool got = false;
+                while (ps < n && !got) got = lazy_examine(lz, l, f, B, t1b, t1area, np, ps);
+                if (!got) break;                // list exhausted
+            }
+            const int e = l[h];
+            if (at_or_before(kk[e], f * B + e, s.last_key, s.last_flat) ||
+                lazy_dead(lz, f, e, F, B, c, max_tracks, s.ntracks)) { ++h; continue; }   // gone for good
+            found = e;
+            break;
+        }
+        if (found >= 0) {
+            // ties: later kept entries with the same key (descending index), the lowest live one wins
+            const uint32_t k0 = kk[found];
+            int best = found;
+            int r = h + 1;
+            for (;;) {
+                if (r >= np) {
+                    if (ps >= n || kk[l[ps]] != k0) break;
+                    lazy_examine(lz, l, f, B, t1b, t1area, np, ps);
+                    continue;
+                }
+                const int e = l[r];
+                if (kk[e] != k0) break;
+                if (!at_or_before(k0, f * B + e, s.last_key, s.last_flat) &&
+                    !lazy_dead(lz, f, e, F, B, c, max_tracks, s.ntracks)) best = e;
+                ++r;
+            }
+            const int flat = f * B + best;
+            if (bflat < 0 || k0 > bk || (k0 == bk && flat < bflat)) { bk = k0; bflat = flat; }
+        }
+        lz.head[p] = h; lz.nkp[p] = np; lz.pos[p] = ps;
     }
     sk[tid] = bk;
     sf[tid] = bflat;
@@ -192,6 +294,16 @@ __global__ __launch_bounds__(LT) void track_link_kernel(const float4 *__restrict
         const bool fast = group_flags && (group_flags[f] & kFlagRegular) && link_t32 > 1e-30f &&
                           carea > 0.0f && carea < __uint_as_float(0x7F800000u);
         const float t32e = link_t32 * 4.76837158203125e-7f;
+        // prefetch the bucket table of the next frame (whatever path this step takes): the loads are
+        // issued here, together with the box loads below, and stored to the other parity slot only
+        // after the boxes were processed (the slot is read after this step's barrier; it was last
+        // read one full step ago)
+        uint32_t pf0 = 0u, pf1 = 0u;
+        if (use_ix) {
+            const int f2 = min(max(f + dir, 0), F - 1);
+            pf0 = ix.cum[(int64_t)f2 * 257 + tid];
+            pf1 = tid == 0 ? ix.cum[(int64_t)f2 * 257 + 256] : __float_as_uint(ix.info[f2 * 4 + min(tid - 1, 2)]);
+        }
         if (fast && use_ix) {
             // indexed frame: only the x-window that can reach IoU >= link_thres is read
             int r0, r1;
@@ -204,13 +316,6 @@ __global__ __launch_bounds__(LT) void track_link_kernel(const float4 *__restrict
                 r0 = (int)scum[par][xbucket((float)fmax(lo, -3.0e38), xmin, scale)];
                 r1 = (int)scum[par][xbucket((float)fmin(hi, 3.0e38), xmin, scale) + 1];
             }
-            // prefetch the table of the next frame: the loads are issued here, together with the box
-            // loads below, and stored to the other parity slot only after the boxes were processed
-            // (the slot is read after this step's barrier; it was last read one full step ago)
-            const int f2 = min(max(f + dir, 0), F - 1);
-            const uint32_t pf0 = ix.cum[(int64_t)f2 * 257 + tid];
-            const uint32_t pf1 = tid == 0 ? ix.cum[(int64_t)f2 * 257 + 256]
-                                          : __float_as_uint(ix.info[f2 * 4 + min(tid - 1, 2)]);
             const float4 *xb = ix.xbox + (int64_t)f * B;
             const uint16_t *xo = ix.xord + (int64_t)f * B;
             // batches of WB boxes per thread: all WB loads are issued before the first use (a load
@@ -234,8 +339,6 @@ __global__ __launch_bounds__(LT) void track_link_kernel(const float4 *__restrict
                     }
                 }
             }
-            scum[par ^ 1][tid] = pf0;                           // LT == 256: entries 0..255
-            if (tid < 4) scum[par ^ 1][tid == 0 ? 256 : 256 + tid] = pf1;   // 256, then xmin/scale/wmax
         } else if (use_ix) {
             // irregular frame while an index exists: plain scan, no prefetch
             for (int b = tid; b < B; b += LT) {
@@ -265,6 +368,10 @@ __global__ __launch_bounds__(LT) void track_link_kernel(const float4 *__restrict
                 const float v = link_iou(cur, carea, x);
                 if (v > bv) { bv = v; bi = b; bb = x; }
             }
+        if (use_ix) {
+            scum[par ^ 1][tid] = pf0;                           // LT == 256: entries 0..255
+            if (tid < 4) scum[par ^ 1][tid == 0 ? 256 : 256 + tid] = pf1;   // 256, then xmin/scale/wmax
+        }
         const int my_bi = bi;
         if (!use_ix) {   // prefetch frame f + dir
             const int f2 = f + dir;
@@ -320,6 +427,7 @@ struct SuppressParams {
     float t32;
     int *status;
     int mask_words;
+    int lazy;                      // 1: the lists of regular frames are maintained by the pick
 };
 
 __global__ __launch_bounds__(256) void track_suppress_kernel(const SuppressParams prm)
@@ -344,6 +452,8 @@ __global__ __launch_bounds__(256) void track_suppress_kernel(const SuppressParam
     const bool has_z = prm.group_z[f] != 0;
 
     const bool seen = prm.visited[p] != 0;
+    // lists of regular frames are maintained lazily by track_pick_kernel (see LazyLists)
+    if (prm.lazy && !has_z && prm.group_flags && (prm.group_flags[f] & kFlagRegular)) return;
     int nk = 0, bad = 0;
     if (seen) {
         // The list already went through round 2 once: it is an independent set of the frame's

@@ -58,7 +58,7 @@ struct Counters {            // one small device block
     unsigned int glob_cnt;
     unsigned long long pool_used;
     int eindex;              // latched "IndexError" of the rescoring kernels
-    int pad;
+    int irregular;           // frames that are not "regular" (frame_flags_kernel), counted per graph build
 };
 
 }  // namespace
@@ -75,7 +75,7 @@ struct vdet_ctx {
     int n_cu = 256;
     // scratch
     DevBuf boxes, scores, keys, excl, frames, groups, tiles, bits, rowz, rowmeta, groupz, adj, comp, origidx,
-        out64, trk_frames, trk_boxes, b1, b2, iou_out, order, ncand, keepidx, keepcnt, gflags, pairs, tkeys, tstate, visited, xkeys, xord, xncand, xbox, xcum, xinfo, tmp[8];
+        out64, trk_frames, trk_boxes, b1, b2, iou_out, order, ncand, keepidx, keepcnt, gflags, pairs, tkeys, tstate, visited, heads, xkeys, xord, xncand, xbox, xcum, xinfo, tmp[8];
     // timing
     bool timing = false;
     bool timing_accumulate = false;   // vdet_set_timing(ctx, 2): keep events across calls until read
@@ -90,6 +90,9 @@ struct vdet_ctx {
     struct PrepKey { const void *boxes = nullptr, *scores = nullptr; int64_t F = 0, B = 0, C = 0; float t32 = 0; int layout = -1, use_thr = 0; float thr = 0; } prep;
     bool graph_valid = false, lists_valid = false;
     bool index_valid = false; const void *index_boxes = nullptr; int64_t index_F = 0, index_B = 0;
+    bool all_regular = false;     // last graph build: every frame regular
+    bool debug_sync = false;      // VDET_DEBUG_SYNC=1: synchronise + report after every tracking kernel
+    bool no_lazy = false;         // VDET_NO_LAZY=1: eager track_det_nms of every crossed list (tests / A-B)
     bool no_index = false;        // VDET_NO_INDEX=1: disable the x-sorted proposal index (tests / A-B)
     const std::vector<GroupDesc> *host_groups = nullptr;   // group table of the call in flight (mode 2)
     bool atomic_rank = false;     // LDS returning atomics serve same-address lanes in lane order (probed)
@@ -295,7 +298,7 @@ int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32, doub
             {
                 StageTimer tm(c, ST_OTHER);
                 hipLaunchKernelGGL(frame_flags_kernel, dim3((unsigned)G), dim3(256), 0, c->stream, d_boxes,
-                                   c->groups.as<GroupDesc>(), c->gflags.as<uint32_t>());
+                                   c->groups.as<GroupDesc>(), c->gflags.as<uint32_t>(), &c->d_cnt->irregular);
             }
             const int rci = build_frame_index(c, d_boxes, pl.ntot, (int64_t)G, pl.nmax);
             if (rci) return rci;
@@ -341,6 +344,7 @@ int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32, doub
         Counters h;
         HIPCHK(c, hipMemcpyAsync(&h, c->d_cnt, sizeof h, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->all_regular = use_sym && h.irregular == 0;
         if (!(h.status & kStPool)) return VDET_OK;
         if (h.pool_used > 0xFFFFFFFFull) return fail(c, VDET_ENOMEM, "suppression graph has more than 2^32 edges");
         if (attempt == 1) break;
@@ -638,6 +642,8 @@ int vdet_create(vdet_ctx **out, int device)
     (void)hipMemsetAsync(c->d_cnt, 0, sizeof(Counters), c->stream);
     if (const char *e = getenv("VDET_NO_TRANSPOSE")) c->no_transpose = atoi(e) != 0;
     if (const char *e = getenv("VDET_NO_INDEX")) c->no_index = atoi(e) != 0;
+    if (const char *e = getenv("VDET_NO_LAZY")) c->no_lazy = atoi(e) != 0;
+    if (const char *e = getenv("VDET_DEBUG_SYNC")) c->debug_sync = atoi(e) != 0;
     {   // probe: do returning LDS atomics resolve same-address lanes in ascending lane order?
         const int npat = 4096;
         std::vector<uint8_t> pats((size_t)npat * 64);
@@ -681,7 +687,7 @@ int vdet_destroy(vdet_ctx *c)
     DevBuf *bufs[] = {&c->boxes, &c->scores, &c->keys, &c->excl, &c->frames, &c->groups, &c->tiles, &c->bits,
                       &c->rowz, &c->rowmeta, &c->groupz, &c->adj, &c->comp, &c->origidx, &c->out64,
                       &c->trk_frames, &c->trk_boxes, &c->b1, &c->b2, &c->iou_out, &c->order, &c->ncand, &c->keepidx,
-                      &c->keepcnt, &c->gflags, &c->pairs, &c->tkeys, &c->tstate, &c->visited, &c->xkeys, &c->xord, &c->xncand,
+                      &c->keepcnt, &c->gflags, &c->pairs, &c->tkeys, &c->tstate, &c->visited, &c->heads, &c->xkeys, &c->xord, &c->xncand,
                       &c->xbox, &c->xcum, &c->xinfo};
     for (DevBuf *b : bufs) b->release();
     for (DevBuf &b : c->tmp) b.release();
@@ -728,6 +734,7 @@ int vdet_query(vdet_ctx *c, int what)
     if (!c) return VDET_EINVAL;
     if (what == 0) return c->atomic_rank ? 1 : 0;
     if (what == 1) return c->n_cu;
+    if (what == 2) return c->all_regular ? 1 : 0;
     return VDET_EINVAL;
 }
 
@@ -981,7 +988,18 @@ int vdet_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scores, 
                       double nms_thres, double thres, int max_tracks, double link_thres, int max_frames,
                       float *d_tracks, float *d_anchors, int32_t *d_ntracks)
 {
+    return vdet_nms_track_volume(c, d_boxes, d_scores, F, B, C, nms_thres, thres, max_tracks, link_thres, max_frames,
+                                 d_tracks, d_anchors, d_ntracks, 0, nullptr, nullptr);
+}
+
+int vdet_nms_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scores, int64_t F, int64_t B, int64_t C,
+                          double nms_thres, double thres, int max_tracks, double link_thres, int max_frames,
+                          float *d_tracks, float *d_anchors, int32_t *d_ntracks, int64_t cap, int32_t *d_keep_idx,
+                          int32_t *d_keep_cnt)
+{
     if (!c) return VDET_EINVAL;
+    const bool want_nms = d_keep_cnt != nullptr;
+    if (want_nms && (cap < 0 || (cap > 0 && !d_keep_idx))) return fail(c, VDET_EINVAL, "null output");
     if (F <= 0 || B <= 0 || C <= 0 || max_tracks < 0) return fail(c, VDET_EINVAL, "bad shape");
     if (!d_boxes || !d_scores || !d_ntracks || (max_tracks > 0 && (!d_tracks || !d_anchors)))
         return fail(c, VDET_EINVAL, "null buffer");
@@ -1019,6 +1037,16 @@ int vdet_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scores, 
         c->no_transpose = saved;
         if (rc) return rc;
     }
+    const bool regular_ok = t32 > 1e-30f && t32 < INFINITY && !c->force_general;
+    if (want_nms) {                  // the NMS survivors: one walk over the lists, before they are consumed
+        SortWalkArgs a{};
+        a.walk_only = true;
+        a.mode = 0; a.P = (int)(F * C); a.B = (int)B; a.C = (int)C;
+        a.scores = d_scores;
+        a.keep_idx = d_keep_idx; a.keep_cnt = d_keep_cnt; a.cap = cap;
+        rc = launch_sort_walk(c, a, (int)B, F * C * B);
+        if (rc) return rc;
+    }
     c->lists_valid = false;          // the lists are consumed (compacted in place) below
     HIPCHK(c, c->tstate.reserve((size_t)C * sizeof(TrackState)));
     TrackState *st = c->tstate.as<TrackState>();
@@ -1033,7 +1061,7 @@ int vdet_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scores, 
     sp.row_meta = c->rowmeta.as<uint2>();
     sp.adj = c->adj.as<uint16_t>();
     sp.group_z = c->groupz.as<uint32_t>();
-    sp.group_flags = (t32 > 1e-30f && t32 < INFINITY && !c->force_general) ? c->gflags.as<uint32_t>() : nullptr;
+    sp.group_flags = regular_ok ? c->gflags.as<uint32_t>() : nullptr;
     sp.ix = FrameIndex{nullptr, nullptr, nullptr, nullptr};
     if (sp.group_flags && c->index_valid && !c->no_index) sp.ix = frame_index_of(c);   // built by build_graph
     sp.thres = nms_thres;
@@ -1047,25 +1075,38 @@ int vdet_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scores, 
     sp.t32 = t32;
     sp.status = &c->d_cnt->status;
     sp.mask_words = (int)((((size_t)4 * ((B + 31) / 32) + 15) & ~(size_t)15) / 4);
+    sp.lazy = c->no_lazy ? 0 : 1;
+    // lazy-list state of track_pick_kernel: t1 | head | nkp | pos, [F*C] int32 each
+    HIPCHK(c, c->heads.reserve((size_t)(F * C) * 16));
+    HIPCHK(c, hipMemsetAsync(c->heads.p, 0, (size_t)(F * C) * 16, c->stream));
+    LazyLists lz{};
+    lz.boxes = sp.boxes; lz.tracks = d_tracks; lz.t32 = t32;
+    lz.t1 = c->heads.as<int32_t>(); lz.head = lz.t1 + F * C; lz.nkp = lz.head + F * C; lz.pos = lz.nkp + F * C;
+    lz.group_flags = sp.lazy ? sp.group_flags : nullptr;
+    // the eager track_det_nms kernel is only needed for the lists the pick does not maintain
+    const bool need_suppress = !sp.lazy || !sp.group_flags || !c->all_regular;
     const float link_t32 = thresh_to_f32(link_thres);
     for (int t = 0; t < max_tracks; ++t) {
         {
             StageTimer tm(c, ST_TPICK);
             hipLaunchKernelGGL(track_pick_kernel, dim3((unsigned)C), dim3(256), 0, c->stream, c->tkeys.as<uint32_t>(),
                                c->order.as<uint16_t>(), c->ncand.as<int32_t>(), (int)F, (int)B, (int)C, d_scores, thres,
-                               max_tracks, st, d_anchors);
+                               max_tracks, st, d_anchors, lz);
         }
+        if (c->debug_sync) { fprintf(stderr, "[vdet] iter %d pick...\n", t); HIPCHK(c, hipStreamSynchronize(c->stream)); fprintf(stderr, "[vdet] iter %d pick ok\n", t); }
         {
             StageTimer tm(c, ST_TLINK);
             hipLaunchKernelGGL(track_link_kernel, dim3((unsigned)C, 2), dim3(LT), 0, c->stream,
                                reinterpret_cast<const float4 *>(d_boxes), (int)F, (int)B, max_tracks, link_t32, reach, st,
                                d_tracks, sp.group_flags, sp.ix, link_thres);
         }
-        {
+        if (c->debug_sync) { fprintf(stderr, "[vdet] iter %d link...\n", t); HIPCHK(c, hipStreamSynchronize(c->stream)); fprintf(stderr, "[vdet] iter %d link ok\n", t); }
+        if (need_suppress) {
             StageTimer tm(c, ST_TSUPP);
             hipLaunchKernelGGL(track_suppress_kernel, dim3((unsigned)((F * C + 3) / 4)), dim3(256),
                                (size_t)sp.mask_words * 16, c->stream, sp);
         }
+        if (c->debug_sync) { fprintf(stderr, "[vdet] iter %d suppress...\n", t); HIPCHK(c, hipStreamSynchronize(c->stream)); fprintf(stderr, "[vdet] iter %d suppress ok\n", t); }
         hipLaunchKernelGGL(track_commit_kernel, dim3(cg), dim3(64), 0, c->stream, st, (int)C, d_ntracks);
     }
     HIPCHK(c, hipGetLastError());
@@ -1102,7 +1143,8 @@ int vdet_rescore_tracks(vdet_ctx *c, const float *d_tracks, const int32_t *d_ntr
             HIPCHK(c, hipMemcpyAsync(c->groups.p, g.data(), (size_t)F * sizeof(GroupDesc), hipMemcpyHostToDevice, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
             hipLaunchKernelGGL(frame_flags_kernel, dim3((unsigned)F), dim3(256), 0, c->stream,
-                               reinterpret_cast<const float4 *>(d_boxes), c->groups.as<GroupDesc>(), c->gflags.as<uint32_t>());
+                               reinterpret_cast<const float4 *>(d_boxes), c->groups.as<GroupDesc>(), c->gflags.as<uint32_t>(),
+                               &c->d_cnt->irregular);
             const int rc = build_frame_index(c, reinterpret_cast<const float4 *>(d_boxes), F * B, F, (int)B);
             if (rc) return rc;
         }

@@ -13,15 +13,19 @@ import torch
 from . import _lib
 
 
-def _ctx_for(t):
+def _ctx_for(t, ctx=None):
+    """The context to run on: the process-wide one of the tensor's device, or an explicit ``ctx``
+    (one context per concurrently used HIP stream: a context owns its scratch buffers).  Either way
+    the work is enqueued on torch's CURRENT stream."""
     if not t.is_cuda:
         raise ValueError("expected a CUDA/HIP tensor (vdetlib_amd has no CPU path)")
-    ctx = _lib.get_context(t.device.index if t.device.index is not None else torch.cuda.current_device())
+    if ctx is None:
+        ctx = _lib.get_context(t.device.index if t.device.index is not None else torch.cuda.current_device())
     ctx.set_stream(torch.cuda.current_stream(t.device).cuda_stream)
     return ctx
 
 
-def nms_volume(boxes, scores, thresh=0.3, score_thresh=None, cap=None, layout="FBC", sync=True):
+def nms_volume(boxes, scores, thresh=0.3, score_thresh=None, cap=None, layout="FBC", sync=True, ctx=None):
     """Per-(frame, class) greedy NMS of a whole video (vdet/image_det.py:117-123 applied to every
     frame and class of vdet/video_det.py:89-99; == utils/nms.pyx vid_nms per class).
 
@@ -49,7 +53,7 @@ def nms_volume(boxes, scores, thresh=0.3, score_thresh=None, cap=None, layout="F
     if boxes.shape[2] != 4:
         raise ValueError("boxes must be [F,B,4]")
     cap = B if cap is None else int(cap)
-    ctx = _ctx_for(boxes)
+    ctx = _ctx_for(boxes, ctx)
     keep_idx = torch.full((F, C, cap), -1, dtype=torch.int32, device=boxes.device)
     keep_cnt = torch.zeros((F, C), dtype=torch.int32, device=boxes.device)
     ctx.check(ctx.lib.vdet_nms_volume(ctx.h, boxes.data_ptr(), scores.data_ptr(), lay, F, B, C, float(thresh),
@@ -61,7 +65,7 @@ def nms_volume(boxes, scores, thresh=0.3, score_thresh=None, cap=None, layout="F
     return keep_idx, keep_cnt
 
 
-def temporal_maxpool(vol, window, pad=-1e5):
+def temporal_maxpool(vol, window, pad=-1e5, ctx=None):
     """Centred sliding max along axis 0 (array form of score_proto_temporal_maxpool,
     vdet/tubelet_cls.py:386-414; pad value :402).  vol: f32 [F, ...]."""
     if window % 2 != 1:
@@ -74,12 +78,12 @@ def temporal_maxpool(vol, window, pad=-1e5):
     out = torch.empty_like(vol)
     F = vol.shape[0]
     S = vol.numel() // F if F else 0
-    ctx = _ctx_for(vol)
+    ctx = _ctx_for(vol, ctx)
     ctx.check(ctx.lib.vdet_temporal_maxpool_f32(ctx.h, vol.data_ptr(), out.data_ptr(), F, S, int(window), float(pad)))
     return out
 
 
-def temporal_conv(vol, taps, bias=0.0, pad=0.0):
+def temporal_conv(vol, taps, bias=0.0, pad=0.0, ctx=None):
     """Single-channel temporal convolution along axis 0 (build-defined stand-in for the external
     TCN of score_conv_cls, vdet/tubelet_cls.py:15-51): out[f] = bias + sum_k taps[k]*in[f+k-K/2]."""
     if vol.dtype != torch.float32:
@@ -89,7 +93,7 @@ def temporal_conv(vol, taps, bias=0.0, pad=0.0):
     out = torch.empty_like(vol)
     F = vol.shape[0]
     S = vol.numel() // F if F else 0
-    ctx = _ctx_for(vol)
+    ctx = _ctx_for(vol, ctx)
     ctx.check(ctx.lib.vdet_temporal_conv_f32(ctx.h, vol.data_ptr(), out.data_ptr(), F, S, t.ctypes.data,
                                              t.shape[0], float(bias), float(pad)))
     return out
@@ -112,7 +116,8 @@ def iou(boxes1, boxes2):
     return out
 
 
-def track_volume(boxes, scores, nms_thres=0.3, thres=0.0, max_tracks=10, link_thres=0.5, max_frames=0, sync=True):
+def track_volume(boxes, scores, nms_thres=0.3, thres=0.0, max_tracks=10, link_thres=0.5, max_frames=0, sync=True,
+                 ctx=None):
     """Greedy tubelet generation for EVERY class of a video on the GPU: the array form of
     greedily_track_from_raw_dets (vdet/track.py:189-252) with the built-in IoU-linking tracker as
     ``track_method`` (the reference's trackers are external MATLAB code).
@@ -127,7 +132,7 @@ def track_volume(boxes, scores, nms_thres=0.3, thres=0.0, max_tracks=10, link_th
     F, B, C = scores.shape
     if tuple(boxes.shape) != (F, B, 4):
         raise ValueError("boxes must be [F,B,4]")
-    ctx = _ctx_for(boxes)
+    ctx = _ctx_for(boxes, ctx)
     tracks = torch.full((C, max_tracks, F, 5), float('nan'), dtype=torch.float32, device=boxes.device)
     anchors = torch.zeros((C, max_tracks, 3), dtype=torch.float32, device=boxes.device)
     ntracks = torch.zeros((C,), dtype=torch.int32, device=boxes.device)
@@ -137,6 +142,36 @@ def track_volume(boxes, scores, nms_thres=0.3, thres=0.0, max_tracks=10, link_th
     if sync:
         ctx.sync()
     return tracks, anchors, ntracks
+
+
+def nms_track_volume(boxes, scores, nms_thres=0.3, thres=0.0, max_tracks=10, link_thres=0.5, max_frames=0, cap=None,
+                     sync=True, ctx=None):
+    """``nms_volume`` (layout 'FBC', no score threshold) and ``track_volume`` of the same video in one
+    call: both are greedy walks over the same sorted lists and suppression graph, and on regular
+    videos one fused walk serves both (include/vdet_hip.h: vdet_nms_track_volume).  Results are
+    bit-identical to the two separate calls.
+    Returns (keep_idx, keep_cnt, tracks, anchors, ntracks)."""
+    if boxes.dtype != torch.float32 or scores.dtype != torch.float32:
+        raise ValueError("Buffer dtype mismatch, expected 'float32_t'")
+    boxes = boxes.contiguous()
+    scores = scores.contiguous()
+    F, B, C = scores.shape
+    if tuple(boxes.shape) != (F, B, 4):
+        raise ValueError("boxes must be [F,B,4]")
+    cap = B if cap is None else int(cap)
+    ctx = _ctx_for(boxes, ctx)
+    keep_idx = torch.full((F, C, cap), -1, dtype=torch.int32, device=boxes.device)
+    keep_cnt = torch.zeros((F, C), dtype=torch.int32, device=boxes.device)
+    tracks = torch.full((C, max_tracks, F, 5), float('nan'), dtype=torch.float32, device=boxes.device)
+    anchors = torch.zeros((C, max_tracks, 3), dtype=torch.float32, device=boxes.device)
+    ntracks = torch.zeros((C,), dtype=torch.int32, device=boxes.device)
+    ctx.check(ctx.lib.vdet_nms_track_volume(ctx.h, boxes.data_ptr(), scores.data_ptr(), F, B, C, float(nms_thres),
+                                            float(thres), int(max_tracks), float(link_thres), int(max_frames),
+                                            tracks.data_ptr(), anchors.data_ptr(), ntracks.data_ptr(), cap,
+                                            keep_idx.data_ptr(), keep_cnt.data_ptr()))
+    if sync:
+        ctx.sync()
+    return keep_idx, keep_cnt, tracks, anchors, ntracks
 
 
 def tracks_to_proto(video_name, tracks, anchors, ntracks, method='iou_link_tracker'):
@@ -159,7 +194,7 @@ def tracks_to_proto(video_name, tracks, anchors, ntracks, method='iou_link_track
     return {'video': video_name, 'method': method, 'tracks': out}
 
 
-def rescore_tracks(tracks, ntracks, boxes, scores, overlap_thres=0.7, window=3, sync=True):
+def rescore_tracks(tracks, ntracks, boxes, scores, overlap_thres=0.7, window=3, sync=True, ctx=None):
     """Re-score device tracks: spatial max-pooling of the detection scores onto the tubelet boxes
     (raw_dets_spatial_max_pooling, vdet/tubelet_cls.py:493-535 -- also replaces each box by the
     best-scoring overlapping detection), gap completion (:284-303) and temporal max-pooling
@@ -168,7 +203,7 @@ def rescore_tracks(tracks, ntracks, boxes, scores, overlap_thres=0.7, window=3, 
         raise ValueError('Window size must be odd!')
     C, T, F = tracks.shape[0], tracks.shape[1], tracks.shape[2]
     B = boxes.shape[1]
-    ctx = _ctx_for(boxes)
+    ctx = _ctx_for(boxes, ctx)
     det = torch.empty((C, T, F), dtype=torch.float64, device=boxes.device)
     pooled = torch.empty((C, T, F), dtype=torch.float64, device=boxes.device)
     ob = torch.empty((C, T, F, 4), dtype=torch.float32, device=boxes.device)
