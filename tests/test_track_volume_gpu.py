@@ -184,3 +184,42 @@ def test_eager_and_lazy_list_maintenance_agree(monkeypatch):
     got2 = ops.track_volume(tb, ts2, max_tracks=30, thres=0.0, ctx=cx)
     for a, b in zip(ref2, got2):
         assert np.array_equal(a.cpu().numpy(), b.cpu().numpy(), equal_nan=True)
+
+
+def test_track_volume_full_size_properties(monkeypatch):
+    """BASELINE config-2/3 sizes (300 frames x 10 000 boxes, a 6-class slab): size-independent
+    properties of the tubelets, and the lazy lists against the eager track_det_nms path."""
+    import torch
+    from vdetlib_amd import ops, _lib
+    F, B, C, T = 300, 10000, 6, 10
+    g = torch.Generator(device='cuda').manual_seed(11)
+    x1 = torch.rand(F, B, generator=g, device='cuda') * 1230
+    y1 = torch.rand(F, B, generator=g, device='cuda') * 670
+    w = 10 + torch.rand(F, B, generator=g, device='cuda') * 290
+    h = 10 + torch.rand(F, B, generator=g, device='cuda') * 290
+    boxes = torch.stack([x1, y1, torch.clamp(x1 + w, max=1279), torch.clamp(y1 + h, max=719)], -1).round().contiguous()
+    scores = torch.rand(F, B, C, generator=g, device='cuda')
+    ki, kc, tr, an, nt = ops.nms_track_volume(boxes, scores, nms_thres=0.3, thres=0.9, max_tracks=T, link_thres=0.5, cap=2048)
+    assert int(nt.min()) == T                       # plenty of detections above the 0.9 stop score
+    # anchors: strictly descending score per class, box truncated, score 1 on the anchor row
+    a = an.cpu().numpy(); t = tr.cpu().numpy(); bx = boxes.cpu().numpy()
+    for c in range(C):
+        assert np.all(np.diff(a[c, :, 2]) <= 0)
+        for k in range(T):
+            f, b = int(a[c, k, 0]) - 1, int(a[c, k, 1])
+            assert np.array_equal(t[c, k, f, :4], np.trunc(bx[f, b])) and t[c, k, f, 4] == 1.0
+            rows = t[c, k]
+            have = ~np.isnan(rows[:, 0])
+            idx = np.nonzero(have)[0]
+            assert np.all(np.diff(idx) == 1)        # one contiguous run of frames around the anchor
+            others = have.copy(); others[f] = False
+            assert np.all(rows[others, 4] >= 0.5)   # every link reached the IoU threshold
+    # NMS by-product == the separate call
+    ki0, kc0 = ops.nms_volume(boxes, scores, 0.3, cap=2048)
+    assert torch.equal(kc, kc0) and torch.equal(ki, ki0)
+    # eager track_det_nms of every crossed list (the reference's literal procedure) gives the same tubelets
+    monkeypatch.setenv('VDET_NO_LAZY', '1')
+    cx = _lib.Context(torch.cuda.current_device())
+    tr2, an2, nt2 = ops.track_volume(boxes, scores, nms_thres=0.3, thres=0.9, max_tracks=T, link_thres=0.5, ctx=cx)
+    assert torch.equal(nt, nt2) and torch.equal(an, an2)
+    assert np.array_equal(t, tr2.cpu().numpy(), equal_nan=True)

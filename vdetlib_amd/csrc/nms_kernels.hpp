@@ -608,12 +608,17 @@ __device__ __forceinline__ unsigned long long match8(uint32_t d, bool valid)
 // order, so the returned value IS "keys of this digit before me in this wave".  That ordering is
 // measured, not documented: vdet_create runs lds_atomic_order_probe on thousands of conflict
 // patterns and the host only selects ARANK when it holds; otherwise the 8-ballot match is used.
+// (1024-thread variants up to CPW = 10, i.e. N <= 10 240, are register-capped to 8 waves per SIMD
+// -- hipcc's second __launch_bounds__ argument -- so that two workgroups are resident per CU)
 template <int BLOCK, int CPW, bool ARANK>
-__global__ __launch_bounds__(BLOCK) void sort_kernel(const SortParams prm)
+__global__ __launch_bounds__(BLOCK, (BLOCK == 1024 && CPW <= 10) ? 8 : 1) void sort_kernel(const SortParams prm)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NW = BLOCK / 64;
-    uint32_t *keys0 = reinterpret_cast<uint32_t *>(smem);
+    // Only 16 key bits live in LDS at a time (passes 0-1 sort by the low half, passes 2-3 by the
+    // high half, which waits in registers meanwhile): 6 B instead of 8 B per key, so TWO workgroups
+    // fit in the CU's 160 KiB at B = 10 000 and one covers the other's barrier stalls.
+    uint16_t *keys0 = reinterpret_cast<uint16_t *>(smem);
     uint16_t *src = reinterpret_cast<uint16_t *>(smem + prm.lds_idxa_off);
     uint16_t *dst = reinterpret_cast<uint16_t *>(smem + prm.lds_idxb_off);
     uint32_t *bases = reinterpret_cast<uint32_t *>(smem + prm.lds_base_off);   // [NW][256]
@@ -628,22 +633,31 @@ __global__ __launch_bounds__(BLOCK) void sort_kernel(const SortParams prm)
     if (tid == 0) tot[256] = 0;
     __syncthreads();
     uint32_t nx = 0;
-    for (int v = tid; v < N; v += BLOCK) {
-        uint32_t ik;
-        bool x = false;
-        if (prm.keys) {                        // explicit priorities; 0 marks "not a candidate"
-            const uint32_t k = prm.keys[pr.sbase + v];
-            ik = ~k;
-            x = (k == 0u);
-        } else {
-            const float s = prm.scores[pr.sbase + (int64_t)v * pr.sstride];
-            ik = ~score_key(s);
-            if (prm.use_thr && !(s > prm.thr)) x = true;
+    uint32_t khi[(CPW + 1) / 2];               // high halves of my keys (key v = tid + k * BLOCK), two per register
+#pragma unroll
+    for (int k = 0; k < (CPW + 1) / 2; ++k) khi[k] = 0xFFFFFFFFu;
+#pragma unroll
+    for (int k = 0; k < CPW; ++k) {
+        const int v = tid + k * BLOCK;         // BLOCK * CPW >= N (host)
+        if (v < N) {
+            uint32_t ik;
+            bool x = false;
+            if (prm.keys) {                    // explicit priorities; 0 marks "not a candidate"
+                const uint32_t kk = prm.keys[pr.sbase + v];
+                ik = ~kk;
+                x = (kk == 0u);
+            } else {
+                const float sc = prm.scores[pr.sbase + (int64_t)v * pr.sstride];
+                ik = ~score_key(sc);
+                if (prm.use_thr && !(sc > prm.thr)) x = true;
+            }
+            if (prm.excl && prm.excl[pr.rb + v]) x = true;
+            if (x) { ik = 0xFFFFFFFFu; ++nx; } // real inverted keys are <= 0xFF800000
+            keys0[v] = (uint16_t)(ik & 0xFFFFu);
+            khi[k >> 1] = (k & 1) ? ((khi[k >> 1] & 0x0000FFFFu) | (ik & 0xFFFF0000u))
+                                  : ((khi[k >> 1] & 0xFFFF0000u) | (ik >> 16));
+            src[v] = (uint16_t)(N - 1 - v);
         }
-        if (prm.excl && prm.excl[pr.rb + v]) x = true;
-        if (x) { ik = 0xFFFFFFFFu; ++nx; }     // real inverted keys are <= 0xFF800000
-        keys0[v] = ik;
-        src[v] = (uint16_t)(N - 1 - v);
     }
     if (nx) atomicAdd(&tot[256], nx);
     __syncthreads();
@@ -653,7 +667,14 @@ __global__ __launch_bounds__(BLOCK) void sort_kernel(const SortParams prm)
     const int c0 = w * CPW;                      // host guarantees NW * CPW >= nchunks
 
     for (int pass = 0; pass < prm.npass; ++pass) {
-        const int shift = pass * 8;
+        const int shift = (pass & 1) * 8;
+        if (pass == 2) {                       // every gather of the low halves is done (barrier at the end of pass 1)
+#pragma unroll
+            for (int k = 0; k < CPW; ++k) {
+                const int v = tid + k * BLOCK;
+                if (v < N) keys0[v] = (uint16_t)((k & 1) ? (khi[k >> 1] >> 16) : (khi[k >> 1] & 0xFFFFu));
+            }
+        }
         for (int i = tid; i < NW * 256; i += BLOCK) bases[i] = 0;
         __syncthreads();
         uint32_t ra[CPW];        // index | digit << 16
@@ -663,7 +684,7 @@ __global__ __launch_bounds__(BLOCK) void sort_kernel(const SortParams prm)
             const int q = (c0 + ch) * 64 + lane;
             const bool valid = (c0 + ch) < nchunks && q < N;
             const uint32_t i = valid ? src[q] : 0u;
-            const uint32_t d = valid ? ((keys0[i] >> shift) & 255u) : 0u;
+            const uint32_t d = valid ? (((uint32_t)keys0[i] >> shift) & 255u) : 0u;
             ra[ch] = i | (d << 16);
             if (ARANK) {
                 rl[ch] = valid ? atomicAdd(&bases[w * 256 + d], 1u) : 0u;

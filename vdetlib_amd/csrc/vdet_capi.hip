@@ -432,7 +432,7 @@ int launch_sort_walk(vdet_ctx *c, const SortWalkArgs &a, int nmax, int64_t order
     sp.ncand = a.order_out ? a.ncand_out : c->ncand.as<int32_t>();
     sp.npass = 4;
     if (const char *e = getenv("VDET_SORT_PASSES")) sp.npass = atoi(e);
-    const size_t keysB = r16((size_t)4 * std::max(nmax, 1));
+    const size_t keysB = r16((size_t)2 * std::max(nmax, 1));     // 16 key bits at a time (see sort_kernel)
     const size_t idxB = r16((size_t)2 * std::max(nmax, 1));
     sp.lds_idxa_off = (int)keysB;
     sp.lds_idxb_off = (int)(keysB + idxB);
