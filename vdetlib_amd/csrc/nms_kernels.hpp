@@ -820,51 +820,75 @@ struct WalkParams {
     int mask_words;           // u32 words per wave
 };
 
+// LDS words through which the lanes of one wave talk to each other (the walks' dead masks): every
+// access must be a real LDS instruction.  A `volatile` access through a GENERIC pointer is not
+// rewritten to the LDS address space by hipcc (InferAddressSpaces skips volatile accesses): it
+// becomes flat_load ... sc0 sc1 + s_waitcnt vmcnt(0), which drains every global load in flight --
+// measured: it serialised the walk's whole prefetch pipeline.  So the masks are typed
+// address_space(3): ds_read_b32 / ds_write_b32 / ds_or_b32, ordered by the wave's in-order LDS queue.
+typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
+typedef volatile lds_u32_t *lds_mask_t;
+
+__device__ __forceinline__ lds_mask_t lds_mask_ptr(unsigned char *dyn_smem, int word_off)
+{
+    return (lds_mask_t)((__attribute__((address_space(3))) unsigned char *)dyn_smem) + word_off;
+}
+__device__ __forceinline__ void lds_or(lds_mask_t m, int word, uint32_t bits)
+{
+    __hip_atomic_fetch_or((lds_u32_t *)(m + word), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+__device__ __forceinline__ void lds_and(lds_mask_t m, int word, uint32_t bits)
+{
+    __hip_atomic_fetch_and((lds_u32_t *)(m + word), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+
 constexpr int kWalkGrp = 8;
 
 // One 64-entry slice of a survivor's adjacency list -> dead bits.  HASZ = false (every regular
 // frame): entries are plain indices, nothing to test -- this is the instruction-issue hot spot of
 // the walk (one wave does ~1 400 survivors x 2 slices per problem), so it is kept to the bone.
 template <bool HASZ>
-__device__ __forceinline__ void walk_apply_slice(volatile uint32_t *mask, uint16_t e, bool in_range, int &bad)
+__device__ __forceinline__ void walk_apply_slice(lds_mask_t mask, uint16_t e, bool in_range, int &bad)
 {
-    if (in_range) {
-        if (HASZ) {
+    if (HASZ) {
+        if (in_range) {
             const int v = e & 0x7FFF;
             if (e & kZTag) { if (!((mask[v >> 5] >> (v & 31)) & 1u)) bad = 1; }
-            else atomicOr(const_cast<uint32_t *>(&mask[v >> 5]), 1u << (v & 31));
-        } else {
-            atomicOr(const_cast<uint32_t *>(&mask[e >> 5]), 1u << (e & 31));
+            else lds_or(mask, v >> 5, 1u << (v & 31));
         }
+    } else {
+        // (exec-masked on purpose: letting the lanes past the end OR 0 into their clamped word makes
+        // them all hit ONE address, and same-address LDS atomics serialise -- measured 6x slower)
+        if (in_range) lds_or(mask, e >> 5, 1u << (e & 31));
     }
 }
 
-// the survivors of one group of up to kWalkGrp alive candidates (lanes ls[0..ng) of c / off / deg)
+// the survivors of one group of up to kWalkGrp alive candidates (lanes ls[0..ng) of c / off / deg).
+// pre[k] = entries 2*lane and 2*lane+1 of candidate k's adjacency list (one 4-byte load; lists start
+// at even offsets).  Survivors are staged 64 at a time and written with one coalesced store.
 template <bool HASZ>
-__device__ __forceinline__ void walk_group(volatile uint32_t *mask, const uint16_t *__restrict__ adj, int lane, int c,
+__device__ __forceinline__ void walk_group(lds_mask_t mask, const uint16_t *__restrict__ adj, int lane, int c,
                                            uint32_t off, int deg, const int (&ls)[kWalkGrp], int ng,
-                                           const uint16_t (&pre0)[kWalkGrp], const uint16_t (&pre1)[kWalkGrp],
-                                           int32_t *__restrict__ out, int64_t cap, int &nk, int &bad)
+                                           const uint32_t (&pre)[kWalkGrp], int32_t *__restrict__ out, int64_t cap,
+                                           int &nk, int &stage, int &bad)
 {
 #pragma unroll
     for (int k = 0; k < kWalkGrp; ++k) {
         if (k >= ng) break;
         const int cu = __builtin_amdgcn_readlane(c, ls[k]);
-        if ((mask[cu >> 5] >> (cu & 31)) & 1u) continue;    // suppressed by an earlier survivor of this chunk
+        // (wave-uniform value made scalar: the branch and the survivor counter stay on the scalar unit)
+        if (__builtin_amdgcn_readfirstlane((mask[cu >> 5] >> (cu & 31)) & 1u)) continue;   // suppressed by an earlier survivor of this chunk
         const int d = __builtin_amdgcn_readlane(deg, ls[k]);
-        if (lane == 0) {
-            if ((int64_t)nk < cap) out[nk] = cu;
-            atomicOr(const_cast<uint32_t *>(&mask[cu >> 5]), 1u << (cu & 31));
-        }
+        if (HASZ && lane == 0) lds_or(mask, cu >> 5, 1u << (cu & 31));   // a kept box reads as dead (zero-union rule)
+        if ((nk & 63) == lane) stage = cu;
         ++nk;
-        walk_apply_slice<HASZ>(mask, pre0[k], lane < d, bad);
-        if (d > 64) {
-            walk_apply_slice<HASZ>(mask, pre1[k], lane + 64 < d, bad);
-            if (d > 128) {   // rare: long lists
-                const uint32_t o = __builtin_amdgcn_readlane(off, ls[k]);
-                for (int e0 = 128; e0 < d; e0 += 64)
-                    walk_apply_slice<HASZ>(mask, adj[o + min(e0 + lane, d - 1)], e0 + lane < d, bad);
-            }
+        if ((nk & 63) == 0 && (int64_t)(nk - 64 + lane) < cap) out[nk - 64 + lane] = stage;
+        walk_apply_slice<HASZ>(mask, (uint16_t)(pre[k] & 0xFFFFu), 2 * lane < d, bad);
+        walk_apply_slice<HASZ>(mask, (uint16_t)(pre[k] >> 16), 2 * lane + 1 < d, bad);
+        if (d > 128) {   // rare: long lists
+            const uint32_t o = __builtin_amdgcn_readlane(off, ls[k]);
+            for (int e0 = 128; e0 < d; e0 += 64)
+                walk_apply_slice<HASZ>(mask, adj[o + min(e0 + lane, d - 1)], e0 + lane < d, bad);
         }
     }
 }
@@ -874,7 +898,7 @@ __global__ __launch_bounds__(256) void walk_kernel(const WalkParams prm)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    volatile uint32_t *mask = reinterpret_cast<uint32_t *>(smem) + w * prm.mask_words;
+    lds_mask_t mask = lds_mask_ptr(smem, w * prm.mask_words);
     const int nwaves_total = gridDim.x * 4;
     // wave-granular XCD mapping: block b -> XCD b % 8; consecutive problems share a frame
     const int per = nwaves_total >> 3;
@@ -893,18 +917,22 @@ __global__ __launch_bounds__(256) void walk_kernel(const WalkParams prm)
     if (has_z) {   // non-candidates must read as dead for the zero-union rule
         for (int q = ncand + lane; q < N; q += 64) {
             const int v = order[q];
-            atomicOr(const_cast<uint32_t *>(&mask[v >> 5]), 1u << (v & 31));
+            lds_or(mask, v >> 5, 1u << (v & 31));
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
 
-    int nk = 0;
+    int nk = 0, stage = 0;
     int bad = 0;
+    const uint32_t *adjw = reinterpret_cast<const uint32_t *>(prm.adj);   // adjacency lists start at even offsets
     // Two-deep software pipeline over the chunks of 64 candidates: the ids of chunk i+2 (one
     // coalesced load) and the row meta of chunk i+1 (an 8-B gather, issued only for the lanes that
     // are still alive NOW -- a dead candidate never revives, so this is a superset of what will be
     // needed) are in flight while chunk i is walked.  Per chunk only the adjacency-list loads of
-    // its survivor groups remain on the critical path.
+    // its survivor groups remain on the critical path.  (Also prefetching the next chunk's first
+    // group of lists was measured: +11 % time -- the walk is instruction-issue bound, ~35
+    // instructions per survivor and ~60 per chunk, not latency-bound; so were two lists per wave
+    // (+20 %) and byte flags instead of the bit mask (+40 %: half the occupancy).)
     const int last = max(ncand - 1, 0);
     int c_cur = (int)order[min(lane, last)];
     int c_nxt = (int)order[min(64 + lane, last)];
@@ -933,20 +961,19 @@ __global__ __launch_bounds__(256) void walk_kernel(const WalkParams prm)
             // Prefetch the first 128 entries of every list of the group.  The loads are
             // UNCONDITIONAL (clamped lane index, no exec-masked branch): a guarded load forces hipcc
             // to drain vmcnt at every join and serialises the whole group.
-            uint16_t pre0[kWalkGrp], pre1[kWalkGrp];
+            uint32_t pre[kWalkGrp];
 #pragma unroll
             for (int k = 0; k < kWalkGrp; ++k) {
                 const uint32_t o = __builtin_amdgcn_readlane(off, ls[k]);
                 const int d = __builtin_amdgcn_readlane(deg, ls[k]);
-                const int dm = max(d, 1) - 1;
-                pre0[k] = prm.adj[o + min(lane, dm)];
-                pre1[k] = prm.adj[o + min(lane + 64, dm)];
+                pre[k] = adjw[(o >> 1) + min(lane, (max(d, 1) - 1) >> 1)];
             }
-            if (has_z) walk_group<true>(mask, prm.adj, lane, c, off, deg, ls, ng, pre0, pre1, out, cap, nk, bad);
-            else walk_group<false>(mask, prm.adj, lane, c, off, deg, ls, ng, pre0, pre1, out, cap, nk, bad);
+            if (has_z) walk_group<true>(mask, prm.adj, lane, c, off, deg, ls, ng, pre, out, cap, nk, stage, bad);
+            else walk_group<false>(mask, prm.adj, lane, c, off, deg, ls, ng, pre, out, cap, nk, stage, bad);
         }
         c_cur = c_nxt; c_nxt = c_nn; m_cur = m_nxt;
     }
+    if (lane < (nk & 63) && (int64_t)((nk & ~63) + lane) < cap) out[(nk & ~63) + lane] = stage;   // tail
     if (lane == 0) prm.keep_cnt[p] = nk;
     if ((int64_t)nk > cap && lane == 0) atomicOr(prm.status, kStCap);
     if (__ballot(bad != 0) && lane == 0) atomicOr(prm.status, kStDivZero);

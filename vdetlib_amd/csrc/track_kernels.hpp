@@ -434,7 +434,7 @@ __global__ __launch_bounds__(256) void track_suppress_kernel(const SuppressParam
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    volatile uint32_t *mask = reinterpret_cast<uint32_t *>(smem) + w * prm.mask_words;
+    lds_mask_t mask = lds_mask_ptr(smem, w * prm.mask_words);
     const int p = blockIdx.x * 4 + w;                 // p = f * C + c
     if (p >= prm.F * prm.C) return;
     const int f = p / prm.C, c = p - f * prm.C;
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(256) void track_suppress_kernel(const SuppressParam
         for (int i = lane; i < ((B + 31) >> 5); i += 64) mask[i] = 0xFFFFFFFFu;
         for (int q = lane; q < n; q += 64) {
             const int v = list[q];
-            atomicAnd(const_cast<uint32_t *>(&mask[v >> 5]), ~(1u << (v & 31)));
+            lds_and(mask, v >> 5, ~(1u << (v & 31)));
         }
     } else if (n > 2048 && prm.group_flags && (prm.group_flags[f] & kFlagRegular)) {
         // long list (first visit of a full frame): round 1 as ONE coalesced sweep over the frame's
@@ -497,7 +497,7 @@ __global__ __launch_bounds__(256) void track_suppress_kernel(const SuppressParam
                 const uint32_t pp = pair_pred(bd, box_area(bd), tb, tarea, prm.t32);
                 if (pp & 1u) {
                     const int b = prm.ix.xord[(int64_t)f * B + r];
-                    atomicOr(const_cast<uint32_t *>(&mask[b >> 5]), 1u << (b & 31));
+                    lds_or(mask, b >> 5, 1u << (b & 31));
                 }
             }
         } else
@@ -526,7 +526,7 @@ __global__ __launch_bounds__(256) void track_suppress_kernel(const SuppressParam
             const uint32_t pp = pair_pred(bd, box_area(bd), tb, tarea, prm.t32);
             if (valid && (pp & 2u)) bad = 1;
             r1 = valid && (pp & 1u);
-            if (r1) atomicOr(const_cast<uint32_t *>(&mask[cidx >> 5]), 1u << (cidx & 31));
+            if (r1) lds_or(mask, cidx >> 5, 1u << (cidx & 31));
         }
         const bool alive = valid && !r1 && !((mask[cidx >> 5] >> (cidx & 31)) & 1u);
         unsigned long long am = __ballot(alive);
@@ -559,7 +559,7 @@ __global__ __launch_bounds__(256) void track_suppress_kernel(const SuppressParam
                 if ((nk & 63) == lane) stage = cu;
                 ++nk;
                 if ((nk & 63) == 0) list[nk - 64 + lane] = (uint16_t)stage;   // coalesced; positions < q0 + 64, all read already
-                if (lane == 0) atomicOr(const_cast<uint32_t *>(&mask[cu >> 5]), 1u << (cu & 31));
+                if (lane == 0) lds_or(mask, cu >> 5, 1u << (cu & 31));
                 const int d = __builtin_amdgcn_readlane(deg, ls[k]);
                 if (has_z) {
                     walk_apply_slice<true>(mask, pre0[k], lane < d, bad);
