@@ -607,7 +607,8 @@ __global__ void track_init_kernel(TrackState *__restrict__ st, int C)
 //   tracks [C,T,F,5] f32 (NaN = no box), ntracks [C]
 //   out_score [C,T,F] f64 (NaN = no box), out_box [C,T,F,4] f32 (the "regressed" box)
 // ------------------------------------------------------------------------------------------------
-// one block per (class, track, frame)
+// one WAVE per (class, track, frame) (600 000 of them at c2: with one 256-thread block each the
+// kernel was bound by the block launch rate and an 8-barrier LDS reduction), 4 per block
 __global__ __launch_bounds__(256) void rescore_spatial_kernel(const float *__restrict__ tracks,
                                                               const int32_t *__restrict__ ntracks,
                                                               const float4 *__restrict__ boxes,
@@ -616,12 +617,15 @@ __global__ __launch_bounds__(256) void rescore_spatial_kernel(const float *__res
                                                               float *__restrict__ out_box, const FrameIndex ix,
                                                               const uint32_t *__restrict__ group_flags)
 {
-    __shared__ double ss[256];
-    __shared__ long long si[256];
-    const int64_t e = blockIdx.x;                 // (c*T + t)*F + f
-    const int f = (int)(e % F);
-    const int ct = (int)(e / F);
-    const int c = ct / T, t = ct - c * T, tid = threadIdx.x;
+    // waves are ordered frame-major ((f*C + c)*T + t): neighbours in the dispatch order read the same
+    // frame's x-window, which then stays in L2
+    const int tid = threadIdx.x & 63;
+    const int64_t wv = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wv >= (int64_t)F * C * T) return;
+    const int t = (int)(wv % T);
+    const int fc = (int)(wv / T);
+    const int f = fc / C, c = fc - f * C;
+    const int64_t e = ((int64_t)c * T + t) * F + f;
     const double qnan = __longlong_as_double(0x7FF8000000000000ll);
     const float *row = tracks + e * 5;
     if (t >= ntracks[c] || row[0] != row[0]) {
@@ -636,8 +640,20 @@ __global__ __launch_bounds__(256) void rescore_spatial_kernel(const float *__res
     if (ix.xbox && group_flags && (group_flags[f] & kFlagRegular) && thres > 1e-6 && wc > 0.0f && wc < 3.0e38f) {
         int r0, r1;
         xwindow(ix, f, row[0], wc, thres, r0, r1);
-        for (int r = r0 + tid; r < r1; r += 256) {
+        // f32 screen before the float64 IoU (vdet/tubelet_cls.py:514-532 computes it in f64): the f32
+        // quotient is within a few 1e-7 (relative) of the exact one on regular boxes, so everything the
+        // f64 test accepts satisfies inter > (thres - 1e-3) * union in f32; the rest (almost all of
+        // the x-window) never reaches the half-rate f64 unit
+        const float pa = ((row[2] - row[0]) + 1.0f) * ((row[3] - row[1]) + 1.0f);
+        const float thr_lo = (float)thres - 1.0e-3f;
+        for (int r = r0 + tid; r < r1; r += 64) {
             const float4 bb = ix.xbox[(int64_t)f * B + r];
+            const float sw = (fminf(row[2], bb.z) - fmaxf(row[0], bb.x)) + 1.0f;
+            const float sh = (fminf(row[3], bb.w) - fmaxf(row[1], bb.y)) + 1.0f;
+            if (!(sw > 0.0f && sh > 0.0f)) continue;
+            const float sinter = sw * sh;
+            const float suni = (pa + box_area(bb)) - sinter;
+            if (!(sinter > thr_lo * suni)) continue;
             const double q[4] = {(double)bb.x, (double)bb.y, (double)bb.z, (double)bb.w};
             if (iou_f64_pair(p, q) > thres) {
                 const int64_t j = ix.xord[(int64_t)f * B + r];
@@ -646,7 +662,7 @@ __global__ __launch_bounds__(256) void rescore_spatial_kernel(const float *__res
             }
         }
     } else
-    for (int j = tid; j < B; j += 256) {
+    for (int j = tid; j < B; j += 64) {
         const float4 bb = boxes[(int64_t)f * B + j];
         const double q[4] = {(double)bb.x, (double)bb.y, (double)bb.z, (double)bb.w};
         if (iou_f64_pair(p, q) > thres) {
@@ -654,21 +670,16 @@ __global__ __launch_bounds__(256) void rescore_spatial_kernel(const float *__res
             if (argmax_better(s, j, bs, bi)) { bs = s; bi = j; }
         }
     }
-    ss[tid] = bs;
-    si[tid] = bi;
-    __syncthreads();
-    for (int d = 128; d > 0; d >>= 1) {
-        if (tid < d) {
-            const double s2 = ss[tid + d];
-            const int64_t i2 = si[tid + d];
-            if (i2 >= 0 && argmax_better(s2, i2, ss[tid], si[tid])) { ss[tid] = s2; si[tid] = i2; }
-        }
-        __syncthreads();
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {        // wave argmax (first index on ties, NaN rules of argmax_better)
+        const double s2 = __shfl_xor(bs, d, 64);
+        const long long i2 = __shfl_xor((long long)bi, d, 64);
+        if (i2 >= 0 && argmax_better(s2, (int64_t)i2, bs, bi)) { bs = s2; bi = (int64_t)i2; }
     }
     if (tid == 0) {
-        if (si[0] >= 0) {
-            const float4 bb = boxes[(int64_t)f * B + si[0]];
-            out_score[e] = ss[0];
+        if (bi >= 0) {
+            const float4 bb = boxes[(int64_t)f * B + bi];
+            out_score[e] = bs;
             out_box[e * 4 + 0] = bb.x; out_box[e * 4 + 1] = bb.y; out_box[e * 4 + 2] = bb.z; out_box[e * 4 + 3] = bb.w;
         } else {   // no overlapping detection: sentinel score, box unchanged (:526-530)
             out_score[e] = -1e5;

@@ -1153,7 +1153,7 @@ int vdet_rescore_tracks(vdet_ctx *c, const float *d_tracks, const int32_t *d_ntr
     }
     {
         StageTimer tm(c, ST_RSPATIAL);
-        hipLaunchKernelGGL(rescore_spatial_kernel, dim3((unsigned)nb), dim3(256), 0, c->stream, d_tracks, d_ntracks,
+        hipLaunchKernelGGL(rescore_spatial_kernel, dim3((unsigned)((nb + 3) / 4)), dim3(256), 0, c->stream, d_tracks, d_ntracks,
                            reinterpret_cast<const float4 *>(d_boxes), d_scores, (int)F, (int)B, (int)C, max_tracks,
                            overlap_thres, d_det_score, d_boxes_out, ix, flags);
     }
