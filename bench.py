@@ -228,6 +228,21 @@ def main():
                                       "stages are added (value = boxes/s through the same stages as the GPU step)",
                    "nms_temp_boxes_per_s": 1.0 / t_nms_per_box, "parity_checked": parity}
 
+        cpu_all = None
+        if not args.no_cpu:
+            # the same NMS sample on every host core (independent problems on threads; the reference
+            # is single-threaded -- SURVEY 8d asks for both a 1-core and an all-core figure)
+            nthr = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            if nthr > 1:
+                t4 = time.perf_counter()
+                midx, mcnt = oracle.nms_volume(hb, hs, args.thresh, cap=args.cap, threads=nthr)
+                oracle.temporal_maxpool(hs, args.window)
+                mdt = time.perf_counter() - t4
+                cpu_all = {"value": cpu_boxes / mdt, "unit": "boxes/s", "cores": nthr, "kind": "port",
+                           "sample": "NMS+TEMP only (no LINK), same %d nms problems on %d host threads in %.2f s"
+                                     % (nf * nc, nthr, mdt),
+                           "parity_checked": bool(np.array_equal(midx, widx) and np.array_equal(mcnt, wcnt))}
+
         pcie = None
         if not args.no_cpu:
             # what the step would cost if the video had to come over PCIe first (never part of `value`)
@@ -262,7 +277,7 @@ def main():
                                     (args.max_tracks, args.track_thres, args.link_thres, args.pool_thres),
                                     "; RCCL all-gather of the final tubelets + kept counts" if world > 1 else ""),
                        "frames": F, "boxes": B, "classes": C, "parallelism": "video-per-gpu x%d, %d videos in flight per GPU" % (world, nstreams)},
-            "roofline": roofline, "cpu_baseline": cpu, "pcie": pcie,
+            "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_allcores": cpu_all, "pcie": pcie,
         }
     if world > 1:
         dist.barrier()

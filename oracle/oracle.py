@@ -51,6 +51,8 @@ def lib():
         L.oracle_iou_f64.restype = None
         L.oracle_nms_volume.argtypes = [vp, vp, i64, i64, i64, i64, i64, i64, i64, f64, ci,
                                         ctypes.c_float, vp, vp, i64]
+        L.oracle_nms_volume_mt.argtypes = [vp, vp, i64, i64, i64, i64, i64, i64, i64, f64, ci,
+                                           ctypes.c_float, vp, vp, i64, ci]
         L.oracle_temporal_maxpool_f32.argtypes = [vp, vp, i64, i64, ci, ctypes.c_float]
         L.oracle_temporal_conv_f32.argtypes = [vp, vp, i64, i64, vp, ci, ctypes.c_float,
                                                ctypes.c_float]
@@ -125,7 +127,7 @@ def iou(boxes1, boxes2):
     return out
 
 
-def nms_volume(boxes, scores, thresh, score_thresh=None, cap=None, frames=None, classes=None):
+def nms_volume(boxes, scores, thresh, score_thresh=None, cap=None, frames=None, classes=None, threads=1):
     """Per-(frame,class) nms over boxes [F,B,4] / scores [F,B,C]: image_det.py:117-123 applied to
     every (frame, class) of video_det.py:89-99's loop.  Returns keep_idx [F,C,cap] (-1 padded),
     keep_cnt [F,C]; only the requested frame/class sub-ranges are filled."""
@@ -137,6 +139,12 @@ def nms_volume(boxes, scores, thresh, score_thresh=None, cap=None, frames=None, 
     c0, c1 = classes if classes is not None else (0, C)
     idx = np.full((F, C, cap), -1, dtype=np.int32)
     cnt = np.zeros((F, C), dtype=np.int32)
+    if threads > 1:     # independent problems on host threads (bench.py's all-core CPU baseline)
+        _check(lib().oracle_nms_volume_mt(_p(b), _p(s), F, B, C, f0, f1, c0, c1, float(thresh),
+                                          0 if score_thresh is None else 1,
+                                          0.0 if score_thresh is None else float(score_thresh),
+                                          _p(idx), _p(cnt), cap, int(threads)))
+        return idx, cnt
     _check(lib().oracle_nms_volume(_p(b), _p(s), F, B, C, f0, f1, c0, c1, float(thresh),
                                    0 if score_thresh is None else 1,
                                    0.0 if score_thresh is None else float(score_thresh),

@@ -249,6 +249,77 @@ int oracle_nms_volume(const float *boxes, const float *scores, int64_t F, int64_
 }
 
 /*
+ * The same per-(frame, class) loop on `nthreads` host threads (the problems are independent; the
+ * reference itself is single-threaded, an 8-process multiprocessing run is how SURVEY 8d quotes
+ * "all cores").  Only bench.py's all-core CPU baseline uses it.  Results == oracle_nms_volume.
+ */
+#include <pthread.h>
+typedef struct {
+    const float *boxes, *scores;
+    int64_t B, C, f0, c0, nc, nprob, cap;
+    double thresh; int use_thr; float thr;
+    int32_t *keep_idx, *keep_cnt;
+    int64_t next;             /* shared problem counter */
+    int rc;
+    pthread_mutex_t mu;
+} mt_job_t;
+
+static void *mt_worker(void *arg)
+{
+    mt_job_t *j = (mt_job_t *)arg;
+    const int64_t B = j->B, C = j->C;
+    float *d = (float *)malloc((size_t)(B ? B : 1) * 5 * sizeof(float));
+    int64_t *map = (int64_t *)malloc((size_t)(B ? B : 1) * sizeof(int64_t));
+    int64_t *k = (int64_t *)malloc((size_t)(B ? B : 1) * sizeof(int64_t));
+    for (;;) {
+        pthread_mutex_lock(&j->mu);
+        const int64_t i = j->next++;
+        const int stop = j->rc != ORACLE_OK;
+        pthread_mutex_unlock(&j->mu);
+        if (i >= j->nprob || stop) break;
+        const int64_t f = j->f0 + i / j->nc, c = j->c0 + i % j->nc;
+        int64_t n = 0;
+        for (int64_t b = 0; b < B; ++b) {
+            const float s = j->scores[(f * B + b) * C + c];
+            if (j->use_thr && !(s > j->thr)) continue;
+            memcpy(d + n * 5, j->boxes + (f * B + b) * 4, 4 * sizeof(float));
+            d[n * 5 + 4] = s; map[n++] = b;
+        }
+        int64_t nk = 0;
+        const int rc = oracle_nms(d, n, 5, 5, j->thresh, NULL, k, &nk);
+        if (rc != ORACLE_OK) { pthread_mutex_lock(&j->mu); j->rc = rc; pthread_mutex_unlock(&j->mu); break; }
+        j->keep_cnt[f * C + c] = (int32_t)nk;
+        for (int64_t q = 0; q < nk && q < j->cap; ++q) j->keep_idx[(f * C + c) * j->cap + q] = (int32_t)map[k[q]];
+    }
+    free(d); free(map); free(k);
+    return NULL;
+}
+
+int oracle_nms_volume_mt(const float *boxes, const float *scores, int64_t F, int64_t B, int64_t C,
+                         int64_t f0, int64_t f1, int64_t c0, int64_t c1,
+                         double thresh, int use_score_thresh, float score_thresh, int32_t *keep_idx,
+                         int32_t *keep_cnt, int64_t cap, int nthreads)
+{
+    (void)F;
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 1024) nthreads = 1024;
+    mt_job_t j;
+    j.boxes = boxes; j.scores = scores; j.B = B; j.C = C; j.f0 = f0; j.c0 = c0; j.nc = c1 - c0;
+    j.nprob = (f1 - f0) * (c1 - c0); j.cap = cap; j.thresh = thresh; j.use_thr = use_score_thresh; j.thr = score_thresh;
+    j.keep_idx = keep_idx; j.keep_cnt = keep_cnt; j.next = 0; j.rc = ORACLE_OK;
+    if (j.nc <= 0 || j.nprob <= 0) return ORACLE_OK;
+    pthread_mutex_init(&j.mu, NULL);
+    pthread_t *th = (pthread_t *)malloc((size_t)nthreads * sizeof(pthread_t));
+    int started = 0;
+    for (int t = 0; t < nthreads; ++t) { if (pthread_create(&th[t], NULL, mt_worker, &j) != 0) break; ++started; }
+    if (started == 0) mt_worker(&j);
+    for (int t = 0; t < started; ++t) pthread_join(th[t], NULL);
+    free(th);
+    pthread_mutex_destroy(&j.mu);
+    return j.rc;
+}
+
+/*
  * Centred sliding temporal max over series laid out [F, S] (series s is
  * in[f*S + s]): the array form of score_proto_temporal_maxpool
  * (vdet/tubelet_cls.py:386-414): out[f] = max(in[f-h .. f+h]), out-of-range = pad

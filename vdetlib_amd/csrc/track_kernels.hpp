@@ -231,8 +231,40 @@ __device__ __forceinline__ float4 trunc4(float4 b)   // int(cor) of utils/protoc
 // buffered LDS slot, every thread finishes the reduction redundantly.  The step is a serial chain
 // executed by every wave, so a SMALL block wins: with 1024 threads the replicated serial part cost
 // ~7 us per frame (measured), the x-window leaves only ~2 000 candidates per frame anyway.
-constexpr int LT = 256;
-static_assert(LT == 256, "the bucket-table prefetch of track_link_kernel assumes 256 threads");
+constexpr int LT = 256;      // (512 threads: 14.8 vs 13.2 ms per video -- every wave replays the serial part)
+
+// One batch of the x-window scan of track_link_kernel: WB boxes per thread starting at rank rb0.
+// All loads are issued before the first use (a load inside the ballot-branching loop body is waited
+// for immediately: one full memory latency per box, ~7 us per frame measured), and the boxes'
+// original indices (tie rule) come with them: fetching the index inside the passing branch was a
+// second, serialised memory round trip per passing iteration (16.4 -> 13.6 ms per video).
+template <int WB>
+__device__ __forceinline__ void link_scan(const float4 *__restrict__ xb, const uint16_t *__restrict__ xo, int rb0, int r1,
+                                          int B, int tid, float4 cur, float carea, float link_t32, float t32e, float &bv,
+                                          int &bi, float4 &bb)
+{
+    float4 xs[WB];
+    uint16_t xi[WB];
+#pragma unroll
+    for (int i = 0; i < WB; ++i) xs[i] = xb[min(rb0 + i * LT + tid, B - 1)];
+#pragma unroll
+    for (int i = 0; i < WB; ++i) xi[i] = xo[min(rb0 + i * LT + tid, B - 1)];
+    // one ballot-guarded candidate at a time: each starts as soon as ITS load has landed (computing all
+    // WB predicates branch-free first was measured slower: 12.3 vs 11.5 ms per video)
+#pragma unroll
+    for (int i = 0; i < WB; ++i) {
+        const int r = rb0 + i * LT + tid;
+        const bool inb = r < r1;
+        bool border;
+        const bool pass = pred_regular(cur, carea, xs[i], box_area(xs[i]), link_t32, t32e, border);
+        if (__ballot((pass || border) && inb)) {
+            const float v = link_iou(cur, carea, xs[i]);
+            const int b = (int)xi[i];
+            if (inb && v >= link_t32 && (v > bv || (v == bv && b < bi))) { bv = v; bi = b; bb = xs[i]; }
+        }
+    }
+}
+static_assert(LT >= 256 && LT % 64 == 0, "the bucket-table prefetch of track_link_kernel needs at least 256 threads");
 __global__ __launch_bounds__(LT) void track_link_kernel(const float4 *__restrict__ boxes, int F, int B, int max_tracks,
                                                           float link_t32, int reach, const TrackState *__restrict__ st,
                                                           float *__restrict__ tracks,
@@ -243,6 +275,7 @@ __global__ __launch_bounds__(LT) void track_link_kernel(const float4 *__restrict
     __shared__ int si[2][LT / 64];
     __shared__ float4 sb[2][LT / 64];          // the winning box travels with its score: no dependent global load
     __shared__ uint32_t scum[2][260];     // next frame's bucket table + (xmin, scale, wmax), prefetched
+
     const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int dir = blockIdx.y == 0 ? 1 : -1;
     const TrackState s = st[c];
@@ -278,6 +311,12 @@ __global__ __launch_bounds__(LT) void track_link_kernel(const float4 *__restrict
 #pragma unroll
         for (int i = 0; i < LB; ++i) nb[i] = fb1[min(tid + i * LT, B - 1)];
     }
+    const float omt = (float)(1.0 - link_thres) * 1.002f + 1.0e-6f;     // (1 - link_thres), rounded up
+#define LINK_DPP_STEP(CTRL, ROWMASK) { \
+        const float v2 = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(-1.0f), __float_as_int(bv), CTRL, ROWMASK, 0xf, false)); \
+        const int i2 = __builtin_amdgcn_update_dpp(-1, bi, CTRL, ROWMASK, 0xf, false); \
+        if (i2 >= 0 && (bi < 0 || v2 > bv || (v2 == bv && i2 < bi))) { bv = v2; bi = i2; } }
+#define LSCAN(W) link_scan<W>(xb, xo, rb0, r1, B, tid, cur, carea, link_t32, t32e, bv, bi, bb);
     for (int step = 1; step <= reach; ++step) {
         const int f = s.anchor_frame + dir * step;
         if (f < 0 || f >= F) break;
@@ -301,7 +340,7 @@ __global__ __launch_bounds__(LT) void track_link_kernel(const float4 *__restrict
         uint32_t pf0 = 0u, pf1 = 0u;
         if (use_ix) {
             const int f2 = min(max(f + dir, 0), F - 1);
-            pf0 = ix.cum[(int64_t)f2 * 257 + tid];
+            pf0 = ix.cum[(int64_t)f2 * 257 + min(tid, 255)];
             pf1 = tid == 0 ? ix.cum[(int64_t)f2 * 257 + 256] : __float_as_uint(ix.info[f2 * 4 + min(tid - 1, 2)]);
         }
         if (fast && use_ix) {
@@ -311,34 +350,21 @@ __global__ __launch_bounds__(LT) void track_link_kernel(const float4 *__restrict
                 const float xmin = __uint_as_float(scum[par][257]), scale = __uint_as_float(scum[par][258]);
                 const float wmax = __uint_as_float(scum[par][259]);
                 const float wc = (cur.z - cur.x) + 1.0f;
-                const double lo = (double)cur.x - (1.0 - link_thres) * (double)wmax * 1.001 - 1.0;
-                const double hi = (double)cur.x + (1.0 - link_thres) * (double)wc * 1.001 + 1.0;
-                r0 = (int)scum[par][xbucket((float)fmax(lo, -3.0e38), xmin, scale)];
-                r1 = (int)scum[par][xbucket((float)fmin(hi, 3.0e38), xmin, scale) + 1];
+                // (f32 with slack instead of f64: the window only has to be a superset)
+                const float lo = cur.x - omt * wmax - 2.0f;
+                const float hi = cur.x + omt * wc + 2.0f;
+                r0 = (int)scum[par][xbucket(fmaxf(lo, -3.0e38f), xmin, scale)];
+                r1 = (int)scum[par][xbucket(fminf(hi, 3.0e38f), xmin, scale) + 1];
             }
             const float4 *xb = ix.xbox + (int64_t)f * B;
             const uint16_t *xo = ix.xord + (int64_t)f * B;
-            // batches of WB boxes per thread: all WB loads are issued before the first use (a load
-            // inside the ballot-branching loop body is waited for immediately: one full memory
-            // latency per box, ~7 us per frame measured)
-            constexpr int WB = 8;
-            for (int rb0 = r0; rb0 < r1; rb0 += WB * LT) {
-                float4 xs[WB];
-#pragma unroll
-                for (int i = 0; i < WB; ++i) xs[i] = xb[min(rb0 + i * LT + tid, B - 1)];
-#pragma unroll
-                for (int i = 0; i < WB; ++i) {
-                    const int r = rb0 + i * LT + tid;
-                    const bool inb = r < r1;
-                    bool border;
-                    const bool pass = pred_regular(cur, carea, xs[i], box_area(xs[i]), link_t32, t32e, border);
-                    if (__ballot((pass || border) && inb)) {
-                        const float v = link_iou(cur, carea, xs[i]);
-                        const int b = (int)xo[min(r, B - 1)];
-                        if (inb && v >= link_t32 && (v > bv || (v == bv && b < bi))) { bv = v; bi = b; bb = xs[i]; }
-                    }
-                }
-            }
+            // batches of WB boxes per thread (link_scan): a typical window (~2 400 boxes) goes in ONE
+            // batch of 16 per thread = one memory round trip per frame step; registers are free here
+            // (400 blocks on 256 CUs: occupancy is irrelevant)
+            int rb0 = r0;
+            while (r1 - rb0 > 16 * LT) { LSCAN(16) rb0 += 16 * LT; }
+            const int nb = (r1 - rb0 + LT - 1) / LT;          // loads per thread still needed (wave-uniform)
+            if (nb > 12) { LSCAN(16) } else if (nb > 8) { LSCAN(12) } else if (nb > 4) { LSCAN(8) } else if (nb > 0) { LSCAN(4) }
         } else if (use_ix) {
             // irregular frame while an index exists: plain scan, no prefetch
             for (int b = tid; b < B; b += LT) {
@@ -369,7 +395,7 @@ __global__ __launch_bounds__(LT) void track_link_kernel(const float4 *__restrict
                 if (v > bv) { bv = v; bi = b; bb = x; }
             }
         if (use_ix) {
-            scum[par ^ 1][tid] = pf0;                           // LT == 256: entries 0..255
+            if (tid < 256) scum[par ^ 1][tid] = pf0;            // entries 0..255
             if (tid < 4) scum[par ^ 1][tid == 0 ? 256 : 256 + tid] = pf1;   // 256, then xmin/scale/wmax
         }
         const int my_bi = bi;
@@ -379,12 +405,12 @@ __global__ __launch_bounds__(LT) void track_link_kernel(const float4 *__restrict
 #pragma unroll
             for (int i = 0; i < LB; ++i) nb[i] = fb2[min(tid + i * LT, B - 1)];
         }
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) {
-            const float v2 = __shfl_xor(bv, d, 64);
-            const int i2 = __shfl_xor(bi, d, 64);
-            if (i2 >= 0 && (bi < 0 || v2 > bv || (v2 == bv && i2 < bi))) { bv = v2; bi = i2; }
-        }
+        // wave argmax on the DPP network (row_shr 1/2/4/8, row_bcast 15/31: the result lands in lane 63);
+        // six ds_bpermute rounds cost ~1 800 cycles of this serial chain, measured
+        LINK_DPP_STEP(0x111, 0xf) LINK_DPP_STEP(0x112, 0xf) LINK_DPP_STEP(0x114, 0xf) LINK_DPP_STEP(0x118, 0xf)
+        LINK_DPP_STEP(0x142, 0xa) LINK_DPP_STEP(0x143, 0xc)
+        bv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bv), 63));
+        bi = __builtin_amdgcn_readlane(bi, 63);
         if (lane == 0) { sv[par][w] = bv; si[par][w] = bi; }
         if (bi >= 0 && my_bi == bi) sb[par][w] = bb;     // exactly one lane of the wave owns the winner
         __syncthreads();
