@@ -474,7 +474,13 @@ __global__ __launch_bounds__(256) void adj_build_kernel(const float4 *__restrict
 
     uint32_t deg = 0, zc = 0;
     if (v < B) {
-        for (int w = w0; w < w1; ++w) deg += __popcll(col[(int64_t)w * B]);
+        for (int wb = w0; wb < w1; wb += 8) {
+            uint64_t mm[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) mm[j] = (wb + j < w1) ? col[(int64_t)(wb + j) * B] : 0ull;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) deg += __popcll(mm[j]);
+        }
         zc = tr ? 0u : row_z[gd.box_off + v];
     }
     const uint32_t tot = deg + zc;
@@ -506,13 +512,25 @@ __global__ __launch_bounds__(256) void adj_build_kernel(const float4 *__restrict
         uint32_t p = (uint32_t)base + lofs;
         row_meta[gd.box_off + vo] = make_uint2(p, tot);
         uint32_t q = lofs;
-        for (int w = w0; w < w1; ++w) {
-            uint64_t m = col[(int64_t)w * B];
-            while (m) {
-                const int k = __ffsll((unsigned long long)m) - 1;
-                const uint16_t e = tr ? tr[w * 64 + k] : (uint16_t)(w * 64 + k);
-                if (staged) sstage[q++] = e; else adj[p++] = e;
-                m &= m - 1;
+        // words in batches of 8, all loads issued before the serial bit loops (inside the loop each
+        // load would be waited for on its own)
+        for (int wb = w0; wb < w1; wb += 8) {
+            uint64_t mm[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) mm[j] = (wb + j < w1) ? col[(int64_t)(wb + j) * B] : 0ull;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                uint64_t m = mm[j];
+                const int w = wb + j;
+                while (m) {
+                    const int k = __ffsll((unsigned long long)m) - 1;
+                    // staged slabs keep x-ranks here and are translated to box indices in the coalesced
+                    // copy-out below (256 independent gathers in flight instead of one dependent global
+                    // load per edge inside this serial bit loop)
+                    if (staged) sstage[q++] = (uint16_t)(w * 64 + k);
+                    else adj[p++] = tr ? tr[w * 64 + k] : (uint16_t)(w * 64 + k);
+                    m &= m - 1;
+                }
             }
         }
         if (zc) {  // rare: degenerate boxes.  Recompute which partners have a zero union.
@@ -527,10 +545,15 @@ __global__ __launch_bounds__(256) void adj_build_kernel(const float4 *__restrict
                 }
             }
         }
+        if (staged && (tot & 1u)) sstage[q] = 0;      // the padding entry of an odd list must be a valid rank (translated below)
     }
     if (staged) {   // one coalesced copy of the tile's slab instead of 256 interleaved 2-byte streams
         __syncthreads();
-        for (uint32_t i = tid; i < tile_total; i += 256) adj[base + i] = sstage[i];
+        if (tr) {   // (zero-union entries only exist on irregular frames, which have no x-index: tr == null)
+            for (uint32_t i = tid; i < tile_total; i += 256) adj[base + i] = tr[sstage[i]];
+        } else {
+            for (uint32_t i = tid; i < tile_total; i += 256) adj[base + i] = sstage[i];
+        }
     }
 }
 
