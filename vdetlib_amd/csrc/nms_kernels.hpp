@@ -328,8 +328,9 @@ __device__ __forceinline__ bool pred_regular(float4 br, float rarea, float4 bc, 
     const float uni = (rarea + carea) - inter;
     const float r = __builtin_fmaf(-t32, uni, inter);
     const float bnd = t32e * uni;                       // 2^-21 * t32 * uni  >> the half-ulp zone
-    border = (r < 0.0f) && (r >= -bnd);
-    return r >= 0.0f;
+    const bool p = r >= 0.0f;
+    border = !p && (r >= -bnd);                         // (r is never NaN on regular frames: !p == r < 0)
+    return p;
 }
 
 // Rows and columns are RANKS of the frame's x1-sorted order (FrameIndex::xbox); adj_build_kernel
@@ -382,7 +383,8 @@ __global__ __launch_bounds__(256) void iou_bits_sym_kernel(const float4 *__restr
         if (cols_left <= 0) break;
         const unsigned long long colvalid = cols_left >= 64 ? ~0ull : ((1ull << cols_left) - 1ull);
         uint32_t lo = 0, hi = 0, tlo = 0, thi = 0;
-        if (!tile_empty && rows_left > 0) {
+        // (same reach test per 64 x 64 block: the columns of block q start at sbox[q*64].x, sorted)
+        if (!tile_empty && rows_left > 0 && !(c > r && sbox[q * 64].x > sreach[w])) {
             bool anyb = false;
 #pragma unroll
             for (int k = 0; k < 32; ++k) {
