@@ -59,11 +59,13 @@ def main():
     ap.add_argument("--link-thres", type=float, default=0.5)
     ap.add_argument("--pool-thres", type=float, default=0.7)
     ap.add_argument("--no-link", action="store_true", help="NMS + temporal only")
+    ap.add_argument("--no-conv", action="store_true", help="skip the temporal convolution pass (temporal max-pool only)")
     ap.add_argument("--separate", action="store_true", help="vdet_nms_volume + vdet_track_volume instead of the fused call")
     ap.add_argument("--streams", type=int, default=4, help="videos in flight per GPU (one HIP stream + context each)")
     ap.add_argument("--cpu-problems", type=int, default=1200, help="(frame,class) problems timed on the CPU oracle")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
+    METRIC = "boxes/sec whole-node (NMS+temporal-conv+link), 300f\u00d710k-box synth; mAP parity"   # BASELINE.json
 
     import numpy as np
     import torch
@@ -77,6 +79,7 @@ def main():
     vdist.init(backend="nccl" if world > 1 else None, device=dev)
     F, B, C = args.frames, args.boxes, args.classes
     TOPK = 100
+    TAPS = [0.25, 0.5, 0.25]     # the temporal convolution of the score volume (stand-in for the external TCN's first layer)
 
     boxes, scores = synth_video_cuda(torch, 2000 + rank, F, B, C, dev)
     ctx = _lib.get_context(local)
@@ -112,6 +115,7 @@ def main():
                     boxes, scores, nms_thres=args.thresh, thres=args.track_thres, max_tracks=args.max_tracks,
                     link_thres=args.link_thres, cap=args.cap, sync=False, ctx=cx)
             pooled = ops.temporal_maxpool(scores, args.window, ctx=cx)
+            conv = ops.temporal_conv(scores, TAPS, bias=0.0, pad=0.0, ctx=cx) if not args.no_conv else None
             if not args.no_link:
                 det, tpool, tboxes = ops.rescore_tracks(tracks, ntracks, boxes, scores, overlap_thres=args.pool_thres,
                                                         window=args.window, sync=False, ctx=cx)
@@ -123,7 +127,7 @@ def main():
                 else:
                     top = keep_idx[:, :, :TOPK].contiguous()
                     gathered = vdist.gather_video_results([rank], top[None], torch.clamp(keep_cnt, max=TOPK)[None])
-        return keep_idx, keep_cnt, pooled, tub
+        return keep_idx, keep_cnt, pooled, tub, conv
 
     def fence():
         if world > 1:
@@ -199,6 +203,7 @@ def main():
             t1 = time.perf_counter()
             widx, wcnt = oracle.nms_volume(hb, hs, args.thresh, cap=args.cap)
             oracle.temporal_maxpool(hs, args.window)
+            wconv = None if args.no_conv else oracle.temporal_conv(hs, TAPS, 0.0, 0.0)
             cdt = time.perf_counter() - t1
             cpu_boxes = nf * B * (nc / C)
             t_nms_per_box = cdt / cpu_boxes                 # seconds per box (all C classes), NMS + TEMP
@@ -207,6 +212,11 @@ def main():
             gi = out[0][:nf, :nc].cpu().numpy()
             gc = out[1][:nf, :nc].cpu().numpy()
             parity = bool(np.array_equal(gc, wcnt) and np.array_equal(gi, widx))
+            if nf > 1:   # temporal ops: the sample's last frame sees padding instead of frame nf, so compare the frames before it
+                wpool = oracle.temporal_maxpool(hs, args.window)
+                parity = parity and bool(np.array_equal(out[2][:nf - 1, :, :nc].cpu().numpy(), wpool[:nf - 1]))
+                if wconv is not None:
+                    parity = parity and bool(np.allclose(out[4][:nf - 1, :, :nc].cpu().numpy(), wconv[:nf - 1], rtol=0, atol=1e-5))
             t_link_per_box = 0.0
             if not args.no_link:
                 # LINK on a bounded sample: the first frames of the video, one class, same options
@@ -237,11 +247,42 @@ def main():
                 t4 = time.perf_counter()
                 midx, mcnt = oracle.nms_volume(hb, hs, args.thresh, cap=args.cap, threads=nthr)
                 oracle.temporal_maxpool(hs, args.window)
+                if not args.no_conv:
+                    oracle.temporal_conv(hs, TAPS, 0.0, 0.0)
                 mdt = time.perf_counter() - t4
                 cpu_all = {"value": cpu_boxes / mdt, "unit": "boxes/s", "cores": nthr, "kind": "port",
                            "sample": "NMS+TEMP only (no LINK), same %d nms problems on %d host threads in %.2f s"
                                      % (nf * nc, nthr, mdt),
                            "parity_checked": bool(np.array_equal(midx, widx) and np.array_equal(mcnt, wcnt))}
+
+        map_par = None
+        if not args.no_cpu and not args.no_link:
+            # BASELINE "mAP parity", config 5 in miniature (the VID dataset is not available): VID-shaped
+            # synthetic annotation protos with planted objects, tubelets + re-scoring on the GPU and
+            # through the oracle, scored with the build's VOC-style evaluator
+            sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
+            import synth
+            from vdetlib_amd import eval as vev
+            gd, cd, annots = [], [], []
+            mf, mb, mc, mt = 20, 120, 5, 4
+            for seed in (51, 52, 53):
+                vb, vs, annot = synth.vid_with_objects(seed, mf, mb, mc)
+                annots.append(annot)
+                tb_, ts_ = torch.from_numpy(vb).to(dev), torch.from_numpy(vs).to(dev)
+                ctx.invalidate()
+                tr_, an_, nt_ = ops.track_volume(tb_, ts_, nms_thres=0.3, thres=0.5, max_tracks=mt, link_thres=0.4)
+                det_, pool_, ob_ = ops.rescore_tracks(tr_, nt_, tb_, ts_, overlap_thres=0.5, window=3)
+                ctx.invalidate()
+                gd += vev.detections_from_tracks(annot["video"], tr_.cpu().numpy(), nt_.cpu().numpy(), pool_.cpu().numpy(),
+                                                 ob_.cpu().numpy())
+                cd += vev.detections_from_tracks(annot["video"], *oracle.rescored_tubelets(vb, vs, 0.3, 0.5, mt, 0.4, 0.5, 3))
+            gt = vev.ground_truth_from_annots(annots)
+            aps_g, map_g = vev.evaluate(gd, gt)
+            aps_c, map_c = vev.evaluate(cd, gt)
+            map_par = {"gpu_mAP": map_g, "oracle_mAP": map_c, "identical_tubelets": bool(gd == cd),
+                       "identical_AP": bool(aps_g == aps_c and map_g == map_c),
+                       "sample": "3 synthetic VID-shaped videos x %d frames x %d proposals x %d classes with planted "
+                                 "objects; tubelets (4 tracks/class) + spatial/temporal re-scoring; VOC-style AP@0.5" % (mf, mb, mc)}
 
         pcie = None
         if not args.no_cpu:
@@ -265,19 +306,19 @@ def main():
                 pcie = {"error": str(e)[:200]}
 
         result = {
-            "metric": "boxes/sec whole-node (NMS+temporal-conv+link), 300fx10k-box synth",
+            "metric": METRIC,
             "value": boxes_per_s, "unit": "boxes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1]%s: 1 video/GPU, %d frames x %d boxes x %d classes; per-(frame,class) "
-                                   "NMS thresh %.2f + temporal max-pool w=%d%s%s" %
+            "config": {"workload": ("configs[1]%s: 1 video/GPU, %d frames x %d boxes x %d classes; per-(frame,class) "
+                                   "NMS thresh %.2f + temporal max-pool w=%d" + ("" if args.no_conv else " + 3-tap temporal convolution") + "%s%s") %
                                    ("" if args.no_link else "+[2]", F, B, C, args.thresh, args.window,
                                     "" if args.no_link else "; greedy tubelets: %d tracks/class (stop < %.2f), IoU-link "
                                     ">= %.2f, spatial max-pool IoU > %.2f + completion + temporal max-pool" %
                                     (args.max_tracks, args.track_thres, args.link_thres, args.pool_thres),
                                     "; RCCL all-gather of the final tubelets + kept counts" if world > 1 else ""),
                        "frames": F, "boxes": B, "classes": C, "parallelism": "video-per-gpu x%d, %d videos in flight per GPU" % (world, nstreams)},
-            "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_allcores": cpu_all, "pcie": pcie,
+            "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_allcores": cpu_all, "map_parity": map_par, "pcie": pcie,
         }
     if world > 1:
         dist.barrier()

@@ -416,3 +416,33 @@ def tcn_forward(x, layers):
     for c in range(x.shape[0]):
         ssum = (ssum + e[c]).astype(f)
     return (e / ssum).astype(f)
+
+
+def rescored_tubelets(boxes, scores, nms_thres, thres, max_tracks, link_thres, pool_thres, window):
+    """greedy_track_volume for every class, then raw_dets_spatial_max_pooling + do_score_completion +
+    score_proto_temporal_maxpool(window) of every tubelet (vdet/track.py:189-252,
+    vdet/tubelet_cls.py:493-535, :284-303, :386-414) -- the array form of what
+    vdet_track_volume + vdet_rescore_tracks return: tracks [C,T,F,5], ntracks [C],
+    pooled score [C,T,F] f64, regressed box [C,T,F,4] (NaN where a track has no box)."""
+    F, B, C = scores.shape
+    T = max_tracks
+    h = window // 2
+    wtr = np.full((C, T, F, 5), np.nan, np.float32)
+    wnt = np.zeros(C, np.int32)
+    wsc = np.full((C, T, F), np.nan)
+    wbx = np.full((C, T, F, 4), np.nan, np.float32)
+    for c in range(C):
+        t_, a_, n_ = greedy_track_volume(boxes, scores[:, :, c], nms_thres, thres, T, link_thres, 0)
+        wtr[c], wnt[c] = t_, n_
+        for t in range(n_):
+            fr = [f for f in range(F) if not np.isnan(t_[t, f, 0])]
+            s, bx = [], []
+            for f in fr:
+                ss, bb, _ = spatial_maxpool([t_[t, f, :4]], boxes[f], scores[f, :, c], pool_thres)
+                s.append(ss[0])
+                bx.append(bb[0])
+            comp = score_completion(s)
+            pool = [max(comp[g] if 0 <= g < len(comp) else -1e5 for g in range(i - h, i + h + 1)) for i in range(len(comp))]
+            wsc[c, t, fr] = pool
+            wbx[c, t, fr] = np.asarray(bx, np.float32)
+    return wtr, wnt, wsc, wbx

@@ -223,3 +223,31 @@ class FakeTCN(object):
         z = self.blobs['det_scores'].data.reshape(L)
         p1 = 1.0 / (1.0 + np.exp(-z))
         return {'probs': np.stack([1 - p1, p1])[None].astype(np.float32)}
+
+
+def vid_with_objects(seed, F, B, C, n_obj=3):
+    """Ground-truth objects drifting over the frames; proposals = jittered copies of the objects
+    (scored high for the object's class) + clutter."""
+    rng = np.random.RandomState(seed)
+    objs = []
+    for k in range(n_obj):
+        x, y = rng.uniform(50, 900), rng.uniform(50, 450)
+        w, h = rng.uniform(60, 250), rng.uniform(60, 220)
+        objs.append(dict(cls=int(rng.randint(1, C + 1)), box=np.array([x, y, x + w, y + h]), v=rng.uniform(-4, 4, 2)))
+    boxes = np.zeros((F, B, 4), np.float32)
+    scores = (0.05 * rng.rand(F, B, C)).astype(np.float32)
+    annot = {'video': 'syn_%d' % seed, 'annotations': []}
+    for k, o in enumerate(objs):
+        annot['annotations'].append({'id': str(k), 'track': []})
+    for f in range(F):
+        clutter_x = rng.uniform(0, 1100, B); clutter_y = rng.uniform(0, 600, B)
+        boxes[f] = np.stack([clutter_x, clutter_y, clutter_x + rng.uniform(20, 200, B), clutter_y + rng.uniform(20, 150, B)], 1)
+        for k, o in enumerate(objs):
+            gtb = np.round(o['box'] + np.tile(o['v'], 2) * f)
+            annot['annotations'][k]['track'].append({'frame': f + 1, 'bbox': [int(v) for v in gtb], 'class_index': o['cls'],
+                                                     'class': 'c%d' % o['cls']})
+            for j in range(6):                                   # 6 jittered proposals per object
+                b = k * 6 + j
+                boxes[f, b] = gtb + rng.randint(-6, 7, 4)
+                scores[f, b, o['cls'] - 1] = 0.6 + 0.39 * rng.rand()
+    return np.round(boxes).astype(np.float32), scores, annot
