@@ -114,8 +114,11 @@ def main():
                 keep_idx, keep_cnt, tracks, anchors, ntracks = ops.nms_track_volume(
                     boxes, scores, nms_thres=args.thresh, thres=args.track_thres, max_tracks=args.max_tracks,
                     link_thres=args.link_thres, cap=args.cap, sync=False, ctx=cx)
-            pooled = ops.temporal_maxpool(scores, args.window, ctx=cx)
-            conv = ops.temporal_conv(scores, TAPS, bias=0.0, pad=0.0, ctx=cx) if not args.no_conv else None
+            if args.no_conv or args.window != len(TAPS):
+                pooled = ops.temporal_maxpool(scores, args.window, ctx=cx)
+                conv = None if args.no_conv else ops.temporal_conv(scores, TAPS, bias=0.0, pad=0.0, ctx=cx)
+            else:   # both temporal operators from one read of the volume
+                pooled, conv = ops.temporal_maxpool_conv(scores, args.window, TAPS, ctx=cx)
             if not args.no_link:
                 det, tpool, tboxes = ops.rescore_tracks(tracks, ntracks, boxes, scores, overlap_thres=args.pool_thres,
                                                         window=args.window, sync=False, ctx=cx)
@@ -188,7 +191,9 @@ def main():
                     "stages": stages}
         # the temporal kernel is the one genuinely HBM-bound stage: report its own stream rate too
         if "temporal" in stages:
-            tb = 8.0 * F * B * C                          # read 4 B + write 4 B per element
+            fused_t = (not args.no_conv) and args.window == len(TAPS)
+            # max-pool alone: read 4 B + write 4 B per element; fused with the convolution: read 4 + write 8
+            tb = (12.0 if fused_t else 8.0) * F * B * C
             roofline["temporal_GBps"] = tb / (stages["temporal"]["avg_launch_ms"] * 1e-3) / 1e9
 
         cpu = None

@@ -212,6 +212,12 @@ int vdet_temporal_maxpool_f32(vdet_ctx *ctx, const float *d_in, float *d_out, in
 int vdet_temporal_conv_f32(vdet_ctx *ctx, const float *d_in, float *d_out, int64_t F, int64_t S,
                            const float *h_taps, int K, float bias, float pad);
 
+/* Both temporal operators of one volume in one pass (the volume is read once): d_out_max as
+ * vdet_temporal_maxpool_f32(window, pad_max), d_out_conv as vdet_temporal_conv_f32(h_taps[window],
+ * bias, pad_conv).  Bit-identical to the two separate calls. */
+int vdet_temporal_maxpool_conv_f32(vdet_ctx *ctx, const float *d_in, float *d_out_max, float *d_out_conv, int64_t F,
+                                   int64_t S, int window, float pad_max, const float *h_taps, float bias, float pad_conv);
+
 /*
  * Greedy tubelet generation for every class of a score volume, device-resident: the array form of
  * greedily_track_from_raw_dets (vdet/track.py:189-252) with the built-in IoU-linking tracker as

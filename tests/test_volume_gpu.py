@@ -120,6 +120,25 @@ def test_temporal_conv(torch_cuda, oracle):
         assert np.allclose(got, want, rtol=0, atol=1e-5)  # north-star tolerance for float scores
 
 
+def test_temporal_maxpool_conv_fused(torch_cuda, oracle):
+    """One pass producing both temporal operators == the two separate passes == the oracle."""
+    torch = torch_cuda
+    from vdetlib_amd import ops
+    rng = np.random.RandomState(5)
+    for shape, w in (((9, 40, 12), 3), ((16, 7, 5), 3), ((11, 64, 8), 5), ((4, 32, 4), 7), ((1, 8, 4), 3)):
+        vol = (rng.randn(*shape) * 3).astype(np.float32)
+        vol[rng.rand(*shape) < 0.01] = np.nan
+        taps = rng.randn(w).astype(np.float32)
+        tv = torch.from_numpy(vol).cuda()
+        pm, pc = ops.temporal_maxpool_conv(tv, w, taps, pad_max=-1e5, bias=0.25, pad_conv=0.5)
+        m0 = ops.temporal_maxpool(tv, w)
+        c0 = ops.temporal_conv(tv, taps, bias=0.25, pad=0.5)
+        assert np.array_equal(pm.cpu().numpy(), m0.cpu().numpy(), equal_nan=True)
+        assert np.array_equal(pc.cpu().numpy(), c0.cpu().numpy(), equal_nan=True)
+        assert np.array_equal(pm.cpu().numpy(), oracle.temporal_maxpool(vol, w), equal_nan=True)
+        assert np.allclose(pc.cpu().numpy(), oracle.temporal_conv(vol, taps, 0.25, 0.5), rtol=0, atol=1e-5, equal_nan=True)
+
+
 def test_volume_edge_shapes(torch_cuda, oracle):
     """Empty / minimal / ragged-in-content inputs of the device-resident entry points."""
     torch = torch_cuda

@@ -46,6 +46,7 @@ SYMBOLS = {
     "vdet_rescore_tracks": (_ci, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _ci, _f64, _ci, _vp, _vp, _vp]),
     "vdet_temporal_maxpool_f32": (_ci, [_vp, _vp, _vp, _i64, _i64, _ci, _f32]),
     "vdet_temporal_conv_f32": (_ci, [_vp, _vp, _vp, _i64, _i64, _vp, _ci, _f32, _f32]),
+    "vdet_temporal_maxpool_conv_f32": (_ci, [_vp, _vp, _vp, _vp, _i64, _i64, _ci, _f32, _vp, _f32, _f32]),
 }
 
 _lib = None

@@ -1431,4 +1431,42 @@ int vdet_temporal_conv_f32(vdet_ctx *c, const float *d_in, float *d_out, int64_t
     return temporal_launch(c, 1, d_in, d_out, F, S, K, pad, bias, taps);
 }
 
+int vdet_temporal_maxpool_conv_f32(vdet_ctx *c, const float *d_in, float *d_out_max, float *d_out_conv, int64_t F, int64_t S,
+                                   int window, float pad_max, const float *h_taps, float bias, float pad_conv)
+{
+    if (!c) return VDET_EINVAL;
+    if (window < 1 || window % 2 != 1) return fail(c, VDET_EINVAL, "Window size must be odd!");
+    if (window > 31 || !h_taps) return fail(c, VDET_EINVAL, "taps: K must be odd and <= 31");
+    if (F < 0 || S < 0 || F * S > ((int64_t)1 << 40) ||
+        (F * S > 0 && (!d_in || !d_out_max || !d_out_conv || d_in == d_out_max || d_in == d_out_conv || d_out_max == d_out_conv)))
+        return fail(c, VDET_EINVAL, "bad temporal_maxpool_conv arguments");
+    if (F == 0 || S == 0) return VDET_OK;
+    const bool vec = (S % 4 == 0) && (((uintptr_t)d_in | (uintptr_t)d_out_max | (uintptr_t)d_out_conv) & 15) == 0 &&
+                     (window == 3 || window == 5 || window == 7);
+    if (!vec) {   // shapes the fused kernel does not cover: the two passes
+        int rc = vdet_temporal_maxpool_f32(c, d_in, d_out_max, F, S, window, pad_max);
+        if (rc) return rc;
+        return vdet_temporal_conv_f32(c, d_in, d_out_conv, F, S, h_taps, window, bias, pad_conv);
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    timing_reset(c);
+    Taps taps{};
+    for (int k = 0; k < window; ++k) taps.w[k] = h_taps[k];
+    StageTimer tm(c, ST_TEMPORAL);
+    const int64_t S4 = S / 4;
+    const unsigned gx = (unsigned)((S4 + 255) / 256);
+    int64_t chunks = 1;
+    if ((int64_t)gx < 4 * c->n_cu) chunks = std::min<int64_t>(std::max<int64_t>(F / 16, 1), (4 * c->n_cu + gx - 1) / gx);
+    chunks = std::min<int64_t>(chunks, 65535);
+    const int64_t fchunk = (F + chunks - 1) / chunks;
+    const dim3 grid(gx, (unsigned)((F + fchunk - 1) / fchunk));
+    const float4 *in4 = reinterpret_cast<const float4 *>(d_in);
+    float4 *om = reinterpret_cast<float4 *>(d_out_max), *oc = reinterpret_cast<float4 *>(d_out_conv);
+#define VDET_TB(WW) hipLaunchKernelGGL((temporal_both_vec4_kernel<WW>), grid, dim3(256), 0, c->stream, in4, om, oc, F, S4, fchunk, pad_max, pad_conv, bias, taps)
+    if (window == 3) VDET_TB(3); else if (window == 5) VDET_TB(5); else VDET_TB(7);
+#undef VDET_TB
+    HIPCHK(c, hipGetLastError());
+    return VDET_OK;
+}
+
 }  // extern "C"

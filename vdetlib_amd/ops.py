@@ -99,6 +99,26 @@ def temporal_conv(vol, taps, bias=0.0, pad=0.0, ctx=None):
     return out
 
 
+def temporal_maxpool_conv(vol, window, taps, pad_max=-1e5, bias=0.0, pad_conv=0.0, ctx=None):
+    """``temporal_maxpool(vol, window, pad_max)`` and ``temporal_conv(vol, taps, bias, pad_conv)`` (len(taps) ==
+    window) in one pass over the volume (it is read once; the pass is HBM-bound).  Returns (pooled, conv)."""
+    if window % 2 != 1:
+        raise ValueError('Window size must be odd!')
+    if vol.dtype != torch.float32:
+        raise ValueError("Buffer dtype mismatch, expected 'float32_t'")
+    t = np.ascontiguousarray(taps, dtype=np.float32)
+    if t.shape[0] != window:
+        raise ValueError('need one tap per window position')
+    vol = vol.contiguous()
+    out_m, out_c = torch.empty_like(vol), torch.empty_like(vol)
+    F = vol.shape[0]
+    S = vol.numel() // F if F else 0
+    ctx = _ctx_for(vol, ctx)
+    ctx.check(ctx.lib.vdet_temporal_maxpool_conv_f32(ctx.h, vol.data_ptr(), out_m.data_ptr(), out_c.data_ptr(), F, S,
+                                                     int(window), float(pad_max), t.ctypes.data, float(bias), float(pad_conv)))
+    return out_m, out_c
+
+
 def iou(boxes1, boxes2):
     """utils/common.py:451-468 -- float64 IoU matrix [n1,n2] (+1 convention), numpy in / numpy out."""
     b1 = np.ascontiguousarray(np.asarray(boxes1).astype('float'))
