@@ -223,3 +223,73 @@ def test_track_volume_full_size_properties(monkeypatch):
     tr2, an2, nt2 = ops.track_volume(boxes, scores, nms_thres=0.3, thres=0.9, max_tracks=T, link_thres=0.5, ctx=cx)
     assert torch.equal(nt, nt2) and torch.equal(an, an2)
     assert np.array_equal(t, tr2.cpu().numpy(), equal_nan=True)
+
+
+def _random_case(seed):
+    """Small adversarial videos: integer boxes on a coarse grid (duplicates, exact-IoU ties, nested
+    boxes), quantised scores (score ties), occasionally a degenerate box (irregular frame)."""
+    rng = np.random.RandomState(1000 + seed)
+    F, B, C = int(rng.randint(2, 9)), int(rng.randint(4, 70)), int(rng.randint(1, 4))
+    grid = int(rng.choice([4, 8, 16]))
+    x1 = rng.randint(0, 12, (F, B)) * grid
+    y1 = rng.randint(0, 8, (F, B)) * grid
+    w = rng.randint(1, 5, (F, B)) * grid
+    h = rng.randint(1, 5, (F, B)) * grid
+    boxes = np.stack([x1, y1, x1 + w - 1, y1 + h - 1], -1).astype(np.float32)
+    if seed % 3 == 0:
+        boxes += rng.rand(F, B, 4).astype(np.float32)             # fractional coordinates: truncation matters
+    scores = rng.rand(F, B, C).astype(np.float32)
+    if seed % 2 == 0:
+        scores = (np.round(scores * 6) / 6).astype(np.float32)    # score ties
+    if seed % 5 == 4:
+        f, b = int(rng.randint(F)), int(rng.randint(B))
+        boxes[f, b] = [30, 30, 29, 40]                            # zero width: that frame is irregular
+        scores[f, b] = 0.01                                       # (low score: rarely evaluated against its twin)
+    if seed % 10 == 9 and B >= 2:
+        f = int(rng.randint(F))
+        boxes[f, 0] = boxes[f, 1] = [30, 30, 29, 40]              # degenerate twins: their union is zero
+        scores[f, 0] = scores[f, 1] = 0.99                        # ... and they are evaluated early
+    opts = dict(nms_thres=float(rng.choice([0.3, 0.5])), thres=float(rng.choice([0.0, 0.3, 0.7])),
+                max_tracks=int(rng.randint(1, 7)), link_thres=float(rng.choice([0.3, 0.5, 0.7])),
+                max_frames=int(rng.choice([0, 0, 3, 4])))
+    return boxes, scores, opts
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_track_volume_random_sweep(oracle, seed):
+    import torch
+    from vdetlib_amd import ops
+    boxes, scores, o = _random_case(seed)
+    F, B, C = scores.shape
+    want, werr = [], None
+    try:
+        for c in range(C):
+            want.append(oracle.greedy_track_volume(boxes, scores[:, :, c], o['nms_thres'], o['thres'], o['max_tracks'],
+                                                   o['link_thres'], o['max_frames']))
+    except ZeroDivisionError as e:
+        werr = e
+    tb, ts = torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda()
+    try:
+        ki, kc, tr, an, nt = ops.nms_track_volume(tb, ts, **o)
+        gerr = None
+    except ZeroDivisionError as e:
+        gerr = e
+    if werr is not None or gerr is not None:
+        # the reference raises only for zero-union pairs it evaluates; which class trips first is an
+        # ordering detail of the host loop, but whether ANY evaluation trips must agree -- unless the
+        # NMS by-product (not part of the oracle's tracking loop) is what raised
+        nms_raises = False
+        try:
+            oracle.nms_volume(boxes, scores, o['nms_thres'])
+        except ZeroDivisionError:
+            nms_raises = True
+        assert (gerr is not None) == (werr is not None or nms_raises), (werr, gerr)
+        return
+    trn, ann, ntn = tr.cpu().numpy(), an.cpu().numpy(), nt.cpu().numpy()
+    for c in range(C):
+        wt, wa, wn = want[c]
+        assert ntn[c] == wn, (c, ntn[c], wn)
+        assert np.array_equal(ann[c, :wn], wa[:wn]), c
+        assert np.array_equal(trn[c, :wn], wt[:wn], equal_nan=True), c
+    widx, wcnt = oracle.nms_volume(boxes, scores, o['nms_thres'])
+    assert np.array_equal(kc.cpu().numpy(), wcnt) and np.array_equal(ki.cpu().numpy(), widx)
