@@ -124,12 +124,14 @@ def main():
                                                         window=args.window, sync=False, ctx=cx)
                 tub = (tracks, ntracks, tpool, tboxes)
             if world > 1:   # the one exchange step: RCCL all-gather of the per-video results over xGMI
+                # (same geometry on every rank: one fixed-shape collective per tensor, nothing the host
+                # has to wait for -- a count exchange would stall the multi-video pipeline)
                 if tub is not None:
                     payload = torch.cat([tub[3].reshape(C, -1), tub[2].to(torch.float32).reshape(C, -1)], 1)
-                    gathered = (vdist.all_gather_ragged(payload[None]), vdist.all_gather_ragged(keep_cnt[None]))
+                    gathered = (vdist.all_gather_fixed(payload), vdist.all_gather_fixed(keep_cnt))
                 else:
                     top = keep_idx[:, :, :TOPK].contiguous()
-                    gathered = vdist.gather_video_results([rank], top[None], torch.clamp(keep_cnt, max=TOPK)[None])
+                    gathered = (vdist.all_gather_fixed(top), vdist.all_gather_fixed(torch.clamp(keep_cnt, max=TOPK)))
         return keep_idx, keep_cnt, pooled, tub, conv
 
     def fence():

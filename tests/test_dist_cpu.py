@@ -46,6 +46,10 @@ def _worker(rank, world, port, n_videos, ret):
     t = torch.arange(rank * 3, dtype=torch.float32).reshape(-1, 1)
     parts = vd.all_gather_ragged(t)
     ok = ok and [p.shape[0] for p in parts] == [r_ * 3 for r_ in range(world)]
+    # fixed-shape gather (what bench.py --gpus N uses: one collective, no count exchange / host sync)
+    fx = torch.full((2, 3), float(rank), dtype=torch.float32)
+    g = vd.all_gather_fixed(fx)
+    ok = ok and tuple(g.shape) == (world, 2, 3) and all(bool((g[r_] == float(r_)).all()) for r_ in range(world))
     ret[rank] = bool(ok)
     dist.barrier()
     dist.destroy_process_group()

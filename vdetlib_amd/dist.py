@@ -68,6 +68,18 @@ def all_gather_ragged(t, group=None):
     return [out[r * cap:r * cap + counts[r]] for r in range(world)]
 
 
+def all_gather_fixed(t, group=None):
+    """All-gather of same-shape tensors (every rank holds one video of the same geometry): ONE
+    collective, no count exchange and therefore no host synchronisation -- the call only enqueues, so
+    a rank can keep several videos in flight on different streams.  Returns [world, *t.shape]."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return t[None]
+    world = dist.get_world_size(group)
+    out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, t.contiguous(), group=group)
+    return out
+
+
 def gather_video_results(video_ids, keep_idx, keep_cnt, group=None):
     """Combine per-video NMS results across ranks.
 
