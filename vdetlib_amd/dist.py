@@ -75,9 +75,13 @@ def all_gather_fixed(t, group=None):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return t[None]
     world = dist.get_world_size(group)
-    out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-    dist.all_gather_into_tensor(out, t.contiguous(), group=group)
-    return out
+    t = t.contiguous()
+    if t.dim() == 0:
+        t = t[None]
+    # concatenated layout along dim 0 (accepted by both RCCL and gloo), viewed as [world, ...]
+    out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, t, group=group)
+    return out.view((world,) + tuple(t.shape))
 
 
 def gather_video_results(video_ids, keep_idx, keep_cnt, group=None):
