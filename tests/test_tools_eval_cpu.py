@@ -89,3 +89,59 @@ def test_average_precision_evaluator():
     assert np.isnan(vev.average_precision([], 0))
     sp = {'video': 'v', 'tubelets': [{'class_index': 1, 'boxes': [{'frame': 1, 'bbox': [10, 10, 60, 60], 'det_score': .5}]}]}
     assert vev.detections_from_score_protos([sp]) == [('v', 1, 1, [10, 10, 60, 60], .5)]
+
+
+def _pb_varint(v):
+    out = bytearray()
+    while True:
+        b = v & 0x7F
+        v >>= 7
+        if v:
+            out.append(b | 0x80)
+        else:
+            out.append(b)
+            return bytes(out)
+
+
+def _pb_len(fn, payload):
+    return _pb_varint((fn << 3) | 2) + _pb_varint(len(payload)) + payload
+
+
+def _pb_blob(arr, legacy=False):
+    arr = np.asarray(arr, dtype='<f4')
+    data = _pb_len(5, arr.tobytes())
+    if legacy:
+        dims = list(arr.shape) + [1] * (4 - arr.ndim)
+        head = b''.join(_pb_varint((k << 3) | 0) + _pb_varint(d) for k, d in zip((1, 2, 3, 4), dims))
+        return head + data
+    shape = _pb_len(1, b''.join(_pb_varint(d) for d in arr.shape))
+    return _pb_len(7, shape) + data
+
+
+def test_caffemodel_to_npz_roundtrip(tmp_path):
+    """A hand-encoded NetParameter (new-style `layer` and V1 `layers` entries, packed blobs, legacy
+    num/channels/height/width shapes) -> npz -> TCNNet weights."""
+    from vdetlib_amd.tools import caffemodel_to_npz as c2n
+    rng = np.random.RandomState(0)
+    w0 = rng.randn(8, 6, 1, 3).astype(np.float32); b0 = rng.randn(8).astype(np.float32)
+    w1 = rng.randn(2, 8, 5, 1).astype(np.float32); b1 = rng.randn(2).astype(np.float32)
+    layer0 = _pb_len(1, b'conv1') + _pb_len(2, b'Convolution') + _pb_len(7, _pb_blob(w0)) + _pb_len(7, _pb_blob(b0))
+    relu = _pb_len(1, b'relu1') + _pb_len(2, b'ReLU')
+    layer1_v1 = _pb_len(4, b'conv2') + _pb_len(6, _pb_blob(w1, legacy=True)) + _pb_len(6, _pb_blob(b1.reshape(1, 1, 1, 2), legacy=True))
+    net = _pb_len(1, b'tcn') + _pb_len(100, layer0) + _pb_len(100, relu) + _pb_len(2, layer1_v1)
+    src = tmp_path / 'tcn.caffemodel'
+    src.write_bytes(net)
+    dst = tmp_path / 'tcn.npz'
+    layers = c2n.convert(str(src), str(dst))
+    assert len(layers) == 2
+    assert np.array_equal(layers[0][0], w0.reshape(8, 6, 3)) and np.array_equal(layers[0][1], b0)
+    assert np.array_equal(layers[1][0], w1.reshape(2, 8, 5)) and np.array_equal(layers[1][1], b1)
+    z = np.load(str(dst))
+    assert sorted(z.files) == ['b0', 'b1', 'w0', 'w1']
+    assert c2n.main([str(src), str(dst)]) == 0
+    from vdetlib_amd.vdet.tcn import TCNNet
+    net2 = TCNNet.from_npz([('det_scores', 1), ('track_scores', 1), ('anchors', 1), ('abs_anchors', 1), ('gt_overlaps', 1),
+                            ('labels', 1)], str(dst))
+    assert [w.shape for w, _ in net2.layers] == [(8, 6, 3), (2, 8, 5)]
+    net2.save_npz(str(tmp_path / 'again.npz'))
+    assert np.array_equal(np.load(str(tmp_path / 'again.npz'))['w1'], w1.reshape(2, 8, 5))

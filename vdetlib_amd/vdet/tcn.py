@@ -54,6 +54,24 @@ class TCNNet(object):
             cin = cout
         return TCNNet(inputs, layers)
 
+    @staticmethod
+    def from_npz(inputs, path):
+        """Weights saved as ``w0, b0, w1, b1, ...`` (e.g. by vdetlib_amd.tools.caffemodel_to_npz)."""
+        z = np.load(path)
+        layers = []
+        i = 0
+        while 'w%d' % i in z.files:
+            layers.append((z['w%d' % i], z['b%d' % i]))
+            i += 1
+        return TCNNet(inputs, layers)
+
+    def save_npz(self, path):
+        arrs = {}
+        for i, (w, b) in enumerate(self.layers):
+            arrs['w%d' % i] = w
+            arrs['b%d' % i] = b
+        np.savez(path, **arrs)
+
     def forward(self):
         L = self.blobs[self.inputs[0][0]].shape[3]
         x = np.concatenate([np.asarray(self.blobs[n].data, dtype=np.float32).reshape(c, L) for n, c in self.inputs], 0)
