@@ -214,3 +214,22 @@ def test_tcn_net_with_score_conv_cls(oracle, proto_golden):
         assert got.shape == want.shape and np.allclose(got, want, rtol=0, atol=1e-5)
     with pytest.raises(ValueError):
         TCNNet([('det_scores', 1)], [(np.zeros((3, 1, 3), np.float32), np.zeros(3, np.float32))])
+
+
+def test_svm_scores_matches_numpy():
+    """vdet/image_det.py:109-114 (the one dense contraction of the path) on the GPU GEMM vs numpy."""
+    from vdetlib_amd.vdet import image_det as I
+    rng = np.random.RandomState(4)
+    feats = rng.randn(257, 1024, 1, 1).astype(np.float32)
+    model = {'feat_norm_mean': np.array([[19.3]]), 'W': rng.randn(1024, 200) * 0.01, 'B': rng.randn(1, 200)}
+    got = I.svm_scores(feats, model)
+    f = np.squeeze(feats, axis=(2, 3)) * (20. / model['feat_norm_mean'])
+    want = np.dot(f, model['W']) + model['B']
+    assert got.dtype == want.dtype and got.shape == want.shape
+    assert np.allclose(got, want, rtol=1e-9, atol=1e-9)
+    model32 = {'feat_norm_mean': np.float32(19.3), 'W': (rng.randn(1024, 200) * 0.01).astype(np.float32),
+               'B': rng.randn(200).astype(np.float32)}
+    got32 = I.svm_scores(feats[:, :, 0, 0], model32)
+    want32 = np.dot(feats[:, :, 0, 0] * (20. / model32['feat_norm_mean']), model32['W']) + model32['B']
+    assert got32.dtype == want32.dtype
+    assert np.allclose(got32, want32, rtol=1e-5, atol=1e-5)      # float scores: the 1e-5 bar of BASELINE.json
