@@ -333,10 +333,109 @@ __device__ __forceinline__ bool pred_regular(float4 br, float rarea, float4 bc, 
     return p;
 }
 
+// ------------------------------------------------------------------------------------------------
+// 64 x 64 bit-matrix transpose inside one wave: lane j holds row j as (lo, hi); afterwards lane k
+// holds column k.  Six butterfly stages (distance 32, 16, 8, 4, 2, 1), each exchanging the
+// off-diagonal blocks of every 2k x 2k sub-matrix between lane pairs (j, j ^ k):
+//   32: v_permlane32_swap   lanes 32..63 of lo  <->  lanes 0..31 of hi       (gfx950)
+//   16: v_permlane16_swap + a byte permute        8: DPP row_ror:8 + a byte permute
+//   4 / 2 / 1: DPP (row_shl/shr:4, quad_perm) + rotate + bit-field insert
+// ~31 VALU instructions instead of the 128 v_writelanes (plus their hazard nops) of building the
+// transposed words from 64 ballots.  The lane-exchange semantics are verified on the device at
+// vdet_create (wave_transpose_probe); K1s falls back to the ballot form if that ever fails.
+// ------------------------------------------------------------------------------------------------
+struct TransposeConsts {     // per lane, computed once per kernel
+    uint32_t sel16, sel8;    // v_perm_b32 selectors
+    uint32_t sh4, m4, sh2, m2, sh1, m1;
+};
+
+__device__ __forceinline__ TransposeConsts transpose_consts(int lane)
+{
+    TransposeConsts t;
+    // v_perm_b32 D = perm(S0, S1, sel): selector byte 0-3 -> S1.byte, 4-7 -> S0.byte
+    t.sel16 = (lane & 16) ? 0x03020706u : 0x01000504u;   // S0 = r0, S1 = r1 (see stage 16)
+    t.sel8 = (lane & 8) ? 0x03070105u : 0x06020400u;     // S0 = partner, S1 = own
+    t.sh4 = (lane & 4) ? 4u : 28u;  t.m4 = (lane & 4) ? 0xF0F0F0F0u : 0x0F0F0F0Fu;
+    t.sh2 = (lane & 2) ? 2u : 30u;  t.m2 = (lane & 2) ? 0xCCCCCCCCu : 0x33333333u;
+    t.sh1 = (lane & 1) ? 1u : 31u;  t.m1 = (lane & 1) ? 0xAAAAAAAAu : 0x55555555u;
+    return t;
+}
+
+__device__ __forceinline__ uint32_t transpose_stage_small(uint32_t r, uint32_t partner, uint32_t sh, uint32_t m)
+{
+    // upper lane of the pair keeps its bits at positions with the stage bit clear and takes the partner's
+    // (shifted up); the lower lane the mirror image: one rotate + one bit-field insert
+    const uint32_t rot = __builtin_amdgcn_alignbit(partner, partner, sh);
+    return (r & m) | (rot & ~m);
+}
+
+__device__ __forceinline__ void wave_transpose64(uint32_t &lo, uint32_t &hi, const TransposeConsts &t)
+{
+    {   // 32: upper lanes' hi <-> lower lanes' lo
+        const auto r = __builtin_amdgcn_permlane32_swap(lo, hi, false, false);
+        lo = r[0]; hi = r[1];
+    }
+    {   // 16 (per 32-bit register): r0 = {own on even rows, partner on odd rows}, r1 the converse
+        auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        lo = __builtin_amdgcn_perm(a[0], a[1], t.sel16);
+        auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        hi = __builtin_amdgcn_perm(b[0], b[1], t.sel16);
+    }
+    {   // 8: partner = lane ^ 8 = row_ror:8
+        const uint32_t pl = __builtin_amdgcn_update_dpp(0u, lo, 0x128, 0xf, 0xf, false);
+        const uint32_t ph = __builtin_amdgcn_update_dpp(0u, hi, 0x128, 0xf, 0xf, false);
+        lo = __builtin_amdgcn_perm(pl, lo, t.sel8);
+        hi = __builtin_amdgcn_perm(ph, hi, t.sel8);
+    }
+    {   // 4: partner = lane ^ 4: row_shl:4 into banks 0,2 and row_shr:4 into banks 1,3
+        uint32_t pl = __builtin_amdgcn_update_dpp(0u, lo, 0x104, 0xf, 0x5, false);
+        pl = __builtin_amdgcn_update_dpp(pl, lo, 0x114, 0xf, 0xa, false);
+        uint32_t ph = __builtin_amdgcn_update_dpp(0u, hi, 0x104, 0xf, 0x5, false);
+        ph = __builtin_amdgcn_update_dpp(ph, hi, 0x114, 0xf, 0xa, false);
+        lo = transpose_stage_small(lo, pl, t.sh4, t.m4);
+        hi = transpose_stage_small(hi, ph, t.sh4, t.m4);
+    }
+    {   // 2: quad_perm [2,3,0,1]
+        const uint32_t pl = __builtin_amdgcn_update_dpp(0u, lo, 0x4E, 0xf, 0xf, false);
+        const uint32_t ph = __builtin_amdgcn_update_dpp(0u, hi, 0x4E, 0xf, 0xf, false);
+        lo = transpose_stage_small(lo, pl, t.sh2, t.m2);
+        hi = transpose_stage_small(hi, ph, t.sh2, t.m2);
+    }
+    {   // 1: quad_perm [1,0,3,2]
+        const uint32_t pl = __builtin_amdgcn_update_dpp(0u, lo, 0xB1, 0xf, 0xf, false);
+        const uint32_t ph = __builtin_amdgcn_update_dpp(0u, hi, 0xB1, 0xf, 0xf, false);
+        lo = transpose_stage_small(lo, pl, t.sh1, t.m1);
+        hi = transpose_stage_small(hi, ph, t.sh1, t.m1);
+    }
+}
+
+// self-test of wave_transpose64: n matrices of 64 x u64 in, transposed out (compared on the host)
+__global__ __launch_bounds__(64) void wave_transpose_probe(const uint64_t *__restrict__ in, uint64_t *__restrict__ out, int n)
+{
+    const int lane = threadIdx.x;
+    const TransposeConsts tc = transpose_consts(lane);
+    for (int t = blockIdx.x; t < n; t += gridDim.x) {
+        const uint64_t v = in[(size_t)t * 64 + lane];
+        uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+        wave_transpose64(lo, hi, tc);
+        out[(size_t)t * 64 + lane] = ((uint64_t)hi << 32) | lo;
+    }
+}
+
+// acc = (acc << 1) | p in ONE VALU instruction: add-with-carry of acc to itself, the carry-in being the
+// compare's own lane mask (instead of v_cndmask + v_or per pair)
+__device__ __forceinline__ void shl1_or_pred(uint32_t &acc, bool p)
+{
+    const unsigned long long m = __ballot(p);
+    unsigned long long carry_out;
+    asm("v_addc_co_u32_e64 %0, %1, %0, %0, %2" : "+v"(acc), "=s"(carry_out) : "s"(m));
+}
+
 // Rows and columns are RANKS of the frame's x1-sorted order (FrameIndex::xbox); adj_build_kernel
 // translates back to box indices.  A tile pair whose columns all start to the right of every row's
 // IoU >= t reach (x1 + (1-t) * w, the same necessary condition as xwindow) is all-zero and is
 // written as such without evaluating a single pair: ~2.8x fewer pair tests at B = 10k.
+template <bool WT>
 __global__ __launch_bounds__(256) void iou_bits_sym_kernel(const float4 *__restrict__ xbox,
                                                            const GroupDesc *__restrict__ groups,
                                                            const uint32_t *__restrict__ group_flags,
@@ -354,6 +453,7 @@ __global__ __launch_bounds__(256) void iou_bits_sym_kernel(const float4 *__restr
     const int r = tp.rt * 4 + w;                 // word-row of this wave
     const int v = r * 64 + lane;                 // my row (rank)
     const float t32e = t32 * 4.76837158203125e-7f;   // 2^-21
+    const TransposeConsts tcs = transpose_consts(lane);
 
     float4 br = make_float4(0.f, 0.f, 0.f, 0.f);
     if (v < B) br = xbox[gd.box_off + v];
@@ -387,24 +487,30 @@ __global__ __launch_bounds__(256) void iou_bits_sym_kernel(const float4 *__restr
         if (!tile_empty && rows_left > 0 && !(c > r && sbox[q * 64].x > sreach[w])) {
             bool anyb = false;
 #pragma unroll
-            for (int k = 0; k < 32; ++k) {
+            for (int kk = 0; kk < 32; ++kk) {
+                const int k = 31 - kk;      // descending: acc = 2*acc + p (one v_addc) leaves column k in bit k
                 bool border;
                 const bool p = pred_regular(br, rarea, sbox[q * 64 + k], sarea[q * 64 + k], t32, t32e, border);
                 anyb |= border;
-                lo |= p ? (1u << k) : 0u;
-                const unsigned long long b = __ballot(p);
-                tlo = (lane == k) ? (uint32_t)b : tlo;
-                thi = (lane == k) ? (uint32_t)(b >> 32) : thi;
+                shl1_or_pred(lo, p);
+                if (!WT) {
+                    const unsigned long long b = __ballot(p);
+                    tlo = (lane == k) ? (uint32_t)b : tlo;
+                    thi = (lane == k) ? (uint32_t)(b >> 32) : thi;
+                }
             }
 #pragma unroll
-            for (int k = 0; k < 32; ++k) {
+            for (int kk = 0; kk < 32; ++kk) {
+                const int k = 31 - kk;
                 bool border;
                 const bool p = pred_regular(br, rarea, sbox[q * 64 + 32 + k], sarea[q * 64 + 32 + k], t32, t32e, border);
                 anyb |= border;
-                hi |= p ? (1u << k) : 0u;
-                const unsigned long long b = __ballot(p);
-                tlo = (lane == 32 + k) ? (uint32_t)b : tlo;
-                thi = (lane == 32 + k) ? (uint32_t)(b >> 32) : thi;
+                shl1_or_pred(hi, p);
+                if (!WT) {
+                    const unsigned long long b = __ballot(p);
+                    tlo = (lane == 32 + k) ? (uint32_t)b : tlo;
+                    thi = (lane == 32 + k) ? (uint32_t)(b >> 32) : thi;
+                }
             }
             if (__builtin_expect(__ballot(anyb) != 0ull, 0)) {
                 // rare (~1e-6 of the pairs sit in the half-ulp band, e.g. IoU exactly 3/10):
@@ -413,9 +519,15 @@ __global__ __launch_bounds__(256) void iou_bits_sym_kernel(const float4 *__restr
                 for (int k = 0; k < 64; ++k) {
                     const bool p = pair_pred_exact_slow(br, rarea, sbox[q * 64 + k], sarea[q * 64 + k], t32);
                     if (k < 32) lo |= p ? (1u << k) : 0u; else hi |= p ? (1u << (k - 32)) : 0u;
-                    const unsigned long long b = __ballot(p);
-                    if (lane == k) { tlo = (uint32_t)b; thi = (uint32_t)(b >> 32); }
+                    if (!WT) {
+                        const unsigned long long b = __ballot(p);
+                        if (lane == k) { tlo = (uint32_t)b; thi = (uint32_t)(b >> 32); }
+                    }
                 }
+            }
+            if (WT && c > r) {   // the transposed block from the row-major words, on the lane-exchange network
+                tlo = lo; thi = hi;
+                wave_transpose64(tlo, thi, tcs);
             }
         }
         unsigned long long m = (((unsigned long long)hi << 32) | lo) & colvalid;

@@ -91,6 +91,7 @@ struct vdet_ctx {
     bool graph_valid = false, lists_valid = false;
     bool index_valid = false; const void *index_boxes = nullptr; int64_t index_F = 0, index_B = 0;
     bool all_regular = false;     // last graph build: every frame regular
+    bool wave_transpose = false;  // wave_transpose64 verified on this device (vdet_create); VDET_WAVE_TRANSPOSE=0 disables
     bool debug_sync = false;      // VDET_DEBUG_SYNC=1: synchronise + report after every tracking kernel
     bool no_lazy = false;         // VDET_NO_LAZY=1: eager track_det_nms of every crossed list (tests / A-B)
     bool no_index = false;        // VDET_NO_INDEX=1: disable the x-sorted proposal index (tests / A-B)
@@ -310,9 +311,14 @@ int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32, doub
             if (nt <= 0) continue;
             if (use_sym && bp.second > bp.first) {
                 StageTimer tm(c, ST_IOU_BITS);
-                hipLaunchKernelGGL(iou_bits_sym_kernel, dim3(bp.second - bp.first), dim3(256), 0, c->stream,
-                                   c->xbox.as<float4>(), c->groups.as<GroupDesc>(), c->gflags.as<uint32_t>(),
-                                   c->pairs.as<TilePair>() + bp.first, t32, one_minus_t, c->bits.as<uint64_t>());
+                if (c->wave_transpose)
+                    hipLaunchKernelGGL(iou_bits_sym_kernel<true>, dim3(bp.second - bp.first), dim3(256), 0, c->stream,
+                                       c->xbox.as<float4>(), c->groups.as<GroupDesc>(), c->gflags.as<uint32_t>(),
+                                       c->pairs.as<TilePair>() + bp.first, t32, one_minus_t, c->bits.as<uint64_t>());
+                else
+                    hipLaunchKernelGGL(iou_bits_sym_kernel<false>, dim3(bp.second - bp.first), dim3(256), 0, c->stream,
+                                       c->xbox.as<float4>(), c->groups.as<GroupDesc>(), c->gflags.as<uint32_t>(),
+                                       c->pairs.as<TilePair>() + bp.first, t32, one_minus_t, c->bits.as<uint64_t>());
             }
             // enough column splits to fill the chip when there are few row tiles
             int splits = 1;
@@ -675,6 +681,32 @@ int vdet_create(vdet_ctx **out, int device)
         c->atomic_rank = ok;
         if (const char *e = getenv("VDET_ATOMIC_RANK")) c->atomic_rank = c->atomic_rank && atoi(e) != 0;
     }
+    {   // does wave_transpose64 (K1s's transposed emission) behave as derived on this device?
+        const int n = 64;
+        std::vector<uint64_t> hin((size_t)n * 64), hout((size_t)n * 64);
+        uint64_t x = 0x9E3779B97F4A7C15ull;
+        for (size_t i = 0; i < hin.size(); ++i) {
+            x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+            hin[i] = (i / 64) == 0 ? (1ull << (i % 64)) : ((i / 64) == 1 ? (uint64_t)(i % 64 == 5 ? ~0ull : 0ull) : x);
+        }
+        bool ok = false;
+        DevBuf bi, bo;
+        if (bi.reserve(hin.size() * 8) == hipSuccess && bo.reserve(hin.size() * 8) == hipSuccess &&
+            hipMemcpyAsync(bi.p, hin.data(), hin.size() * 8, hipMemcpyHostToDevice, c->stream) == hipSuccess) {
+            hipLaunchKernelGGL(wave_transpose_probe, dim3(16), dim3(64), 0, c->stream, bi.as<uint64_t>(), bo.as<uint64_t>(), n);
+            if (hipMemcpyAsync(hout.data(), bo.p, hout.size() * 8, hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
+                hipStreamSynchronize(c->stream) == hipSuccess) {
+                ok = true;
+                for (int t = 0; t < n && ok; ++t)
+                    for (int r = 0; r < 64 && ok; ++r)
+                        for (int k = 0; k < 64; ++k)
+                            if (((hin[(size_t)t * 64 + r] >> k) & 1ull) != ((hout[(size_t)t * 64 + k] >> r) & 1ull)) { ok = false; break; }
+            }
+        }
+        bi.release(); bo.release();
+        c->wave_transpose = ok;
+        if (const char *e = getenv("VDET_WAVE_TRANSPOSE")) c->wave_transpose = c->wave_transpose && atoi(e) != 0;
+    }
     *out = c;
     return VDET_OK;
 }
@@ -735,6 +767,7 @@ int vdet_query(vdet_ctx *c, int what)
     if (what == 0) return c->atomic_rank ? 1 : 0;
     if (what == 1) return c->n_cu;
     if (what == 2) return c->all_regular ? 1 : 0;
+    if (what == 3) return c->wave_transpose ? 1 : 0;
     return VDET_EINVAL;
 }
 
