@@ -40,6 +40,8 @@ def synth_video_cuda(torch, seed, F, B, C, device):
     h = 10 + torch.rand(F, B, generator=g, device=device) * 290
     boxes = torch.stack([x1, y1, torch.clamp(x1 + w, max=1279), torch.clamp(y1 + h, max=719)], -1).round().contiguous()
     scores = torch.rand(F, B, C, generator=g, device=device)
+    if os.environ.get("VDET_BENCH_SCORES") == "randn":      # experiment: SVM-margin-like scores (many exponents, both signs)
+        scores = torch.randn(F, B, C, generator=g, device=device)
     return boxes, scores
 
 

@@ -823,7 +823,34 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 && CPW <= 10) ? 8 : 1) void s
             const uint32_t i = valid ? src[q] : 0u;
             const uint32_t d = valid ? (((uint32_t)keys0[i] >> shift) & 255u) : 0u;
             ra[ch] = i | (d << 16);
-            if (ARANK) {
+            // The top byte (sign + exponent bits) takes only a handful of values: 64 lanes adding to 2-3
+            // addresses serialise inside the LDS atomic unit (measured: that pass cost 1.75 ms, the
+            // other three 0.5 ms each), so the last pass always ranks by ballots.
+            if (ARANK && pass == 3) {
+                // The top byte (sign + exponent bits) takes only a handful of values: 64 lanes adding to
+                // 2-3 LDS addresses serialise inside the atomic unit (measured: this pass 1.75 ms, the
+                // other three 0.5 ms each).  Peel the two most likely digits with one ballot each (one
+                // atomic by one lane per digit), the few lanes left use their own atomics.
+                uint32_t r = 0u;
+                bool pending = valid;
+#pragma unroll
+                for (int peel = 0; peel < 2; ++peel) {
+                    const unsigned long long rem = __ballot(pending);
+                    if (rem) {                                   // (scalar)
+                        const int l0 = __ffsll((unsigned long long)rem) - 1;
+                        const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)d, l0);
+                        const bool mine = pending && d == d0;
+                        const unsigned long long m = __ballot(mine);
+                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                        uint32_t old = 0u;
+                        if (lane == l0) old = atomicAdd(&bases[w * 256 + d0], (uint32_t)__popcll(m));
+                        old = (uint32_t)__builtin_amdgcn_readlane((int)old, l0);
+                        if (mine) { r = old + rank; pending = false; }
+                    }
+                }
+                if (pending) r = atomicAdd(&bases[w * 256 + d], 1u);
+                rl[ch] = r;
+            } else if (ARANK) {
                 rl[ch] = valid ? atomicAdd(&bases[w * 256 + d], 1u) : 0u;
             } else {
                 const unsigned long long peers = match8(d, valid);
