@@ -601,20 +601,26 @@ __global__ __launch_bounds__(256) void adj_build_kernel(const float4 *__restrict
     // every list starts at an even pool offset (slabs are sums of even sizes): the walks read two
     // u16 entries with one 4-byte load
     const uint32_t tot_al = (tot + 1u) & ~1u;
-    // block exclusive scan (Hillis-Steele over 256 entries)
-    sscan[tid] = tot_al;
+    // block inclusive scan of the 256 list sizes: a DPP scan inside each wave (row_shr 1/2/4/8, then the
+    // row_bcast 15/31 carries), the four wave totals combined through LDS -- two barriers instead of the
+    // sixteen of a Hillis-Steele scan over LDS
+    uint32_t incl = tot_al;
+#define VDET_SCAN_STEP(CTRL, ROWMASK) incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, CTRL, ROWMASK, 0xf, false);
+    VDET_SCAN_STEP(0x111, 0xf) VDET_SCAN_STEP(0x112, 0xf) VDET_SCAN_STEP(0x114, 0xf) VDET_SCAN_STEP(0x118, 0xf)
+    VDET_SCAN_STEP(0x142, 0xa) VDET_SCAN_STEP(0x143, 0xc)
+#undef VDET_SCAN_STEP
+    if ((tid & 63) == 63) sscan[tid >> 6] = incl;
     __syncthreads();
-    for (int d = 1; d < 256; d <<= 1) {
-        const uint32_t t = (tid >= d) ? sscan[tid - d] : 0u;
-        __syncthreads();
-        sscan[tid] += t;
-        __syncthreads();
+    {
+        const int wv = tid >> 6;
+        uint32_t carry = 0;
+        for (int k = 0; k < wv; ++k) carry += sscan[k];
+        incl += carry;
     }
-    const uint32_t incl = sscan[tid];
-    if (tid == 255) sbase = atomicAdd(pool_used, (unsigned long long)incl);
+    if (tid == 255) { sscan[4] = incl; sbase = atomicAdd(pool_used, (unsigned long long)incl); }
     __syncthreads();
     const unsigned long long base = sbase;
-    const uint32_t tile_total = sscan[255];
+    const uint32_t tile_total = sscan[4];
     if (base + tile_total > pool_cap || base + tile_total > 0xFFFFFFFFull) {
         if (tid == 0) atomicOr(status, kStPool);
         if (v < B) row_meta[gd.box_off + vo] = make_uint2(0u, 0u);
