@@ -906,7 +906,13 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 && CPW <= 10) ? 8 : 1) void s
         uint16_t *t = src; src = dst; dst = t;
     }
     uint16_t *out = prm.order + pr.obase;
-    for (int v = tid; v < N; v += BLOCK) out[v] = src[v];
+    if (((pr.obase | (int64_t)N) & 1) == 0) {      // two indices per lane: 256-B instead of 128-B stores per wave
+        uint32_t *out2 = reinterpret_cast<uint32_t *>(out);
+        const uint32_t *src2 = reinterpret_cast<const uint32_t *>(src);
+        for (int v = tid; v < (N >> 1); v += BLOCK) out2[v] = src2[v];
+    } else {
+        for (int v = tid; v < N; v += BLOCK) out[v] = src[v];
+    }
     if (tid == 0) prm.ncand[p] = ncand;
 }
 
