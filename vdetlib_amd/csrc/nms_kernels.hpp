@@ -440,7 +440,7 @@ __global__ __launch_bounds__(256) void iou_bits_sym_kernel(const float4 *__restr
                                                            const GroupDesc *__restrict__ groups,
                                                            const uint32_t *__restrict__ group_flags,
                                                            const TilePair *__restrict__ pairs, float t32, float one_minus_t,
-                                                           uint64_t *__restrict__ bits)
+                                                           uint64_t *__restrict__ bits, uint32_t *__restrict__ row_deg)
 {
     __shared__ float4 sbox[256];
     __shared__ float sarea[256];
@@ -476,6 +476,7 @@ __global__ __launch_bounds__(256) void iou_bits_sym_kernel(const float4 *__restr
     const bool tile_empty = tp.ct > tp.rt &&
                             sbox[0].x > fmaxf(fmaxf(sreach[0], sreach[1]), fmaxf(sreach[2], sreach[3]));
 
+    uint32_t dsum = 0;
     for (int q = 0; q < 4; ++q) {
         const int c = tp.ct * 4 + q;
         if (c < r) continue;                     // lower triangle: produced by the transposed stores
@@ -532,12 +533,19 @@ __global__ __launch_bounds__(256) void iou_bits_sym_kernel(const float4 *__restr
         }
         unsigned long long m = (((unsigned long long)hi << 32) | lo) & colvalid;
         if (c == r) m &= ~(1ull << lane);        // no self edge
-        if (v < B) bits[gd.bits_off + (int64_t)c * B + v] = m;
+        if (v < B) { bits[gd.bits_off + (int64_t)c * B + v] = m; dsum += (uint32_t)__popcll(m); }
         if (c > r) {
             const int u = c * 64 + lane;
-            if (u < B) bits[gd.bits_off + (int64_t)r * B + u] = (((unsigned long long)thi << 32) | tlo) & rowvalid;
+            if (u < B) {
+                const unsigned long long tm = (((unsigned long long)thi << 32) | tlo) & rowvalid;
+                bits[gd.bits_off + (int64_t)r * B + u] = tm;
+                const uint32_t cnt = (uint32_t)__popcll(tm);
+                if (cnt) atomicAdd(&row_deg[gd.box_off + u], cnt);
+            }
         }
     }
+    // the rows' degrees (list lengths) come for free here; adj_build_kernel does not have to count them
+    if (dsum) atomicAdd(&row_deg[gd.box_off + v], dsum);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -587,7 +595,9 @@ __global__ __launch_bounds__(256) void adj_build_kernel(const float4 *__restrict
     }
 
     uint32_t deg = 0, zc = 0;
-    if (v < B) {
+    if (v < B && tr) {
+        deg = row_z[gd.box_off + v];             // regular group: the degree was accumulated by iou_bits_sym_kernel
+    } else if (v < B) {
         for (int wb = w0; wb < w1; wb += 8) {
             uint64_t mm[8];
 #pragma unroll
@@ -595,7 +605,7 @@ __global__ __launch_bounds__(256) void adj_build_kernel(const float4 *__restrict
 #pragma unroll
             for (int j = 0; j < 8; ++j) deg += __popcll(mm[j]);
         }
-        zc = tr ? 0u : row_z[gd.box_off + v];
+        zc = row_z[gd.box_off + v];
     }
     const uint32_t tot = deg + zc;
     // every list starts at an even pool offset (slabs are sums of even sizes): the walks read two

@@ -314,11 +314,11 @@ int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32, doub
                 if (c->wave_transpose)
                     hipLaunchKernelGGL(iou_bits_sym_kernel<true>, dim3(bp.second - bp.first), dim3(256), 0, c->stream,
                                        c->xbox.as<float4>(), c->groups.as<GroupDesc>(), c->gflags.as<uint32_t>(),
-                                       c->pairs.as<TilePair>() + bp.first, t32, one_minus_t, c->bits.as<uint64_t>());
+                                       c->pairs.as<TilePair>() + bp.first, t32, one_minus_t, c->bits.as<uint64_t>(), c->rowz.as<uint32_t>());
                 else
                     hipLaunchKernelGGL(iou_bits_sym_kernel<false>, dim3(bp.second - bp.first), dim3(256), 0, c->stream,
                                        c->xbox.as<float4>(), c->groups.as<GroupDesc>(), c->gflags.as<uint32_t>(),
-                                       c->pairs.as<TilePair>() + bp.first, t32, one_minus_t, c->bits.as<uint64_t>());
+                                       c->pairs.as<TilePair>() + bp.first, t32, one_minus_t, c->bits.as<uint64_t>(), c->rowz.as<uint32_t>());
             }
             // enough column splits to fill the chip when there are few row tiles
             int splits = 1;
