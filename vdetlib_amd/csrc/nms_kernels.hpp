@@ -675,7 +675,9 @@ __global__ __launch_bounds__(256) void adj_build_kernel(const float4 *__restrict
                 }
             }
         }
-        if (staged && (tot & 1u)) sstage[q] = 0;      // the padding entry of an odd list must be a valid rank (translated below)
+        // odd lists are padded to even length with a DUPLICATE of their last entry: the walks apply
+        // entries in pairs (a second OR of the same bit is harmless)
+        if (tot & 1u) { if (staged) sstage[q] = sstage[q - 1]; else adj[p] = adj[p - 1]; }
     }
     if (staged) {   // one coalesced copy of the tile's slab instead of 256 interleaved 2-byte streams
         __syncthreads();
@@ -1051,26 +1053,28 @@ __device__ __forceinline__ void walk_apply_slice(lds_mask_t mask, uint16_t e, bo
 
 // the survivors of one group of up to kWalkGrp alive candidates (lanes ls[0..ng) of c / off / deg).
 // pre[k] = entries 2*lane and 2*lane+1 of candidate k's adjacency list (one 4-byte load; lists start
-// at even offsets).  Survivors are staged 64 at a time and written with one coalesced store.
+// at even offsets and are padded to even length with a duplicate entry, so a lane's two entries are
+// valid together).  A survivor is recorded by setting its lane's bit in the SCALAR mask kept_lanes
+// (the caller writes the chunk's survivors with one compacting store): the walk is instruction-issue
+// bound (~63 % of a list's time is this loop, measured), every instruction per survivor counts.
 template <bool HASZ>
 __device__ __forceinline__ void walk_group(lds_mask_t mask, const uint16_t *__restrict__ adj, int lane, int c,
                                            uint32_t off, int deg, const int (&ls)[kWalkGrp], int ng,
-                                           const uint32_t (&pre)[kWalkGrp], int32_t *__restrict__ out, int64_t cap,
-                                           int &nk, int &stage, int &bad)
+                                           const uint32_t (&pre)[kWalkGrp], unsigned long long &kept_lanes, int &bad)
 {
 #pragma unroll
     for (int k = 0; k < kWalkGrp; ++k) {
         if (k >= ng) break;
         const int cu = __builtin_amdgcn_readlane(c, ls[k]);
-        // (wave-uniform value made scalar: the branch and the survivor counter stay on the scalar unit)
+        // (wave-uniform value made scalar: scalar branch)
         if (__builtin_amdgcn_readfirstlane((mask[cu >> 5] >> (cu & 31)) & 1u)) continue;   // suppressed by an earlier survivor of this chunk
+        kept_lanes |= 1ull << ls[k];
         const int d = __builtin_amdgcn_readlane(deg, ls[k]);
         if (HASZ && lane == 0) lds_or(mask, cu >> 5, 1u << (cu & 31));   // a kept box reads as dead (zero-union rule)
-        if ((nk & 63) == lane) stage = cu;
-        ++nk;
-        if ((nk & 63) == 0 && (int64_t)(nk - 64 + lane) < cap) out[nk - 64 + lane] = stage;
-        walk_apply_slice<HASZ>(mask, (uint16_t)(pre[k] & 0xFFFFu), 2 * lane < d, bad);
-        walk_apply_slice<HASZ>(mask, (uint16_t)(pre[k] >> 16), 2 * lane + 1 < d, bad);
+        if (2 * lane < d) {
+            walk_apply_slice<HASZ>(mask, (uint16_t)(pre[k] & 0xFFFFu), true, bad);
+            walk_apply_slice<HASZ>(mask, (uint16_t)(pre[k] >> 16), true, bad);
+        }
         if (d > 128) {   // rare: long lists
             const uint32_t o = __builtin_amdgcn_readlane(off, ls[k]);
             for (int e0 = 128; e0 < d; e0 += 64)
@@ -1108,7 +1112,7 @@ __global__ __launch_bounds__(256) void walk_kernel(const WalkParams prm)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
 
-    int nk = 0, stage = 0;
+    int nk = 0;
     int bad = 0;
     const uint32_t *adjw = reinterpret_cast<const uint32_t *>(prm.adj);   // adjacency lists start at even offsets
     // Two-deep software pipeline over the chunks of 64 candidates: the ids of chunk i+2 (one
@@ -1133,6 +1137,7 @@ __global__ __launch_bounds__(256) void walk_kernel(const WalkParams prm)
         if ((q + 64) < ncand && !((mask[c_nxt >> 5] >> (c_nxt & 31)) & 1u)) m_nxt = prm.row_meta[rb + c_nxt];
         const bool alive = valid && !((mask[c >> 5] >> (c & 31)) & 1u);
         unsigned long long am = __ballot(alive);
+        unsigned long long kept_lanes = 0ull;
         const uint32_t off = m_cur.x;
         const int deg = (int)m_cur.y;
         while (am) {
@@ -1154,12 +1159,17 @@ __global__ __launch_bounds__(256) void walk_kernel(const WalkParams prm)
                 const int d = __builtin_amdgcn_readlane(deg, ls[k]);
                 pre[k] = adjw[(o >> 1) + min(lane, (max(d, 1) - 1) >> 1)];
             }
-            if (has_z) walk_group<true>(mask, prm.adj, lane, c, off, deg, ls, ng, pre, out, cap, nk, stage, bad);
-            else walk_group<false>(mask, prm.adj, lane, c, off, deg, ls, ng, pre, out, cap, nk, stage, bad);
+            if (has_z) walk_group<true>(mask, prm.adj, lane, c, off, deg, ls, ng, pre, kept_lanes, bad);
+            else walk_group<false>(mask, prm.adj, lane, c, off, deg, ls, ng, pre, kept_lanes, bad);
+        }
+        if (kept_lanes) {   // the chunk's survivors, in lane (= descending score) order, with one compacting store
+            const int pos = nk + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(kept_lanes >> 32),
+                                                               __builtin_amdgcn_mbcnt_lo((uint32_t)kept_lanes, 0u));
+            if (((kept_lanes >> lane) & 1ull) && (int64_t)pos < cap) out[pos] = c;
+            nk += __popcll(kept_lanes);
         }
         c_cur = c_nxt; c_nxt = c_nn; m_cur = m_nxt;
     }
-    if (lane < (nk & 63) && (int64_t)((nk & ~63) + lane) < cap) out[(nk & ~63) + lane] = stage;   // tail
     if (lane == 0) prm.keep_cnt[p] = nk;
     if ((int64_t)nk > cap && lane == 0) atomicOr(prm.status, kStCap);
     if (__ballot(bad != 0) && lane == 0) atomicOr(prm.status, kStDivZero);
