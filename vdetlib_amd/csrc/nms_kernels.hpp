@@ -834,6 +834,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 && CPW <= 10) ? 8 : 1) void s
         __syncthreads();
         uint32_t ra[CPW];        // index | digit << 16
         uint32_t rl[CPW];        // offset inside this wave's run of the digit
+        bool peel_on = false;    // this pass's digits are concentrated: peel them (see below)
 #pragma unroll
         for (int ch = 0; ch < CPW; ++ch) {
             const int q = (c0 + ch) * 64 + lane;
@@ -844,32 +845,38 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 && CPW <= 10) ? 8 : 1) void s
             // The top byte (sign + exponent bits) takes only a handful of values: 64 lanes adding to 2-3
             // addresses serialise inside the LDS atomic unit (measured: that pass cost 1.75 ms, the
             // other three 0.5 ms each), so the last pass always ranks by ballots.
-            if (ARANK && pass == 3) {
-                // The top byte (sign + exponent bits) takes only a handful of values: 64 lanes adding to
-                // 2-3 LDS addresses serialise inside the atomic unit (measured: this pass 1.75 ms, the
-                // other three 0.5 ms each).  Peel the two most likely digits with one ballot each (one
-                // atomic by one lane per digit), the few lanes left use their own atomics.
+            if (ARANK) {
+                // 64 lanes adding to 2-3 LDS addresses serialise inside the atomic unit.  That is the rule
+                // for the top byte (sign + exponent bits: a handful of values; measured: that pass cost
+                // 1.75 ms, the other three 0.5 ms each) and happens in any pass on quantised scores.  So a
+                // digit shared by many lanes is peeled with one ballot (rank = position among its lanes,
+                // ONE atomic by one lane), at most twice; the lanes left use their own atomics.  In the
+                // other passes the first probe (one ballot + popcount) decides whether peeling pays.
                 uint32_t r = 0u;
                 bool pending = valid;
 #pragma unroll
                 for (int peel = 0; peel < 2; ++peel) {
+                    if (ch > 0 && !peel_on) break;
                     const unsigned long long rem = __ballot(pending);
                     if (rem) {                                   // (scalar)
                         const int l0 = __ffsll((unsigned long long)rem) - 1;
                         const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)d, l0);
                         const bool mine = pending && d == d0;
                         const unsigned long long m = __ballot(mine);
-                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                        uint32_t old = 0u;
-                        if (lane == l0) old = atomicAdd(&bases[w * 256 + d0], (uint32_t)__popcll(m));
-                        old = (uint32_t)__builtin_amdgcn_readlane((int)old, l0);
-                        if (mine) { r = old + rank; pending = false; }
+                        if (ch == 0 && peel == 0) peel_on = (pass == 3) || __popcll(m) >= 12;   // (the wave's first chunk decides for the pass)
+                        if (peel_on) {
+                            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                            uint32_t old = 0u;
+                            if (lane == l0) old = atomicAdd(&bases[w * 256 + d0], (uint32_t)__popcll(m));
+                            old = (uint32_t)__builtin_amdgcn_readlane((int)old, l0);
+                            if (mine) { r = old + rank; pending = false; }
+                        } else {
+                            break;                               // digits look spread out: per-lane atomics
+                        }
                     }
                 }
                 if (pending) r = atomicAdd(&bases[w * 256 + d], 1u);
                 rl[ch] = r;
-            } else if (ARANK) {
-                rl[ch] = valid ? atomicAdd(&bases[w * 256 + d], 1u) : 0u;
             } else {
                 const unsigned long long peers = match8(d, valid);
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
