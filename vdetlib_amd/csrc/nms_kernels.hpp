@@ -1037,7 +1037,7 @@ __device__ __forceinline__ void lds_and(lds_mask_t m, int word, uint32_t bits)
     __hip_atomic_fetch_and((lds_u32_t *)(m + word), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
 
-constexpr int kWalkGrp = 8;
+constexpr int kWalkGrp = 4;
 
 // One 64-entry slice of a survivor's adjacency list -> dead bits.  HASZ = false (every regular
 // frame): entries are plain indices, nothing to test -- this is the instruction-issue hot spot of
