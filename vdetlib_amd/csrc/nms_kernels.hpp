@@ -246,7 +246,10 @@ __global__ __launch_bounds__(256) void frame_index_kernel(const float4 *__restri
 __device__ __forceinline__ void xwindow(const FrameIndex &ix, int f, float x1c, float wc, double t, int &r0, int &r1)
 {
     const float xmin = ix.info[f * 4 + 0], scale = ix.info[f * 4 + 1], wmax = ix.info[f * 4 + 2];
-    const double lo = (double)x1c - (1.0 - t) * (double)wmax * 1.001 - 1.0;
+    // a partner j that starts left of c needs x1c - x1_j <= (1 - t) * w_j, and IoU >= t bounds its width:
+    // t <= inter / union <= (wc * h_j) / (w_j * h_j)  =>  w_j <= wc / t  (so not only w_j <= wmax)
+    const double wj = fmin((double)wmax, (double)wc / t * 1.001);
+    const double lo = (double)x1c - (1.0 - t) * wj * 1.001 - 1.0;
     const double hi = (double)x1c + (1.0 - t) * (double)wc * 1.001 + 1.0;
     const int b0 = xbucket((float)fmax(lo, -3.0e38), xmin, scale);
     const int b1 = xbucket((float)fmin(hi, 3.0e38), xmin, scale);
@@ -586,8 +589,11 @@ __global__ __launch_bounds__(256) void adj_build_kernel(const float4 *__restrict
     if (tr && v < B) {
         const float4 bx = ix.xbox[gd.box_off + v];
         const float xmin = ix.info[td.group * 4 + 0], scale = ix.info[td.group * 4 + 1], wmax = ix.info[td.group * 4 + 2];
-        const float lo = bx.x - one_minus_t * wmax * 1.001f - 2.0f;
-        const float hi = bx.x + one_minus_t * ((bx.z - bx.x) + 1.0f) * 1.001f + 2.0f;
+        const float wrow = (bx.z - bx.x) + 1.0f;
+        // (partners starting to the left are at most wrow / t wide, see xwindow; 1 - one_minus_t <= t)
+        const float wleft = fminf(wmax, wrow / fmaxf(1.0f - one_minus_t, 1.0e-6f) * 1.001f);
+        const float lo = bx.x - one_minus_t * wleft * 1.001f - 2.0f;
+        const float hi = bx.x + one_minus_t * wrow * 1.001f + 2.0f;
         const int r0 = (int)ix.cum[(int64_t)td.group * 257 + xbucket(lo, xmin, scale)];
         const int r1 = (int)ix.cum[(int64_t)td.group * 257 + xbucket(hi, xmin, scale) + 1];
         w0 = r0 >> 6;

@@ -312,6 +312,7 @@ __global__ __launch_bounds__(LT) void track_link_kernel(const float4 *__restrict
         for (int i = 0; i < LB; ++i) nb[i] = fb1[min(tid + i * LT, B - 1)];
     }
     const float omt = (float)(1.0 - link_thres) * 1.002f + 1.0e-6f;     // (1 - link_thres), rounded up
+    const float inv_t = (float)(1.002 / fmax(link_thres, 1.0e-6));         // 1 / link_thres, rounded up
 #define LINK_DPP_STEP(CTRL, ROWMASK) { \
         const float v2 = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(-1.0f), __float_as_int(bv), CTRL, ROWMASK, 0xf, false)); \
         const int i2 = __builtin_amdgcn_update_dpp(-1, bi, CTRL, ROWMASK, 0xf, false); \
@@ -351,7 +352,7 @@ __global__ __launch_bounds__(LT) void track_link_kernel(const float4 *__restrict
                 const float wmax = __uint_as_float(scum[par][259]);
                 const float wc = (cur.z - cur.x) + 1.0f;
                 // (f32 with slack instead of f64: the window only has to be a superset)
-                const float lo = cur.x - omt * wmax - 2.0f;
+                const float lo = cur.x - omt * fminf(wmax, wc * inv_t) - 2.0f;   // partners to the left are at most wc / t wide (xwindow)
                 const float hi = cur.x + omt * wc + 2.0f;
                 r0 = (int)scum[par][xbucket(fmaxf(lo, -3.0e38f), xmin, scale)];
                 r1 = (int)scum[par][xbucket(fminf(hi, 3.0e38f), xmin, scale) + 1];
