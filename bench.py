@@ -48,8 +48,8 @@ def synth_video_cuda(torch, seed, F, B, C, device):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--frames", type=int, default=300)
     ap.add_argument("--boxes", type=int, default=10000)
     ap.add_argument("--classes", type=int, default=200)
