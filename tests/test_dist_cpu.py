@@ -64,6 +64,14 @@ def test_world2_gloo_gather(n_videos):
     assert dict(ret) == {0: True, 1: True}
 
 
+def test_class_slices_partition():
+    for C, world in ((200, 8), (30, 8), (5, 8), (201, 4)):
+        got = [vd.class_slice(C, r, world) for r in range(world)]
+        assert got[0][0] == 0 and got[-1][1] == C
+        assert all(got[i][1] == got[i + 1][0] for i in range(world - 1))
+        assert max(b - a for a, b in got) - min(b - a for a, b in got) <= 1
+
+
 def test_sharding_rules():
     assert vd.shard_round_robin(10, 1, 4) == [1, 5, 9]
     assert sorted(sum((vd.shard_round_robin(64, r, 8) for r in range(8)), [])) == list(range(64))

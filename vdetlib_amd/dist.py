@@ -49,6 +49,16 @@ def shard_lpt(costs, world):
     return [sorted(o) for o in owned]
 
 
+def class_slice(n_classes, rank, world):
+    """Secondary partition for ONE huge video on several GPUs: shard by CLASS -- never by
+    frame, so temporal windows and tubelets need no halo.  Every rank keeps the boxes (48 MB at c2) and
+    a contiguous slice of the class axis of the score volume; the suppression graph is rebuilt on every
+    rank (class-independent, a few ms), everything per (frame, class) splits.  Returns (c0, c1)."""
+    per, rem = divmod(n_classes, world)
+    c0 = rank * per + min(rank, rem)
+    return c0, c0 + per + (1 if rank < rem else 0)
+
+
 def all_gather_ragged(t, group=None):
     """All-gather tensors whose first dimension differs per rank: counts first, then one padded
     fixed-capacity payload (a single large collective instead of many small ones -- xGMI rings are
