@@ -76,9 +76,14 @@ def main():
     from vdetlib_amd import dist as vdist
 
     world, rank, local = vdist.env_world()
+    # (test hook: VDET_BENCH_ONE_GPU=1 runs every rank on device 0 over gloo, to dry-run the N > 1 control
+    #  flow on a single-GPU box; the real multi-GPU run is one rank per GPU over RCCL)
+    one_gpu = os.environ.get("VDET_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    vdist.init(backend="nccl" if world > 1 else None, device=dev)
+    vdist.init(backend=("gloo" if one_gpu else "nccl") if world > 1 else None, device=dev)
     F, B, C = args.frames, args.boxes, args.classes
     TOPK = 100
     TAPS = [0.25, 0.5, 0.25]     # the temporal convolution of the score volume (stand-in for the external TCN's first layer)
@@ -97,7 +102,7 @@ def main():
         cx.set_cache(True)   # NMS and LINK of one step share the suppression graph and the sorted lists
     step_no = [0]
 
-    def step():
+    def step(exchange=True):
         nonlocal gathered
         k = step_no[0] % nstreams
         step_no[0] += 1
@@ -125,7 +130,7 @@ def main():
                 det, tpool, tboxes = ops.rescore_tracks(tracks, ntracks, boxes, scores, overlap_thres=args.pool_thres,
                                                         window=args.window, sync=False, ctx=cx)
                 tub = (tracks, ntracks, tpool, tboxes)
-            if world > 1:   # the one exchange step: RCCL all-gather of the per-video results over xGMI
+            if world > 1 and exchange:   # the one exchange step: RCCL all-gather of the per-video results over xGMI
                 # (same geometry on every rank: one fixed-shape collective per tensor, nothing the host
                 # has to wait for -- a count exchange would stall the multi-video pipeline)
                 if tub is not None:
@@ -154,7 +159,7 @@ def main():
     dt = time.perf_counter() - t0
     for cx in ctxs:
         cx.sync()       # surfaces latched device-side failures (capacity / zero union)
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if one_gpu else dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
@@ -170,7 +175,7 @@ def main():
         reps = 3
         for _ in range(reps):
             step_no[0] = 0          # per-kernel timing: one video at a time on stream 0
-            step()
+            step(exchange=False)    # (rank 0 only: no collective here)
             torch.cuda.synchronize()
         ctx.sync()
         agg = {k: [ms, n] for k, (ms, n) in ctx.last_timing().items()}

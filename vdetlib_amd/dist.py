@@ -65,6 +65,8 @@ def all_gather_ragged(t, group=None):
     per-link bound).  Returns the list of per-rank tensors (on every rank)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return [t]
+    if _stage_on_host(t, group):
+        return [p.to(t.device) for p in all_gather_ragged(t.cpu(), group)]
     world = dist.get_world_size(group)
     n = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
     counts = torch.empty(world, dtype=torch.int64, device=t.device)
@@ -78,6 +80,12 @@ def all_gather_ragged(t, group=None):
     return [out[r * cap:r * cap + counts[r]] for r in range(world)]
 
 
+def _stage_on_host(t, group):
+    """gloo moves host memory: device tensors are staged through the CPU (tests / single-GPU dry runs
+    of the N > 1 control flow; RCCL takes device pointers directly)."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
 def all_gather_fixed(t, group=None):
     """All-gather of same-shape tensors (every rank holds one video of the same geometry): ONE
     collective, no count exchange and therefore no host synchronisation -- the call only enqueues, so
@@ -88,6 +96,8 @@ def all_gather_fixed(t, group=None):
     t = t.contiguous()
     if t.dim() == 0:
         t = t[None]
+    if _stage_on_host(t, group):
+        return all_gather_fixed(t.cpu(), group).to(t.device)
     # concatenated layout along dim 0 (accepted by both RCCL and gloo), viewed as [world, ...]
     out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
     dist.all_gather_into_tensor(out, t, group=group)
