@@ -67,6 +67,8 @@ def main():
     ap.add_argument("--cpu-problems", type=int, default=1200, help="(frame,class) problems timed on the CPU oracle")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        args.no_cpu = True       # the CPU baseline / mAP-parity / PCIe legs are reported at N = 1 only
     METRIC = "boxes/sec whole-node (NMS+temporal-conv+link), 300f\u00d710k-box synth; mAP parity"   # BASELINE.json
 
     import numpy as np
