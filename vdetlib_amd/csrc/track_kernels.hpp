@@ -1,20 +1,22 @@
 // track_kernels.hpp -- device-resident greedy tubelet generation for a whole score volume
 // (the array form of greedily_track_from_raw_dets, vdet/track.py:189-252, for every class at once).
 //
-// State per (frame, class): the list of still-kept detections in descending score order
-// (initially the full argsort produced by sort_kernel) + its length.  Because the reference only
-// ever REMOVES detections, "keep[i]" is exactly "i is still in its frame's list", the next anchor is
-// the best list head over the frames, and each track_det_nms call (utils/nms.pyx:128-189) rewrites
-// one list: round 1 drops entries overlapping the track box, round 2 is the greedy walk over what
-// is left (same adjacency lists as the NMS stage), survivors are compacted back in place.
+// State per (frame, class): the list of still-kept detections in descending score order (initially
+// the full argsort produced by sort_kernel).  The reference only ever REMOVES detections, so the next
+// anchor is the best live list head over the frames, and each track_det_nms call
+// (utils/nms.pyx:128-189) rewrites one list: round 1 drops entries overlapping the track box, round 2
+// is a greedy walk over what is left.
 //
-//   track_pick_kernel      one block per class: next anchor = best head over the frames, honouring
+//   track_pick_kernel      one block per class: next anchor = best live head over the frames, honouring
 //                          the reference's monotone cursor (cur_top_det_id never goes back) and its
-//                          stop rule (score < opts.thres).
-//   track_link_kernel      one block per class: the built-in IoU-linking tracker plug-in
+//                          stop rule (score < opts.thres).  On regular frames it also IS track_det_nms,
+//                          lazily: see LazyLists (kept prefix evaluated on demand, persistent heads).
+//   track_link_kernel      one block per (class, direction): the built-in IoU-linking tracker plug-in
 //                          (stand-in for the external MATLAB trackers): from the anchor, frame by
 //                          frame, the proposal with the highest IoU with the current box (>= link_thres).
-//   track_suppress_kernel  one wave per (frame, class) crossed by the new track.
+//   track_suppress_kernel  eager track_det_nms, one wave per (frame, class) crossed by the new track:
+//                          irregular frames only (and everywhere under VDET_NO_LAZY=1).
+//   rescore_*_kernel       spatial max-pool / completion / temporal max-pool of the finished tubelets.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
