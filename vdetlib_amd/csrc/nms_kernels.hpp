@@ -8,10 +8,17 @@
 //   that shared graph under its own priority order -- which is exactly what the reference's greedy
 //   loop computes (box v is kept iff no higher-priority box that suppresses it is kept).
 //
-//   K1 iou_bits_kernel   all-pairs predicate of one frame, one lane per row (the "i" box), column boxes
-//                        (the "j" boxes) broadcast from LDS; 64 predicates packed per u64, written
+//   K0 frame_flags / frame_index   per frame: "regular" flag (finite boxes, positive sizes) and the
+//                        x1-sorted index (boxes in x1 order + bucket table) that every window test uses.
+//   K1s iou_bits_sym_kernel   regular frames: upper triangle of 256 x 256 tiles in x1-rank space, tiles /
+//                        blocks beyond the IoU reach skipped, divide-free exact predicate, row words
+//                        accumulated with add-with-carry, the transposed block by a 64 x 64 bit transpose
+//                        on the lane-exchange network; also accumulates the rows' degrees.  At the VALU
+//                        roofline.
+//   K1 iou_bits_kernel   irregular frames (NaN / inf / degenerate boxes): all-pairs predicate with the
+//                        reference's asymmetric NaN semantics, one lane per row (the "i" box), column
+//                        boxes (the "j" boxes) broadcast from LDS; 64 predicates packed per u64, written
 //                        transposed ([word][row]) so the stores and the later loads are coalesced.
-//                        VALU-bound.
 //   K2 adj_build_kernel  bit rows -> compact u16 adjacency lists = OUT-lists "whom do I suppress"
 //                        (CSR slabs allocated with one atomicAdd per 256-row tile).
 //   K3 sort_kernel       one workgroup per (frame, class): stable LSD radix argsort of the scores,
