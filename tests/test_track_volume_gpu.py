@@ -293,3 +293,25 @@ def test_track_volume_random_sweep(oracle, seed):
         assert np.array_equal(trn[c, :wn], wt[:wn], equal_nan=True), c
     widx, wcnt = oracle.nms_volume(boxes, scores, o['nms_thres'])
     assert np.array_equal(kc.cpu().numpy(), wcnt) and np.array_equal(ki.cpu().numpy(), widx)
+
+
+@pytest.mark.parametrize("knob", ["VDET_FORCE_GENERAL", "VDET_NO_INDEX", "VDET_NO_TRANSPOSE", "VDET_NO_LAZY",
+                                  "VDET_WAVE_TRANSPOSE=0", "VDET_ATOMIC_RANK=0"])
+def test_alternative_kernel_paths_agree(monkeypatch, knob):
+    """Every A/B knob selects a different kernel path for the same result (general predicate kernel,
+    no x-index, strided key reads, eager track_det_nms, ballot transposition in K1s, ballot ranks in
+    the sort): NMS survivors, tubelets and re-scored tubelets must be bit-identical to the default."""
+    import torch
+    from vdetlib_amd import ops, _lib
+    boxes, scores = _fused_case(61, 12, 1300, 6)
+    tb, ts = torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda()
+    kw = dict(nms_thres=0.3, thres=0.2, max_tracks=4, link_thres=0.5)
+    ref = ops.nms_track_volume(tb, ts, **kw)
+    ref_r = ops.rescore_tracks(ref[2], ref[4], tb, ts, overlap_thres=0.6, window=3)
+    name, _, val = knob.partition('=')
+    monkeypatch.setenv(name, val or '1')
+    cx = _lib.Context(torch.cuda.current_device())
+    got = ops.nms_track_volume(tb, ts, ctx=cx, **kw)
+    got_r = ops.rescore_tracks(got[2], got[4], tb, ts, overlap_thres=0.6, window=3, ctx=cx)
+    for a, b in zip(list(ref) + list(ref_r), list(got) + list(got_r)):
+        assert np.array_equal(a.cpu().numpy(), b.cpu().numpy(), equal_nan=True), knob
