@@ -45,8 +45,11 @@ typedef enum vdet_status {
     VDET_EDIVZERO = -4,  /* zero union where the reference raises ZeroDivisionError
                             (Cython cdivision=False, utils/nms.pyx:64,122,180) */
     VDET_ENOMEM = -5,
-    VDET_EINDEX = -6     /* where the reference raises IndexError (do_score_completion on a tubelet
+    VDET_EINDEX = -6,    /* where the reference raises IndexError (do_score_completion on a tubelet
                             without any valid score, vdet/tubelet_cls.py:293-295) */
+    VDET_EAGAIN = -7     /* vdet_sync only, asynchronous mode (vdet_set_async): a suppression-graph build
+                            ran out of scratch; the results since the last vdet_sync are invalid, the
+                            scratch has been enlarged -- enqueue the same calls again (RuntimeError) */
 } vdet_status;
 
 /* ---- context ------------------------------------------------------------------------------- */
@@ -79,11 +82,19 @@ int vdet_last_launches(vdet_ctx *ctx, int *out16);
  * it whenever a buffer was rewritten in place).  Default: disabled. */
 int vdet_set_cache(vdet_ctx *ctx, int enable);
 int vdet_invalidate(vdet_ctx *ctx);
+/* Asynchronous video step (default: disabled).  When enabled, the d_* volume entry points
+ * (vdet_nms_volume, vdet_track_volume, vdet_nms_track_volume, vdet_rescore_tracks, vdet_volume_pass)
+ * never wait for the device once the context has built one suppression graph: the per-geometry launch
+ * tables stay resident, the device status words stay latched until vdet_sync, and the scratch for the
+ * adjacency lists is sized from the largest graph seen so far (+50 %).  A graph that still outgrows
+ * it makes the next vdet_sync return VDET_EAGAIN (nothing is written out of bounds). */
+int vdet_set_async(vdet_ctx *ctx, int enable);
 /* Introspection: what = 0 -> 1 if the per-(frame,class) sort uses the returning-LDS-atomic rank
  * (selected by a hardware self-test at vdet_create), 0 if it uses the ballot match;
  * what = 1 -> number of compute units;
- * what = 2 -> 1 if every frame of the last suppression-graph build was "regular" (finite boxes,
- * positive width / height / area). */
+ * what = 2 -> 1 if every frame of the last SYNCHRONOUS suppression-graph build was "regular" (finite
+ * boxes, positive width / height / area); 0 after an asynchronous build (not known on the host);
+ * what = 3 -> 1 if the 64x64 in-wave bit transpose passed its self-test at vdet_create. */
 int vdet_query(vdet_ctx *ctx, int what);
 /* Per-stage HIP-event timing: 0 off (default), 1 on (events of the most recent call), 2 on and
  * accumulating over calls until vdet_last_timing_ms reads them. */
@@ -193,6 +204,20 @@ int vdet_nms_volume(vdet_ctx *ctx, const float *d_boxes, const float *d_scores, 
                     float score_thresh, int32_t *d_keep_idx, int32_t *d_keep_cnt, int64_t cap);
 
 /*
+ * vdet_nms_volume preceded, on the device, by the per-class candidate selection of
+ * fast_rcnn_det_vid (vdet/video_det.py:89-99): per (frame, class) the candidates are the boxes with
+ * score > score_thresh (use_score_thresh; float32 compare like numpy's), and when more than `topk`
+ * (> 0; the reference's max_per_image = 100) remain only the topk best -- argsort(-scores)[:topk],
+ * i.e. ties at the cut go to the LOWEST indices -- enter the NMS.  The reference's pipeline order
+ * (threshold -> top-k -> apply_image_nms, vdet/image_det.py:117-123) without the scores ever leaving
+ * HBM.  topk == 0: no cut (== vdet_nms_volume).
+ */
+int vdet_nms_volume_topk(vdet_ctx *ctx, const float *d_boxes, const float *d_scores, int layout,
+                         int64_t F, int64_t B, int64_t C, double thresh, int use_score_thresh,
+                         float score_thresh, int topk, int32_t *d_keep_idx, int32_t *d_keep_cnt,
+                         int64_t cap);
+
+/*
  * Centred sliding temporal max over series laid out [F,S] (series s = in[f*S+s]); the array form
  * of score_proto_temporal_maxpool (vdet/tubelet_cls.py:386-414): out[f] = max(in[f-h..f+h]),
  * out-of-range samples = pad (-1e5 in the reference, :402); NaN propagates (np.max).  window must
@@ -217,6 +242,23 @@ int vdet_temporal_conv_f32(vdet_ctx *ctx, const float *d_in, float *d_out, int64
  * bias, pad_conv).  Bit-identical to the two separate calls. */
 int vdet_temporal_maxpool_conv_f32(vdet_ctx *ctx, const float *d_in, float *d_out_max, float *d_out_conv, int64_t F,
                                    int64_t S, int window, float pad_max, const float *h_taps, float bias, float pad_conv);
+
+/*
+ * The one pass over a class-innermost score volume d_scores [F,B,C] (zs[B,C] per frame,
+ * utils/protocol.py:538): every score is read ONCE and produces
+ *   d_out_max  [F,B,C]  = vdet_temporal_maxpool_f32(window, pad_max)        (vdet/tubelet_cls.py:386-414)
+ *   d_out_conv [F,B,C]  = vdet_temporal_conv_f32(h_taps[window], bias, pad_conv); h_taps NULL: none
+ *   and, inside the context, the class-major sort keys of all F*C per-(frame, class) problems
+ *   (score > score_thresh candidates only when use_score_thresh), which the next
+ *   vdet_nms_volume[_topk] (layout FBC) / vdet_track_volume / vdet_nms_track_volume call on the SAME
+ *   d_scores, shape and score threshold then uses instead of reading the volume again -- under the
+ *   vdet_set_cache contract (cache enabled, buffers unchanged in between; vdet_invalidate drops them).
+ * Bit-identical to the separate calls.  Shapes the fused kernel does not cover (C % 4 != 0, window
+ * other than 3 / 5, unaligned pointers) run the separate temporal kernels and leave no keys.
+ */
+int vdet_volume_pass(vdet_ctx *ctx, const float *d_scores, int64_t F, int64_t B, int64_t C, int window,
+                     float pad_max, const float *h_taps, float bias, float pad_conv, float *d_out_max,
+                     float *d_out_conv, int use_score_thresh, float score_thresh);
 
 /*
  * Greedy tubelet generation for every class of a score volume, device-resident: the array form of

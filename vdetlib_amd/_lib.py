@@ -11,7 +11,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvdet_hip.so")
 
-VDET_OK, VDET_EINVAL, VDET_ECAP, VDET_EHIP, VDET_EDIVZERO, VDET_ENOMEM, VDET_EINDEX = 0, -1, -2, -3, -4, -5, -6
+VDET_OK, VDET_EINVAL, VDET_ECAP, VDET_EHIP, VDET_EDIVZERO, VDET_ENOMEM, VDET_EINDEX, VDET_EAGAIN = 0, -1, -2, -3, -4, -5, -6, -7
 LAYOUT_FBC, LAYOUT_FCB = 0, 1
 
 # every symbol include/vdet_hip.h declares: (name, restype, argtypes)
@@ -30,6 +30,7 @@ SYMBOLS = {
     "vdet_query": (_ci, [_vp, _ci]),
     "vdet_set_cache": (_ci, [_vp, _ci]),
     "vdet_invalidate": (_ci, [_vp]),
+    "vdet_set_async": (_ci, [_vp, _ci]),
     "vdet_nms_f32": (_ci, [_vp, _vp, _i64, _i64, _ci, _f64, _vp, _vp, ctypes.POINTER(_i64)]),
     "vdet_track_det_nms_f32": (_ci, [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _f64, _vp, ctypes.POINTER(_i64)]),
     "vdet_iou_f64": (_ci, [_vp, _vp, _i64, _vp, _i64, _vp]),
@@ -40,6 +41,8 @@ SYMBOLS = {
     "vdet_threshold_topk": (_ci, [_vp, _vp, _ci, _i64, _i64, _ci, _ci, _f64, _ci, _vp, _vp]),
     "vdet_conv1d_f32": (_ci, [_vp, _vp, _ci, _ci, _vp, _vp, _ci, _ci, _ci, _vp]),
     "vdet_nms_volume": (_ci, [_vp, _vp, _vp, _ci, _i64, _i64, _i64, _f64, _ci, _f32, _vp, _vp, _i64]),
+    "vdet_nms_volume_topk": (_ci, [_vp, _vp, _vp, _ci, _i64, _i64, _i64, _f64, _ci, _f32, _ci, _vp, _vp, _i64]),
+    "vdet_volume_pass": (_ci, [_vp, _vp, _i64, _i64, _i64, _ci, _f32, _vp, _f32, _f32, _vp, _vp, _ci, _f32]),
     "vdet_track_volume": (_ci, [_vp, _vp, _vp, _i64, _i64, _i64, _f64, _f64, _ci, _f64, _ci, _vp, _vp, _vp]),
     "vdet_nms_track_volume": (_ci, [_vp, _vp, _vp, _i64, _i64, _i64, _f64, _f64, _ci, _f64, _ci, _vp, _vp, _vp,
                                     _i64, _vp, _vp]),
@@ -48,6 +51,13 @@ SYMBOLS = {
     "vdet_temporal_conv_f32": (_ci, [_vp, _vp, _vp, _i64, _i64, _vp, _ci, _f32, _f32]),
     "vdet_temporal_maxpool_conv_f32": (_ci, [_vp, _vp, _vp, _vp, _i64, _i64, _ci, _f32, _vp, _f32, _f32]),
 }
+
+
+
+class RetryError(RuntimeError):
+    """vdet_sync in asynchronous mode: a graph build outgrew its scratch; the scratch has been enlarged,
+    enqueue the same calls again (include/vdet_hip.h: VDET_EAGAIN)."""
+
 
 _lib = None
 _lock = threading.Lock()
@@ -130,6 +140,8 @@ class Context(object):
             raise MemoryError(msg)
         if rc == VDET_EINDEX:
             raise IndexError(msg or "list index out of range")
+        if rc == VDET_EAGAIN:
+            raise RetryError(msg)
         raise RuntimeError("libvdet_hip: %s (rc=%d)" % (msg, rc))
 
     def set_stream(self, stream_ptr):
@@ -146,6 +158,10 @@ class Context(object):
 
     def invalidate(self):
         self.check(self.lib.vdet_invalidate(self.h))
+
+    def set_async(self, on):
+        """No host synchronisation inside the volume entry points (include/vdet_hip.h: vdet_set_async)."""
+        self.check(self.lib.vdet_set_async(self.h, 1 if on else 0))
 
     def query(self, what):
         return int(self.lib.vdet_query(self.h, int(what)))

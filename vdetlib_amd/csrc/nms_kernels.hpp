@@ -65,6 +65,7 @@ constexpr uint16_t kZTag = 0x8000;
 constexpr int kStCap = 1;       // survivors > cap
 constexpr int kStDivZero = 2;   // evaluated zero-union pair
 constexpr int kStPool = 4;      // adjacency pool too small (internal, retried by the host)
+constexpr int kStPoolAsync = 8; // ... in an asynchronous build (no retry possible: reported by vdet_sync)
 constexpr uint32_t kFlagRegular = 1u;   // group_flags bit: see frame_flags_kernel
 
 // Sortable key of a float32 score: larger key == earlier in "argsort()[::-1]".
@@ -575,7 +576,7 @@ __global__ __launch_bounds__(256) void adj_build_kernel(const float4 *__restrict
                                                         unsigned long long *__restrict__ pool_used,
                                                         unsigned long long pool_cap, int *__restrict__ status,
                                                         const uint32_t *__restrict__ group_flags,
-                                                        const FrameIndex ix, float one_minus_t)
+                                                        const FrameIndex ix, float one_minus_t, int pool_bits)
 {
     __shared__ uint32_t sscan[256];
     __shared__ unsigned long long sbase;
@@ -645,7 +646,7 @@ __global__ __launch_bounds__(256) void adj_build_kernel(const float4 *__restrict
     const unsigned long long base = sbase;
     const uint32_t tile_total = sscan[4];
     if (base + tile_total > pool_cap || base + tile_total > 0xFFFFFFFFull) {
-        if (tid == 0) atomicOr(status, kStPool);
+        if (tid == 0) atomicOr(status, pool_bits);
         if (v < B) row_meta[gd.box_off + vo] = make_uint2(0u, 0u);
         return;
     }
@@ -728,6 +729,7 @@ struct SortParams {
     int32_t *ncand;           // [P]
     int lds_idxa_off, lds_idxb_off, lds_base_off;   // dynamic-LDS carve, multiples of 16
     int npass;                // 4 (debug knob VDET_SORT_PASSES: fewer passes = timing experiments only)
+    int topk;                 // > 0: only the topk best candidates stay candidates (vdet/video_det.py:93-95)
 };
 
 struct ProblemRef { int g, N, rb; int64_t sbase, sstride, obase; };
@@ -937,6 +939,50 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 && CPW <= 10) ? 8 : 1) void s
         __syncthreads();
         uint16_t *t = src; src = dst; dst = t;
     }
+    int ncand_out = ncand;
+    if (prm.topk > 0 && ncand > prm.topk) {
+        // vdet/video_det.py:93-95: top = argsort(-cls_scores)[:max_per_image] keeps, among candidates tied
+        // with the k-th best score, the LOWEST indices (stable argsort of the negated scores), while this
+        // list holds ties by DESCENDING index: move the last (k - a) entries of the tied run [a, b) that
+        // straddles position k to [a, k).  One wave; the run is one entry long unless scores tie.
+        const int k = prm.topk;
+        if (w == 0) {
+            auto key_at = [&](int q) -> uint32_t {
+                const int i = src[q];
+                if (prm.keys) return prm.keys[pr.sbase + i];
+                return score_key(prm.scores[pr.sbase + (int64_t)i * pr.sstride]);
+            };
+            const uint32_t kk = key_at(k - 1);
+            int a = k - 1, b = k;
+            for (;;) {          // extend the run downwards
+                const int q = a - 1 - lane;
+                const bool eq = q >= 0 && key_at(q) == kk;
+                const unsigned long long m = __ballot(eq);
+                const int n = m == ~0ull ? 64 : (__ffsll((unsigned long long)~m) - 1);
+                a -= n;
+                if (n < 64) break;
+            }
+            for (;;) {          // ... and upwards (candidates only)
+                const int q = b + lane;
+                const bool eq = q < ncand && key_at(q) == kk;
+                const unsigned long long m = __ballot(eq);
+                const int n = m == ~0ull ? 64 : (__ffsll((unsigned long long)~m) - 1);
+                b += n;
+                if (n < 64) break;
+            }
+            const int nsel = k - a, s0 = b - nsel;          // s0 >= a: an ascending chunked copy never reads what it wrote
+            if (s0 > a)
+                for (int t = 0; t < nsel; t += 64) {
+                    const bool v = t + lane < nsel;
+                    const uint16_t e = v ? src[s0 + t + lane] : (uint16_t)0;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    if (v) src[a + t + lane] = e;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                }
+        }
+        ncand_out = k;
+        __syncthreads();
+    }
     uint16_t *out = prm.order + pr.obase;
     if (((pr.obase | (int64_t)N) & 1) == 0) {      // two indices per lane: 256-B instead of 128-B stores per wave
         uint32_t *out2 = reinterpret_cast<uint32_t *>(out);
@@ -945,7 +991,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 && CPW <= 10) ? 8 : 1) void s
     } else {
         for (int v = tid; v < N; v += BLOCK) out[v] = src[v];
     }
-    if (tid == 0) prm.ncand[p] = ncand;
+    if (tid == 0) prm.ncand[p] = ncand_out;
 }
 
 // Self-test for ARANK (see sort_kernel): for each of the n patterns, every lane adds 1 to

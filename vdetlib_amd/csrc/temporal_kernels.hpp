@@ -11,6 +11,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "nms_kernels.hpp"     // score_key
+
 namespace vdet {
 
 struct Taps { float w[32]; };
@@ -134,6 +136,124 @@ __global__ __launch_bounds__(256) void temporal_both_vec4_kernel(const float4 *_
             r.z = r.z + t * v.z; r.w = r.w + t * v.w;
         }
         out_conv[f * S4 + s] = r;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The ONE pass over a score volume [F,B,C] (class innermost, as zs[B,C] of utils/protocol.py:538):
+// per element it is read once and produces
+//   out_max  [F,B,C]  temporal max-pool  (score_proto_temporal_maxpool, vdet/tubelet_cls.py:386-414)
+//   out_conv [F,B,C]  temporal convolution (stand-in for the external TCN of :15-51), optional
+//   keys     [F,C,B]  class-major sortable keys of every (frame, class) NMS problem (what
+//                     transpose_keys_kernel produced from a second read of the volume)
+// = 4 B in, 12 B out per element instead of 8 B in, 12 B out (and no strided 256-B reads: a block
+// owns TB whole rows of C scores, which are contiguous in memory).
+// Block = 256 threads, tile = TB boxes x C classes (C % 4 == 0), item i of thread t is float4
+// number t + 256*i of the tile; a thread walks the frames of its chunk with the window of every
+// item in registers (same arithmetic as temporal_both_vec4_kernel).  The keys of the centre frame
+// go through a double-buffered LDS tile [C/4][TB + 1] of uint4 (one barrier per frame) and leave as
+// TB*4-byte row segments.
+// ------------------------------------------------------------------------------------------------
+template <int W, int ITEMS, bool CONV>
+__global__ __launch_bounds__(256) void volume_pass_kernel(const float4 *__restrict__ in, float4 *__restrict__ out_max,
+                                                          float4 *__restrict__ out_conv, uint32_t *__restrict__ keys,
+                                                          int F, int B, int C4, int TB, int tb_shift, int fchunk,
+                                                          float pad_max, float pad_conv, float bias, Taps taps,
+                                                          int use_thr, float thr)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char vp_smem[];
+    uint4 *tile = reinterpret_cast<uint4 *>(vp_smem);            // [2][C4][TB + 1]
+    constexpr int H = W / 2;
+    const int tid = threadIdx.x;
+    const int b0 = blockIdx.x * TB;
+    const int rows = min(TB, B - b0);
+    const int n4 = rows * C4;                                    // valid float4 of this tile
+    const int f0 = blockIdx.y * fchunk;
+    const int f1 = min(F, f0 + fchunk);
+    if (f0 >= f1) return;
+    const int64_t S4 = (int64_t)B * C4;
+    const int pitch = TB + 1;
+    const int tile_sz = C4 * pitch;
+
+    int64_t goff[ITEMS];      // float4 offset inside a frame
+    int loff[ITEMS];          // LDS slot of the item's keys: [c4][b]
+    bool on[ITEMS];
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const int idx = tid + 256 * i;
+        on[i] = idx < n4;
+        const int idc = on[i] ? idx : 0;
+        const int b = idc / C4, c4 = idc - b * C4;
+        goff[i] = (int64_t)b0 * C4 + idc;
+        loff[i] = c4 * pitch + b;
+    }
+    float4 win[ITEMS][W];
+    bool ok[W];
+#pragma unroll
+    for (int k = 0; k < W - 1; ++k) {
+        const int g = f0 - H + k;
+        const int gc = min(max(g, 0), F - 1);
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) win[i][k + 1] = in[(int64_t)gc * S4 + goff[i]];
+        ok[k + 1] = (g == gc);
+    }
+    const float4 pm = splat4(pad_max), pc = splat4(pad_conv);
+    for (int f = f0; f < f1; ++f) {
+#pragma unroll
+        for (int k = 0; k < W - 1; ++k) {
+            ok[k] = ok[k + 1];
+#pragma unroll
+            for (int i = 0; i < ITEMS; ++i) win[i][k] = win[i][k + 1];
+        }
+        {
+            const int g = f + H;
+            const int gc = min(g, F - 1);
+#pragma unroll
+            for (int i = 0; i < ITEMS; ++i) win[i][W - 1] = in[(int64_t)gc * S4 + goff[i]];
+            ok[W - 1] = (g == gc);
+        }
+        uint4 *tb = tile + (f & 1) * tile_sz;
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            if (!on[i]) continue;
+            MaxAcc a;
+            a.init(ok[0] ? win[i][0] : pm);
+#pragma unroll
+            for (int k = 1; k < W; ++k) a.add(ok[k] ? win[i][k] : pm);
+            out_max[(int64_t)f * S4 + goff[i]] = a.get();
+            if (CONV) {
+                float4 r = splat4(bias);
+#pragma unroll
+                for (int k = 0; k < W; ++k) {
+                    const float t = taps.w[k];
+                    const float4 v = ok[k] ? win[i][k] : pc;
+                    r.x = r.x + t * v.x; r.y = r.y + t * v.y;
+                    r.z = r.z + t * v.z; r.w = r.w + t * v.w;
+                }
+                out_conv[(int64_t)f * S4 + goff[i]] = r;
+            }
+            const float4 s = win[i][H];
+            uint4 k4 = make_uint4(score_key(s.x), score_key(s.y), score_key(s.z), score_key(s.w));
+            if (use_thr) {
+                if (!(s.x > thr)) k4.x = 0u;
+                if (!(s.y > thr)) k4.y = 0u;
+                if (!(s.z > thr)) k4.z = 0u;
+                if (!(s.w > thr)) k4.w = 0u;
+            }
+            tb[loff[i]] = k4;
+        }
+        __syncthreads();       // (the other buffer was last read one iteration ago, before this barrier's predecessor)
+        uint32_t *kf = keys + (int64_t)f * C4 * 4 * B + b0;
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            const int idx = tid + 256 * i;                       // now (c4, b) with b fastest
+            const int c4 = idx >> tb_shift, b = idx & (TB - 1);
+            if (c4 < C4 && b < rows) {
+                const uint4 k4 = tb[c4 * pitch + b];
+                uint32_t *kr = kf + (int64_t)(c4 * 4) * B + b;
+                kr[0] = k4.x; kr[B] = k4.y; kr[2 * (int64_t)B] = k4.z; kr[3 * (int64_t)B] = k4.w;
+            }
+        }
     }
 }
 

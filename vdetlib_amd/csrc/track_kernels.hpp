@@ -457,15 +457,12 @@ struct SuppressParams {
     int *status;
     int mask_words;
     int lazy;                      // 1: the lists of regular frames are maintained by the pick
+    const int *n_irregular;        // device counter of irregular frames (frame_flags_kernel)
 };
 
-__global__ __launch_bounds__(256) void track_suppress_kernel(const SuppressParams prm)
+// one (frame, class) list p = f * C + c, one wave
+__device__ __forceinline__ void track_suppress_list(const SuppressParams &prm, lds_mask_t mask, int lane, int p)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    lds_mask_t mask = lds_mask_ptr(smem, w * prm.mask_words);
-    const int p = blockIdx.x * 4 + w;                 // p = f * C + c
-    if (p >= prm.F * prm.C) return;
     const int f = p / prm.C, c = p - f * prm.C;
     const TrackState s = prm.st[c];
     if (!s.active) return;
@@ -610,6 +607,21 @@ __global__ __launch_bounds__(256) void track_suppress_kernel(const SuppressParam
     if (lane == 0) prm.visited[p] = 1;
     if (lane == 0) prm.cnt[p] = nk;
     if (__ballot(bad != 0) && lane == 0) atomicOr(prm.status, kStDivZero);
+}
+
+// grid-stride over the lists (4 waves per block, one list each): a video whose frames are all regular
+// has nothing to do here when the pick maintains the lists lazily -- every block leaves after one load
+__global__ __launch_bounds__(256) void track_suppress_kernel(const SuppressParams prm)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (prm.lazy && prm.group_flags && *prm.n_irregular == 0) return;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    lds_mask_t mask = lds_mask_ptr(smem, w * prm.mask_words);
+    const int P = prm.F * prm.C;
+    for (int p = blockIdx.x * 4 + w; p < P; p += gridDim.x * 4) {
+        track_suppress_list(prm, mask, lane, p);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // the mask is reused by the next list
+    }
 }
 
 // close the iteration: count the finished track

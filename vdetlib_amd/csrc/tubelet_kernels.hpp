@@ -183,7 +183,9 @@ __global__ __launch_bounds__(256) void threshold_topk_kernel(const T *__restrict
         const int64_t b = b0 + tid;
         T s = 0;
         bool c = false;
-        if (b < B) { s = scores[b * ld + col]; c = (double)s > thresh; }
+        // np.where(scores[:, j] > thresh) with a python-float thresh (vdet/video_det.py:90): numpy compares in the
+        // ARRAY's dtype, i.e. float32 scores against float32(thresh) (round to nearest), float64 against thresh
+        if (b < B) { s = scores[b * ld + col]; c = s > (T)thresh; }
         sscan[tid] = c ? 1u : 0u;
         __syncthreads();
         for (int d = 1; d < 256; d <<= 1) {

@@ -54,11 +54,25 @@ enum Stage { ST_IOU_BITS = 0, ST_ADJ = 1, ST_SORTK = 2, ST_WALK = 3, ST_TEMPORAL
              ST_TRANSPOSE = 8, ST_TPICK = 9, ST_TLINK = 10, ST_TSUPP = 11, ST_RSPATIAL = 12, ST_RSERIES = 13, ST_COUNT = 16 };
 
 struct Counters {            // one small device block
+    // sticky until vdet_sync (or a synchronous graph build) reads and clears them
     int status;
-    unsigned int glob_cnt;
-    unsigned long long pool_used;
     int eindex;              // latched "IndexError" of the rescoring kernels
+    // per graph build (kPerBuildOff .. end): cleared when a build starts
+    unsigned int glob_cnt;
     int irregular;           // frames that are not "regular" (frame_flags_kernel), counted per graph build
+    unsigned long long pool_used;
+};
+constexpr size_t kPerBuildOff = 8;
+
+struct NmsPlan {
+    std::vector<GroupDesc> groups;   // bits_off is batch-local
+    std::vector<TileDesc> tiles;     // ordered by batch
+    std::vector<TilePair> pairs;     // upper-triangle 256x256 tile pairs, ordered by batch
+    std::vector<std::pair<int, int>> batch_tiles;  // [t0, t1) per batch
+    std::vector<std::pair<int, int>> batch_pairs;  // [p0, p1) per batch
+    size_t bits_words_max = 0;       // largest batch
+    int64_t ntot = 0;
+    int nmax = 0;
 };
 
 }  // namespace
@@ -87,8 +101,12 @@ struct vdet_ctx {
     bool sort_attr_set = false;
     // opt-in reuse of the per-video preparation (graph + sorted lists) between d_* calls
     bool cache_enabled = false;
-    struct PrepKey { const void *boxes = nullptr, *scores = nullptr; int64_t F = 0, B = 0, C = 0; float t32 = 0; int layout = -1, use_thr = 0; float thr = 0; } prep;
+    struct PrepKey { const void *boxes = nullptr, *scores = nullptr; int64_t F = 0, B = 0, C = 0; float t32 = 0; int layout = -1, use_thr = 0; float thr = 0; int topk = 0; } prep;
     bool graph_valid = false, lists_valid = false;
+    // class-major sort keys left in c->tkeys by vdet_volume_pass (reused like the other prep, cache on)
+    struct KeySrc { const void *scores = nullptr; int64_t F = 0, B = 0, C = 0; int use_thr = 0; float thr = 0; } keysrc;
+    bool keys_valid = false;
+    bool vpass_attr_set = false;
     bool index_valid = false; const void *index_boxes = nullptr; int64_t index_F = 0, index_B = 0;
     bool all_regular = false;     // last graph build: every frame regular
     bool wave_transpose = false;  // wave_transpose64 verified on this device (vdet_create); VDET_WAVE_TRANSPOSE=0 disables
@@ -96,6 +114,16 @@ struct vdet_ctx {
     bool no_lazy = false;         // VDET_NO_LAZY=1: eager track_det_nms of every crossed list (tests / A-B)
     bool no_index = false;        // VDET_NO_INDEX=1: disable the x-sorted proposal index (tests / A-B)
     const std::vector<GroupDesc> *host_groups = nullptr;   // group table of the call in flight (mode 2)
+    bool sym_built = false;       // the last graph build ran K0 + frame index + K1s (regular-frame fast path)
+    // volume geometry whose group / tile / pair tables are resident in c->groups / c->tiles / c->pairs
+    // (uploaded once per geometry: the host copy lives here so no call has to wait for the copies)
+    NmsPlan vplan;
+    bool vplan_valid = false;     // ... and the device tables still hold it
+    int64_t vplan_F = 0, vplan_B = 0;
+    size_t vplan_budget = 0;
+    // asynchronous video step (vdet_set_async): no host synchronisation inside the d_* entry points
+    bool async_enabled = false;
+    unsigned long long pool_hint = 0;   // adjacency entries used by the largest graph built so far
     bool atomic_rank = false;     // LDS returning atomics serve same-address lanes in lane order (probed)
     bool no_transpose = false;    // VDET_NO_TRANSPOSE=1 (tests / A-B)
     bool force_general = false;   // VDET_FORCE_GENERAL=1: disable the symmetric fast kernel (tests)
@@ -174,17 +202,6 @@ int translate_status(vdet_ctx *c, int st)
 // ---------------------------------------------------------------------------------------------
 // NMS orchestration
 // ---------------------------------------------------------------------------------------------
-struct NmsPlan {
-    std::vector<GroupDesc> groups;   // bits_off is batch-local
-    std::vector<TileDesc> tiles;     // ordered by batch
-    std::vector<TilePair> pairs;     // upper-triangle 256x256 tile pairs, ordered by batch
-    std::vector<std::pair<int, int>> batch_tiles;  // [t0, t1) per batch
-    std::vector<std::pair<int, int>> batch_pairs;  // [p0, p1) per batch
-    size_t bits_words_max = 0;       // largest batch
-    int64_t ntot = 0;
-    int nmax = 0;
-};
-
 int make_plan(vdet_ctx *c, NmsPlan &pl)
 {
     const size_t budget_words = std::max<size_t>(c->bits_budget / 8, 1);
@@ -253,12 +270,43 @@ FrameIndex frame_index_of(vdet_ctx *c)
     return FrameIndex{c->xbox.as<float4>(), c->xord.as<uint16_t>(), c->xcum.as<uint32_t>(), c->xinfo.as<float>()};
 }
 
-// K1 + K2 for every batch; retries once with a larger adjacency pool.  Synchronizes the stream.
-int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32, double thresh)
+// The plan of a regular volume (one group of B boxes per frame).  Built on the host once per geometry
+// and kept in the context: the host tables then outlive every asynchronous copy made from them, and a
+// video with the geometry of the previous one finds the device tables already in place.
+NmsPlan &volume_plan(vdet_ctx *c, int64_t F, int64_t B)
+{
+    if (c->vplan_F == F && c->vplan_B == B && c->vplan_budget == c->bits_budget && !c->vplan.groups.empty()) return c->vplan;
+    (void)hipStreamSynchronize(c->stream);     // (rare: geometry change) copies from the old tables may be in flight
+    c->vplan = NmsPlan();
+    c->vplan.groups.resize((size_t)F);
+    for (int64_t f = 0; f < F; ++f) c->vplan.groups[(size_t)f] = {(int32_t)(f * B), (int32_t)B, 0};
+    make_plan(c, c->vplan);
+    c->vplan_F = F; c->vplan_B = B; c->vplan_budget = c->bits_budget;
+    c->vplan_valid = false;
+    return c->vplan;
+}
+
+// host-buffer entry points: their group table dies with the call
+struct HostGroupsGuard {
+    vdet_ctx *c;
+    explicit HostGroupsGuard(vdet_ctx *ctx) : c(ctx) {}
+    ~HostGroupsGuard() { c->host_groups = nullptr; }
+};
+
+
+// K0 + index + K1(s) + K2 for every batch.
+//   volume == false (host-buffer entry points, plan owned by the caller): synchronous, retries once
+//     with a larger adjacency pool, clears the device status block (after picking up a failure
+//     latched by earlier asynchronous calls).
+//   volume == true  (pl == c->vplan): the tables are uploaded once per geometry.  With
+//     vdet_set_async and a pool size known from an earlier build there is NO host synchronisation:
+//     the status words stay sticky until vdet_sync, which also reports a pool overflow.
+int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32, double thresh, bool volume)
 {
     const float one_minus_t = (float)std::max(0.0, 1.0 - (thresh == thresh ? thresh : 0.0));
     const size_t G = pl.groups.size();
     c->host_groups = &pl.groups;
+    c->sym_built = false;
     HIPCHK(c, c->groups.reserve(G * sizeof(GroupDesc)));
     HIPCHK(c, c->tiles.reserve(std::max<size_t>(pl.tiles.size(), 1) * sizeof(TileDesc)));
     HIPCHK(c, c->bits.reserve(std::max<size_t>(pl.bits_words_max, 1) * 8));
@@ -267,42 +315,56 @@ int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32, doub
     HIPCHK(c, c->groupz.reserve(G * 4));
     HIPCHK(c, c->gflags.reserve(G * 4));
     HIPCHK(c, c->pairs.reserve(std::max<size_t>(pl.pairs.size(), 1) * sizeof(TilePair)));
-    if (!pl.pairs.empty())
-        HIPCHK(c, hipMemcpyAsync(c->pairs.p, pl.pairs.data(), pl.pairs.size() * sizeof(TilePair),
-                                 hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->groups.p, pl.groups.data(), G * sizeof(GroupDesc), hipMemcpyHostToDevice, c->stream));
-    if (!pl.tiles.empty())
-        HIPCHK(c, hipMemcpyAsync(c->tiles.p, pl.tiles.data(), pl.tiles.size() * sizeof(TileDesc),
-                                 hipMemcpyHostToDevice, c->stream));
-    // the host vectors must outlive the async copies; also pick up a failure latched by an earlier
-    // asynchronous call before the status word is cleared below
-    {
+    if (!(volume && c->vplan_valid)) {
+        if (!pl.pairs.empty())
+            HIPCHK(c, hipMemcpyAsync(c->pairs.p, pl.pairs.data(), pl.pairs.size() * sizeof(TilePair),
+                                     hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->groups.p, pl.groups.data(), G * sizeof(GroupDesc), hipMemcpyHostToDevice, c->stream));
+        if (!pl.tiles.empty())
+            HIPCHK(c, hipMemcpyAsync(c->tiles.p, pl.tiles.data(), pl.tiles.size() * sizeof(TileDesc),
+                                     hipMemcpyHostToDevice, c->stream));
+        c->vplan_valid = volume;         // (a host-call plan overwrites the volume tables)
+    }
+    const unsigned long long min_pool = (unsigned long long)pl.ntot * 32;
+    const bool async = volume && c->async_enabled && c->pool_hint > 0;
+    if (async) {
+        const unsigned long long want = std::max(min_pool, c->pool_hint + c->pool_hint / 2);
+        if (c->adj.cap < want * 2) HIPCHK(c, c->adj.reserve((size_t)want * 2 + 4096));
+    } else {
+        // the caller's host vectors must outlive the async copies; also pick up a failure latched by an
+        // earlier asynchronous call before the status word is cleared below
         Counters h0;
         HIPCHK(c, hipMemcpyAsync(&h0, c->d_cnt, sizeof h0, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (h0.status && !c->latched) c->latched = translate_status(c, h0.status);
         if (h0.eindex && !c->latched) c->latched = fail(c, VDET_EINDEX, "list index out of range");
+        if (c->adj.cap < min_pool * 2) HIPCHK(c, c->adj.reserve((size_t)min_pool * 2 + 4096));
     }
-    if (c->adj.cap < (size_t)pl.ntot * 32 * 2) HIPCHK(c, c->adj.reserve((size_t)pl.ntot * 32 * 2 + 4096));
 
     for (int attempt = 0; attempt < 2; ++attempt) {
         HIPCHK(c, hipMemsetAsync(c->rowz.p, 0, (size_t)pl.ntot * 4, c->stream));
         HIPCHK(c, hipMemsetAsync(c->rowmeta.p, 0, (size_t)pl.ntot * 8, c->stream));
         HIPCHK(c, hipMemsetAsync(c->groupz.p, 0, G * 4, c->stream));
-        HIPCHK(c, hipMemsetAsync(c->d_cnt, 0, sizeof(Counters), c->stream));
+        if (async) HIPCHK(c, hipMemsetAsync((char *)c->d_cnt + kPerBuildOff, 0, sizeof(Counters) - kPerBuildOff, c->stream));
+        else HIPCHK(c, hipMemsetAsync(c->d_cnt, 0, sizeof(Counters), c->stream));
         const unsigned long long pool_cap = c->adj.cap / 2;
         // fast symmetric kernel for regular frames needs 0 < t32 < inf (exact divide-free test)
         // ... and the x1 index, whose sort must fit the LDS (8 B per box + tables)
         const bool use_sym = t32 > 1e-30f && t32 < INFINITY && !c->force_general &&
                              (size_t)8 * pl.nmax + 24 * 1024 <= c->max_lds;
+        c->sym_built = use_sym;
         if (use_sym) {
             {
                 StageTimer tm(c, ST_OTHER);
                 hipLaunchKernelGGL(frame_flags_kernel, dim3((unsigned)G), dim3(256), 0, c->stream, d_boxes,
                                    c->groups.as<GroupDesc>(), c->gflags.as<uint32_t>(), &c->d_cnt->irregular);
             }
+            // (the index cache is keyed on the boxes pointer: never valid for the context's own scratch)
+            if (!volume) c->index_valid = false;
             const int rci = build_frame_index(c, d_boxes, pl.ntot, (int64_t)G, pl.nmax);
             if (rci) return rci;
+        } else {
+            c->index_valid = false;      // gflags / the x-index describe some earlier boxes
         }
         for (size_t bi = 0; bi < pl.batch_tiles.size(); ++bi) {
             const auto bt = pl.batch_tiles[bi];
@@ -343,15 +405,23 @@ int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32, doub
                                    c->bits.as<uint64_t>(), c->rowz.as<uint32_t>(), c->rowmeta.as<uint2>(),
                                    c->adj.as<uint16_t>(), &c->d_cnt->pool_used, pool_cap,
                                    &c->d_cnt->status, use_sym ? c->gflags.as<uint32_t>() : (const uint32_t *)nullptr,
-                                   use_sym ? frame_index_of(c) : FrameIndex{nullptr, nullptr, nullptr, nullptr}, one_minus_t);
+                                   use_sym ? frame_index_of(c) : FrameIndex{nullptr, nullptr, nullptr, nullptr}, one_minus_t,
+                                   async ? (kStPool | kStPoolAsync) : kStPool);
             }
         }
         HIPCHK(c, hipGetLastError());
+        if (async) {
+            c->all_regular = false;      // not known on the host: the tracking loop asks the device (n_irregular)
+            return VDET_OK;
+        }
         Counters h;
         HIPCHK(c, hipMemcpyAsync(&h, c->d_cnt, sizeof h, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         c->all_regular = use_sym && h.irregular == 0;
-        if (!(h.status & kStPool)) return VDET_OK;
+        if (!(h.status & kStPool)) {
+            c->pool_hint = std::max(c->pool_hint, h.pool_used);
+            return VDET_OK;
+        }
         if (h.pool_used > 0xFFFFFFFFull) return fail(c, VDET_ENOMEM, "suppression graph has more than 2^32 edges");
         if (attempt == 1) break;
         HIPCHK(c, c->adj.reserve((size_t)h.pool_used * 2 + 4096));
@@ -371,6 +441,7 @@ struct SortWalkArgs {
     const uint8_t *excl;
     int use_thr;
     float thr;
+    int topk = 0;
     int32_t *keep_idx;
     int32_t *keep_cnt;
     int64_t cap;
@@ -421,8 +492,12 @@ int launch_sort_walk(vdet_ctx *c, const SortWalkArgs &a, int nmax, int64_t order
     if (a.mode == 0 && !a.keys && !c->no_transpose && !a.walk_only) {
         // class-innermost volume: one coalesced transpose to [F,C,B] keys, then the sort reads rows
         const int64_t F = a.P / a.C;
+        const bool have_keys = c->cache_enabled && c->keys_valid && c->keysrc.scores == a.scores && c->keysrc.F == F &&
+                               c->keysrc.B == a.B && c->keysrc.C == a.C && c->keysrc.use_thr == (a.use_thr ? 1 : 0) &&
+                               (!a.use_thr || c->keysrc.thr == a.thr);     // left there by vdet_volume_pass
+        if (!have_keys) c->keys_valid = false;
         HIPCHK(c, c->tkeys.reserve((size_t)a.P * a.B * 4));
-        {
+        if (!have_keys) {
             StageTimer tm(c, ST_TRANSPOSE);
             hipLaunchKernelGGL(transpose_keys_kernel, dim3((a.B + 63) / 64, (a.C + 63) / 64, (unsigned)F), dim3(256), 0,
                                c->stream, a.scores, c->tkeys.as<uint32_t>(), a.B, a.C, a.use_thr, a.thr);
@@ -437,6 +512,7 @@ int launch_sort_walk(vdet_ctx *c, const SortWalkArgs &a, int nmax, int64_t order
     sp.order = a.order_out ? a.order_out : c->order.as<uint16_t>();
     sp.ncand = a.order_out ? a.ncand_out : c->ncand.as<int32_t>();
     sp.npass = 4;
+    sp.topk = a.topk;
     if (const char *e = getenv("VDET_SORT_PASSES")) sp.npass = atoi(e);
     const size_t keysB = r16((size_t)2 * std::max(nmax, 1));     // 16 key bits at a time (see sort_kernel)
     const size_t idxB = r16((size_t)2 * std::max(nmax, 1));
@@ -750,14 +826,14 @@ int vdet_set_cache(vdet_ctx *c, int enable)
 {
     if (!c) return VDET_EINVAL;
     c->cache_enabled = enable != 0;
-    c->graph_valid = c->lists_valid = c->index_valid = false;
+    c->graph_valid = c->lists_valid = c->index_valid = c->keys_valid = false;
     return VDET_OK;
 }
 
 int vdet_invalidate(vdet_ctx *c)
 {
     if (!c) return VDET_EINVAL;
-    c->graph_valid = c->lists_valid = c->index_valid = false;
+    c->graph_valid = c->lists_valid = c->index_valid = c->keys_valid = false;
     return VDET_OK;
 }
 
@@ -816,8 +892,26 @@ int vdet_sync(vdet_ctx *c)
     const int l = c->latched;
     c->latched = 0;
     if (l) return l;
+    if (h.status & kStPoolAsync) {
+        // an asynchronous graph build (vdet_set_async) ran out of adjacency pool: everything enqueued
+        // since is invalid.  The pool is enlarged here, so running the same calls again succeeds.
+        c->graph_valid = c->lists_valid = false;
+        c->pool_hint = std::max(c->pool_hint, h.pool_used);
+        if (h.pool_used <= 0xFFFFFFFFull) (void)c->adj.reserve((size_t)(h.pool_used + h.pool_used / 2) * 2 + 4096);
+        return fail(c, VDET_EAGAIN, "adjacency pool overflow in an asynchronous graph build (%llu entries needed): the "
+                                    "results since the last vdet_sync are invalid; the pool has been enlarged, run the calls again",
+                    (unsigned long long)h.pool_used);
+    }
+    c->pool_hint = std::max(c->pool_hint, h.pool_used);
     if (h.eindex) return fail(c, VDET_EINDEX, "list index out of range");
     return translate_status(c, h.status);
+}
+
+int vdet_set_async(vdet_ctx *c, int enable)
+{
+    if (!c) return VDET_EINVAL;
+    c->async_enabled = enable != 0;
+    return VDET_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -878,7 +972,10 @@ int vdet_nms_f32(vdet_ctx *c, const float *h_dets, int64_t n, int64_t ld, int nc
         d_keys = c->keys.as<uint32_t>();
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    int rc = build_graph(c, c->boxes.as<float4>(), pl, thresh_to_f32(thresh), thresh);
+    // the graph / lists / index of an earlier d_* call are overwritten below (shared scratch)
+    c->graph_valid = c->lists_valid = c->index_valid = false;
+    HostGroupsGuard guard(c);
+    int rc = build_graph(c, c->boxes.as<float4>(), pl, thresh_to_f32(thresh), thresh, false);
     if (rc) return rc;
     return nms_grouped_tail(c, pl, c->scores.as<float>(), d_keys, nullptr, h_keep, n_keep);
 }
@@ -928,8 +1025,10 @@ int vdet_track_det_nms_f32(vdet_ctx *c, const float *h_tracks, int64_t t, int64_
     HIPCHK(c, hipMemcpyAsync(c->trk_boxes.p, tb.data(), tb.size() * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->trk_frames.p, tf.data(), tf.size() * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->graph_valid = c->lists_valid = c->index_valid = false;     // shared scratch is overwritten below
+    HostGroupsGuard guard(c);
     // build_graph clears the status word, so round 1 runs after it (inside the same stream order):
-    rc = build_graph(c, c->boxes.as<float4>(), pl, t32, thresh);
+    rc = build_graph(c, c->boxes.as<float4>(), pl, t32, thresh, false);
     if (rc) return rc;
     {
         StageTimer tm(c, ST_OTHER);
@@ -970,8 +1069,16 @@ int vdet_nms_volume(vdet_ctx *c, const float *d_boxes, const float *d_scores, in
                     int64_t C, double thresh, int use_score_thresh, float score_thresh, int32_t *d_keep_idx,
                     int32_t *d_keep_cnt, int64_t cap)
 {
+    return vdet_nms_volume_topk(c, d_boxes, d_scores, layout, F, B, C, thresh, use_score_thresh, score_thresh, 0,
+                                d_keep_idx, d_keep_cnt, cap);
+}
+
+int vdet_nms_volume_topk(vdet_ctx *c, const float *d_boxes, const float *d_scores, int layout, int64_t F, int64_t B,
+                         int64_t C, double thresh, int use_score_thresh, float score_thresh, int topk,
+                         int32_t *d_keep_idx, int32_t *d_keep_cnt, int64_t cap)
+{
     if (!c) return VDET_EINVAL;
-    if (F < 0 || B < 0 || C < 0 || cap < 0 || (layout != VDET_LAYOUT_FBC && layout != VDET_LAYOUT_FCB))
+    if (F < 0 || B < 0 || C < 0 || cap < 0 || topk < 0 || (layout != VDET_LAYOUT_FBC && layout != VDET_LAYOUT_FCB))
         return fail(c, VDET_EINVAL, "bad shape/layout");
     if (F == 0 || C == 0) return VDET_OK;
     if (!d_keep_cnt || (cap > 0 && !d_keep_idx)) return fail(c, VDET_EINVAL, "null output");
@@ -989,15 +1096,11 @@ int vdet_nms_volume(vdet_ctx *c, const float *d_boxes, const float *d_scores, in
                           c->prep.B == B && memcmp(&c->prep.t32, &t32, 4) == 0;
     const bool same_lists = same_geo && c->lists_valid && c->prep.scores == d_scores && c->prep.C == C &&
                             c->prep.layout == layout && c->prep.use_thr == use_score_thresh &&
-                            (!use_score_thresh || c->prep.thr == score_thresh);
+                            (!use_score_thresh || c->prep.thr == score_thresh) && c->prep.topk == topk;
     int rc;
     if (!same_geo) {
         c->graph_valid = c->lists_valid = false;
-        NmsPlan pl;
-        pl.groups.resize((size_t)F);
-        for (int64_t f = 0; f < F; ++f) pl.groups[(size_t)f] = {(int32_t)(f * B), (int32_t)B, 0};
-        make_plan(c, pl);
-        rc = build_graph(c, reinterpret_cast<const float4 *>(d_boxes), pl, t32, thresh);
+        rc = build_graph(c, reinterpret_cast<const float4 *>(d_boxes), volume_plan(c, F, B), t32, thresh, true);
         if (rc) return rc;
         c->prep.boxes = d_boxes; c->prep.F = F; c->prep.B = B; c->prep.t32 = t32;
         c->graph_valid = true;
@@ -1006,12 +1109,12 @@ int vdet_nms_volume(vdet_ctx *c, const float *d_boxes, const float *d_scores, in
     a.walk_only = same_lists;
     a.mode = layout; a.P = (int)(F * C); a.B = (int)B; a.C = (int)C;
     a.scores = d_scores;
-    a.use_thr = use_score_thresh; a.thr = score_thresh;
+    a.use_thr = use_score_thresh; a.thr = score_thresh; a.topk = topk;
     a.keep_idx = d_keep_idx; a.keep_cnt = d_keep_cnt; a.cap = cap;
     rc = launch_sort_walk(c, a, (int)B, F * C * B);
     if (rc) return rc;
     c->prep.scores = d_scores; c->prep.C = C; c->prep.layout = layout; c->prep.use_thr = use_score_thresh;
-    c->prep.thr = score_thresh;
+    c->prep.thr = score_thresh; c->prep.topk = topk;
     c->lists_valid = true;
     return VDET_OK;
 }
@@ -1045,15 +1148,11 @@ int vdet_nms_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scor
     const bool same_geo = c->cache_enabled && c->graph_valid && c->prep.boxes == d_boxes && c->prep.F == F &&
                           c->prep.B == B && memcmp(&c->prep.t32, &t32, 4) == 0;
     const bool same_lists = same_geo && c->lists_valid && c->prep.scores == d_scores && c->prep.C == C &&
-                            c->prep.layout == VDET_LAYOUT_FBC && c->prep.use_thr == 0 && !c->no_transpose;
+                            c->prep.layout == VDET_LAYOUT_FBC && c->prep.use_thr == 0 && c->prep.topk == 0 && !c->no_transpose;
     int rc;
     if (!same_geo) {
         c->graph_valid = c->lists_valid = false;
-        NmsPlan pl;
-        pl.groups.resize((size_t)F);
-        for (int64_t f = 0; f < F; ++f) pl.groups[(size_t)f] = {(int32_t)(f * B), (int32_t)B, 0};
-        make_plan(c, pl);
-        rc = build_graph(c, reinterpret_cast<const float4 *>(d_boxes), pl, t32, nms_thres);
+        rc = build_graph(c, reinterpret_cast<const float4 *>(d_boxes), volume_plan(c, F, B), t32, nms_thres, true);
         if (rc) return rc;
         c->prep.boxes = d_boxes; c->prep.F = F; c->prep.B = B; c->prep.t32 = t32;
         c->graph_valid = true;
@@ -1070,7 +1169,9 @@ int vdet_nms_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scor
         c->no_transpose = saved;
         if (rc) return rc;
     }
-    const bool regular_ok = t32 > 1e-30f && t32 < INFINITY && !c->force_general;
+    // regular-frame fast paths (lazy lists, x-window link): only when THIS graph build (or the cached
+    // one being reused) ran K0 + the frame index -- gflags / the index are stale otherwise
+    const bool regular_ok = c->sym_built;
     if (want_nms) {                  // the NMS survivors: one walk over the lists, before they are consumed
         SortWalkArgs a{};
         a.walk_only = true;
@@ -1116,8 +1217,10 @@ int vdet_nms_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scor
     lz.boxes = sp.boxes; lz.tracks = d_tracks; lz.t32 = t32;
     lz.t1 = c->heads.as<int32_t>(); lz.head = lz.t1 + F * C; lz.nkp = lz.head + F * C; lz.pos = lz.nkp + F * C;
     lz.group_flags = sp.lazy ? sp.group_flags : nullptr;
-    // the eager track_det_nms kernel is only needed for the lists the pick does not maintain
+    // the eager track_det_nms kernel is only needed for the lists the pick does not maintain; when the
+    // host does not know whether every frame is regular (asynchronous build) the kernel asks the device
     const bool need_suppress = !sp.lazy || !sp.group_flags || !c->all_regular;
+    sp.n_irregular = &c->d_cnt->irregular;
     const float link_t32 = thresh_to_f32(link_thres);
     for (int t = 0; t < max_tracks; ++t) {
         {
@@ -1136,7 +1239,8 @@ int vdet_nms_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scor
         if (c->debug_sync) { fprintf(stderr, "[vdet] iter %d link...\n", t); HIPCHK(c, hipStreamSynchronize(c->stream)); fprintf(stderr, "[vdet] iter %d link ok\n", t); }
         if (need_suppress) {
             StageTimer tm(c, ST_TSUPP);
-            hipLaunchKernelGGL(track_suppress_kernel, dim3((unsigned)((F * C + 3) / 4)), dim3(256),
+            const int64_t nblk = (F * C + 3) / 4;     // grid-stride: a video without irregular frames exits at once
+            hipLaunchKernelGGL(track_suppress_kernel, dim3((unsigned)std::min<int64_t>(nblk, 8 * c->n_cu)), dim3(256),
                                (size_t)sp.mask_words * 16, c->stream, sp);
         }
         if (c->debug_sync) { fprintf(stderr, "[vdet] iter %d suppress...\n", t); HIPCHK(c, hipStreamSynchronize(c->stream)); fprintf(stderr, "[vdet] iter %d suppress ok\n", t); }
@@ -1162,19 +1266,22 @@ int vdet_rescore_tracks(vdet_ctx *c, const float *d_tracks, const int32_t *d_ntr
     timing_reset(c);
     FrameIndex ix{nullptr, nullptr, nullptr, nullptr};
     const uint32_t *flags = nullptr;
-    if (!c->no_index && !c->force_general && B <= 18000) {
+    if (!c->no_index && !c->force_general && (size_t)8 * B + 24 * 1024 <= c->max_lds) {   // (the x1 sort must fit the LDS)
         // per-frame regular flags + x-sorted index: reused from the graph build of the same boxes
         // when the cache is on, else rebuilt here (cheap: one 3 M-key sort)
         const bool have = c->cache_enabled && c->graph_valid && c->index_valid && c->prep.boxes == d_boxes &&
                           c->prep.F == F && c->prep.B == B && c->index_boxes == d_boxes;
         if (!have) {
-            c->graph_valid = c->lists_valid = c->index_valid = false;       // c->groups is rewritten
+            c->graph_valid = c->lists_valid = c->index_valid = false;       // gflags / the index are rewritten
+            NmsPlan &pl = volume_plan(c, F, B);
+            c->host_groups = &pl.groups;
             HIPCHK(c, c->groups.reserve((size_t)F * sizeof(GroupDesc)));
             HIPCHK(c, c->gflags.reserve((size_t)F * 4));
-            std::vector<GroupDesc> g((size_t)F);
-            for (int64_t f = 0; f < F; ++f) g[(size_t)f] = {(int32_t)(f * B), (int32_t)B, 0};
-            HIPCHK(c, hipMemcpyAsync(c->groups.p, g.data(), (size_t)F * sizeof(GroupDesc), hipMemcpyHostToDevice, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (!c->vplan_valid) {
+                // (only the group table is needed here; tiles / pairs follow with the next graph build)
+                HIPCHK(c, hipMemcpyAsync(c->groups.p, pl.groups.data(), (size_t)F * sizeof(GroupDesc), hipMemcpyHostToDevice, c->stream));
+            }
+            c->sym_built = false;
             hipLaunchKernelGGL(frame_flags_kernel, dim3((unsigned)F), dim3(256), 0, c->stream,
                                reinterpret_cast<const float4 *>(d_boxes), c->groups.as<GroupDesc>(), c->gflags.as<uint32_t>(),
                                &c->d_cnt->irregular);
@@ -1499,6 +1606,79 @@ int vdet_temporal_maxpool_conv_f32(vdet_ctx *c, const float *d_in, float *d_out_
     if (window == 3) VDET_TB(3); else if (window == 5) VDET_TB(5); else VDET_TB(7);
 #undef VDET_TB
     HIPCHK(c, hipGetLastError());
+    return VDET_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+int vdet_volume_pass(vdet_ctx *c, const float *d_scores, int64_t F, int64_t B, int64_t C, int window, float pad_max,
+                     const float *h_taps, float bias, float pad_conv, float *d_out_max, float *d_out_conv,
+                     int use_score_thresh, float score_thresh)
+{
+    if (!c) return VDET_EINVAL;
+    if (window < 1 || window % 2 != 1) return fail(c, VDET_EINVAL, "Window size must be odd!");
+    if (window > 31) return fail(c, VDET_EINVAL, "taps: K must be odd and <= 31");
+    if (F < 0 || B < 0 || C < 0 || F * B * C > ((int64_t)1 << 40)) return fail(c, VDET_EINVAL, "bad shape");
+    if (F == 0 || B == 0 || C == 0) return VDET_OK;
+    const bool conv = h_taps != nullptr;
+    if (!d_scores || !d_out_max || (conv && !d_out_conv) || d_scores == d_out_max || (conv && (d_scores == d_out_conv || d_out_max == d_out_conv)))
+        return fail(c, VDET_EINVAL, "bad volume_pass arguments");
+    if (B > 32767 || F * C > 0x7FFFFFF0ll || F * B > 0x7FFFFFF0ll) return fail(c, VDET_EINVAL, "volume too large");
+    c->keys_valid = false;
+    // tile: TB boxes (a power of two, >= 16 so that a key row segment is >= 64 B) x C classes in <= 256 * ITEMS float4
+    const int64_t C4 = C / 4;
+    int items = 0, TB = 0;
+    if (C % 4 == 0 && (window == 3 || window == 5) && !c->no_transpose &&
+        (((uintptr_t)d_scores | (uintptr_t)d_out_max | (uintptr_t)(conv ? d_out_conv : d_out_max)) & 15) == 0) {
+        for (int it : {4, 8}) {
+            int tb = 64;
+            while (tb >= 16 && (int64_t)tb * C4 > 256 * it) tb >>= 1;
+            if (tb >= 16 && (it == 8 || tb >= 32)) { items = it; TB = tb; break; }
+        }
+        if (items && (size_t)2 * C4 * (TB + 1) * 16 > c->max_lds) items = 0;
+    }
+    if (!items) {
+        // shapes the fused kernel does not cover: the temporal pass(es) now, the key transpose with the sort
+        if (conv) return vdet_temporal_maxpool_conv_f32(c, d_scores, d_out_max, d_out_conv, F, B * C, window, pad_max, h_taps, bias, pad_conv);
+        return vdet_temporal_maxpool_f32(c, d_scores, d_out_max, F, B * C, window, pad_max);
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    timing_reset(c);
+    HIPCHK(c, c->tkeys.reserve((size_t)(F * C * B) * 4));
+    Taps taps{};
+    if (conv) for (int k = 0; k < window; ++k) taps.w[k] = h_taps[k];
+    const int ntiles = (int)((B + TB - 1) / TB);
+    int64_t chunks = std::min<int64_t>(std::max<int64_t>(F / 8, 1), (8 * c->n_cu + ntiles - 1) / ntiles);
+    chunks = std::max<int64_t>(1, std::min<int64_t>(chunks, 65535));
+    const int fchunk = (int)((F + chunks - 1) / chunks);
+    const dim3 grid((unsigned)ntiles, (unsigned)((F + fchunk - 1) / fchunk));
+    const size_t lds = (size_t)2 * C4 * (TB + 1) * 16;
+    int tb_shift = 0;
+    while ((1 << tb_shift) < TB) ++tb_shift;
+    const void *fn = nullptr;
+#define VDET_VP(WW, IT, CV) reinterpret_cast<const void *>(volume_pass_kernel<WW, IT, CV>)
+    if (window == 3) fn = items == 4 ? (conv ? VDET_VP(3, 4, true) : VDET_VP(3, 4, false)) : (conv ? VDET_VP(3, 8, true) : VDET_VP(3, 8, false));
+    else fn = items == 4 ? (conv ? VDET_VP(5, 4, true) : VDET_VP(5, 4, false)) : (conv ? VDET_VP(5, 8, true) : VDET_VP(5, 8, false));
+    if (!c->vpass_attr_set) {
+        for (const void *f : {VDET_VP(3, 4, true), VDET_VP(3, 4, false), VDET_VP(3, 8, true), VDET_VP(3, 8, false),
+                              VDET_VP(5, 4, true), VDET_VP(5, 4, false), VDET_VP(5, 8, true), VDET_VP(5, 8, false)})
+            HIPCHK(c, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->max_lds));
+        c->vpass_attr_set = true;
+    }
+#undef VDET_VP
+    const float4 *in4 = reinterpret_cast<const float4 *>(d_scores);
+    float4 *om = reinterpret_cast<float4 *>(d_out_max), *oc = reinterpret_cast<float4 *>(d_out_conv);
+    uint32_t *keys = c->tkeys.as<uint32_t>();
+    int Fi = (int)F, Bi = (int)B, C4i = (int)C4;
+    void *args[] = {&in4, &om, &oc, &keys, &Fi, &Bi, &C4i, &TB, &tb_shift, (void *)&fchunk, &pad_max, &pad_conv, &bias, &taps,
+                    &use_score_thresh, &score_thresh};
+    {
+        StageTimer tm(c, ST_TEMPORAL);
+        HIPCHK(c, hipLaunchKernel(fn, grid, dim3(256), args, lds, c->stream));
+    }
+    HIPCHK(c, hipGetLastError());
+    c->keysrc.scores = d_scores; c->keysrc.F = F; c->keysrc.B = B; c->keysrc.C = C;
+    c->keysrc.use_thr = use_score_thresh ? 1 : 0; c->keysrc.thr = score_thresh;
+    c->keys_valid = true;
     return VDET_OK;
 }
 

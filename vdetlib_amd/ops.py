@@ -25,13 +25,22 @@ def _ctx_for(t, ctx=None):
     return ctx
 
 
-def nms_volume(boxes, scores, thresh=0.3, score_thresh=None, cap=None, layout="FBC", sync=True, ctx=None):
+def _keep_buffer(shape, device, pad):
+    if pad:
+        return torch.full(shape, -1, dtype=torch.int32, device=device)
+    return torch.empty(shape, dtype=torch.int32, device=device)
+
+
+def nms_volume(boxes, scores, thresh=0.3, score_thresh=None, cap=None, layout="FBC", sync=True, ctx=None, topk=0,
+               pad=True):
     """Per-(frame, class) greedy NMS of a whole video (vdet/image_det.py:117-123 applied to every
     frame and class of vdet/video_det.py:89-99; == utils/nms.pyx vid_nms per class).
 
     boxes [F,B,4] f32, scores [F,B,C] (layout 'FBC', class innermost like zs[B,C]) or [F,C,B] ('FCB').
+    score_thresh / topk: the candidate selection of fast_rcnn_det_vid (vdet/video_det.py:89-99:
+    score > thresh, then the max_per_image best) on the device, before the NMS.
     Returns (keep_idx int32 [F,C,cap], keep_cnt int32 [F,C]); keep_idx[f,c,:cnt] are box indices in
-    descending score order, the rest is -1.
+    descending score order, the rest is -1 (pad=False: left uninitialised, saves one fill of the buffer).
     """
     if boxes.dtype != torch.float32 or scores.dtype != torch.float32:
         raise ValueError("Buffer dtype mismatch, expected 'float32_t'")
@@ -54,12 +63,12 @@ def nms_volume(boxes, scores, thresh=0.3, score_thresh=None, cap=None, layout="F
         raise ValueError("boxes must be [F,B,4]")
     cap = B if cap is None else int(cap)
     ctx = _ctx_for(boxes, ctx)
-    keep_idx = torch.full((F, C, cap), -1, dtype=torch.int32, device=boxes.device)
+    keep_idx = _keep_buffer((F, C, cap), boxes.device, pad)
     keep_cnt = torch.zeros((F, C), dtype=torch.int32, device=boxes.device)
-    ctx.check(ctx.lib.vdet_nms_volume(ctx.h, boxes.data_ptr(), scores.data_ptr(), lay, F, B, C, float(thresh),
-                                      0 if score_thresh is None else 1,
-                                      0.0 if score_thresh is None else float(score_thresh),
-                                      keep_idx.data_ptr(), keep_cnt.data_ptr(), cap))
+    ctx.check(ctx.lib.vdet_nms_volume_topk(ctx.h, boxes.data_ptr(), scores.data_ptr(), lay, F, B, C, float(thresh),
+                                           0 if score_thresh is None else 1,
+                                           0.0 if score_thresh is None else float(score_thresh), int(topk),
+                                           keep_idx.data_ptr(), keep_cnt.data_ptr(), cap))
     if sync:
         ctx.sync()
     return keep_idx, keep_cnt
@@ -74,7 +83,7 @@ def temporal_maxpool(vol, window, pad=-1e5, ctx=None):
         raise ValueError("Buffer dtype mismatch, expected 'float32_t'")
     vol = vol.contiguous()
     if window == 1:
-        return vol
+        return vol.clone()          # (a copy like every other window size, never an alias of the input)
     out = torch.empty_like(vol)
     F = vol.shape[0]
     S = vol.numel() // F if F else 0
@@ -116,6 +125,36 @@ def temporal_maxpool_conv(vol, window, taps, pad_max=-1e5, bias=0.0, pad_conv=0.
     ctx = _ctx_for(vol, ctx)
     ctx.check(ctx.lib.vdet_temporal_maxpool_conv_f32(ctx.h, vol.data_ptr(), out_m.data_ptr(), out_c.data_ptr(), F, S,
                                                      int(window), float(pad_max), t.ctypes.data, float(bias), float(pad_conv)))
+    return out_m, out_c
+
+
+def volume_pass(scores, window=3, taps=None, pad_max=-1e5, bias=0.0, pad_conv=0.0, score_thresh=None, ctx=None):
+    """ONE read of a score volume [F,B,C]: ``temporal_maxpool(scores, window, pad_max)``, optionally
+    ``temporal_conv(scores, taps, bias, pad_conv)`` (len(taps) == window), and -- left inside the context for
+    the next ``nms_volume`` / ``track_volume`` / ``nms_track_volume`` call on the SAME scores tensor (cache
+    enabled) -- the class-major sort keys of every (frame, class) problem (include/vdet_hip.h: vdet_volume_pass).
+    Returns (pooled, conv or None)."""
+    if window % 2 != 1:
+        raise ValueError('Window size must be odd!')
+    if scores.dtype != torch.float32:
+        raise ValueError("Buffer dtype mismatch, expected 'float32_t'")
+    if scores.dim() != 3:
+        raise ValueError("scores must be [F,B,C]")
+    t = None
+    if taps is not None:
+        t = np.ascontiguousarray(taps, dtype=np.float32)
+        if t.shape[0] != window:
+            raise ValueError('need one tap per window position')
+    scores = scores.contiguous()
+    F, B, C = scores.shape
+    ctx = _ctx_for(scores, ctx)
+    out_m = torch.empty_like(scores)
+    out_c = torch.empty_like(scores) if t is not None else None
+    ctx.check(ctx.lib.vdet_volume_pass(ctx.h, scores.data_ptr(), F, B, C, int(window), float(pad_max),
+                                       t.ctypes.data if t is not None else None, float(bias), float(pad_conv),
+                                       out_m.data_ptr(), out_c.data_ptr() if out_c is not None else None,
+                                       0 if score_thresh is None else 1,
+                                       0.0 if score_thresh is None else float(score_thresh)))
     return out_m, out_c
 
 
@@ -165,7 +204,7 @@ def track_volume(boxes, scores, nms_thres=0.3, thres=0.0, max_tracks=10, link_th
 
 
 def nms_track_volume(boxes, scores, nms_thres=0.3, thres=0.0, max_tracks=10, link_thres=0.5, max_frames=0, cap=None,
-                     sync=True, ctx=None):
+                     sync=True, ctx=None, pad=True):
     """``nms_volume`` (layout 'FBC', no score threshold) and ``track_volume`` of the same video in one
     call: both are greedy walks over the same sorted lists and suppression graph, and on regular
     videos one fused walk serves both (include/vdet_hip.h: vdet_nms_track_volume).  Results are
@@ -180,7 +219,7 @@ def nms_track_volume(boxes, scores, nms_thres=0.3, thres=0.0, max_tracks=10, lin
         raise ValueError("boxes must be [F,B,4]")
     cap = B if cap is None else int(cap)
     ctx = _ctx_for(boxes, ctx)
-    keep_idx = torch.full((F, C, cap), -1, dtype=torch.int32, device=boxes.device)
+    keep_idx = _keep_buffer((F, C, cap), boxes.device, pad)
     keep_cnt = torch.zeros((F, C), dtype=torch.int32, device=boxes.device)
     tracks = torch.full((C, max_tracks, F, 5), float('nan'), dtype=torch.float32, device=boxes.device)
     anchors = torch.zeros((C, max_tracks, 3), dtype=torch.float32, device=boxes.device)
@@ -221,8 +260,24 @@ def rescore_tracks(tracks, ntracks, boxes, scores, overlap_thres=0.7, window=3, 
     (:386-414).  Returns (det_score f64 [C,T,F], pooled f64 [C,T,F], boxes f32 [C,T,F,4])."""
     if window % 2 != 1:
         raise ValueError('Window size must be odd!')
+    if tracks.dtype != torch.float32 or boxes.dtype != torch.float32 or scores.dtype != torch.float32:
+        raise ValueError("Buffer dtype mismatch, expected 'float32_t'")
+    if ntracks.dtype != torch.int32:
+        raise ValueError("ntracks must be int32")
+    if tracks.dim() != 4 or tracks.shape[3] != 5:
+        raise ValueError("tracks must be [C,T,F,5]")
     C, T, F = tracks.shape[0], tracks.shape[1], tracks.shape[2]
+    if boxes.dim() != 3 or boxes.shape[0] != F or boxes.shape[2] != 4:
+        raise ValueError("boxes must be [F,B,4]")
     B = boxes.shape[1]
+    if tuple(scores.shape) != (F, B, C):
+        raise ValueError("scores must be [F,B,C]")
+    if tuple(ntracks.shape) != (C,):
+        raise ValueError("ntracks must be [C]")
+    for t in (tracks, ntracks, scores):
+        if not t.is_cuda or t.device != boxes.device:
+            raise ValueError("tracks, ntracks, boxes and scores must live on the same GPU")
+    ntracks = ntracks.contiguous()
     ctx = _ctx_for(boxes, ctx)
     det = torch.empty((C, T, F), dtype=torch.float64, device=boxes.device)
     pooled = torch.empty((C, T, F), dtype=torch.float64, device=boxes.device)
