@@ -1,0 +1,121 @@
+// valu_bench.hip -- VALU issue-rate microbenchmark for MI355X (gfx950): settles the ceiling the VALU-bound
+// kernels of libvdet_hip (K1s iou_bits_sym, the walk, the sort) are priced against.
+//   hipcc --offload-arch=gfx950 -O3 -o devtools/valu_bench devtools/valu_bench.hip && devtools/valu_bench
+// Every variant runs ITER iterations of 16 INDEPENDENT instructions per lane (8 accumulators x 2), at 8 and at
+// 4 waves per SIMD on all CUs, and reports lane-operations per second (one wave64 instruction = 64 lane-ops;
+// a packed f32 instruction counts 128) next to the guide's figure 256 CU x 4 SIMD x 32 lanes x 2.4 GHz = 7.86e13.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+constexpr int ITER = 4096;
+
+#define REP8(OP) OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7)
+
+// mode: 0 v_fma_f32  1 v_pk_fma_f32  2 v_max_f32  3 v_add_f32  4 v_pk_add_f32  5 v_pk_mul_f32
+//       6 v_cmp_ge_f32 + v_addc_co_u32 (K1s's bit accumulator)  7 v_add_u32  8 v_and_b32/v_lshlrev mix  9 v_min_f32+v_max_f32+v_sub
+template <int MODE>
+__global__ __launch_bounds__(256) void valu_kernel(float *out, float seed)
+{
+    float a[8];
+    float2 p[8];
+    unsigned u[8];
+    for (int i = 0; i < 8; ++i) { a[i] = seed + i + threadIdx.x * 1e-3f; p[i] = make_float2(a[i], a[i] * 0.5f); u[i] = (unsigned)threadIdx.x * 2654435761u + i; }
+    const float b = 1.0000001f, c = 1e-9f;
+    const float2 b2 = make_float2(b, b), c2 = make_float2(c, c);
+    for (int it = 0; it < ITER; ++it) {
+        if (MODE == 0) {
+#define OP(i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+            REP8(OP) REP8(OP)
+#undef OP
+        } else if (MODE == 1) {
+#define OP(i) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[i]) : "v"(b2), "v"(c2));
+            REP8(OP) REP8(OP)
+#undef OP
+        } else if (MODE == 2) {
+#define OP(i) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
+            REP8(OP) REP8(OP)
+#undef OP
+        } else if (MODE == 3) {
+#define OP(i) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
+            REP8(OP) REP8(OP)
+#undef OP
+        } else if (MODE == 4) {
+#define OP(i) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[i]) : "v"(c2));
+            REP8(OP) REP8(OP)
+#undef OP
+        } else if (MODE == 5) {
+#define OP(i) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[i]) : "v"(b2));
+            REP8(OP) REP8(OP)
+#undef OP
+        } else if (MODE == 6) {
+#define OP(i) asm volatile("v_cmp_ge_f32 vcc, %1, %2\n v_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(u[i]) : "v"(a[i]), "v"(c) : "vcc");
+            REP8(OP)
+#undef OP
+        } else if (MODE == 7) {
+#define OP(i) asm volatile("v_add_u32 %0, %0, %1" : "+v"(u[i]) : "v"(u[(i + 1) & 7]));
+            REP8(OP) REP8(OP)
+#undef OP
+        } else if (MODE == 8) {
+#define OP(i) asm volatile("v_lshrrev_b32 %0, 5, %0\n v_and_b32 %0, 0x3ff, %0" : "+v"(u[i]));
+            REP8(OP)
+#undef OP
+        } else {
+#define OP(i) asm volatile("v_max_f32 %0, %0, %1\n v_min_f32 %0, %0, %2" : "+v"(a[i]) : "v"(c), "v"(b));
+            REP8(OP)
+#undef OP
+        }
+    }
+    float s = 0;
+    for (int i = 0; i < 8; ++i) s += a[i] + p[i].x + p[i].y + (float)u[i];
+    if (s == 12345.678f) out[threadIdx.x] = s;
+}
+
+template <int MODE>
+double run(int blocks_per_cu, int ncu, float *d_out, int lane_ops_per_instr)
+{
+    hipEvent_t e0, e1;
+    CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+    const int grid = blocks_per_cu * ncu;
+    hipLaunchKernelGGL(valu_kernel<MODE>, dim3(grid), dim3(256), 0, 0, d_out, 1.0f);
+    CHK(hipDeviceSynchronize());
+    CHK(hipEventRecord(e0));
+    for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(valu_kernel<MODE>, dim3(grid), dim3(256), 0, 0, d_out, 1.0f);
+    CHK(hipEventRecord(e1));
+    CHK(hipEventSynchronize(e1));
+    float ms = 0;
+    CHK(hipEventElapsedTime(&ms, e0, e1));
+    const double instr = 16.0 * ITER * (double)grid * 4 /*waves*/ * 5;
+    return instr * lane_ops_per_instr / (ms * 1e-3);
+}
+
+int main()
+{
+    hipDeviceProp_t prop;
+    CHK(hipGetDeviceProperties(&prop, 0));
+    const int ncu = prop.multiProcessorCount;
+    float *d_out;
+    CHK(hipMalloc(&d_out, 4096));
+    printf("# %s, %d CUs, clock %d MHz; guide figure 256*4*32*2.4e9 = 7.86e13 lane-ops/s\n", prop.gcnArchName, ncu, prop.clockRate / 1000);
+    printf("variant,waves_per_simd,lane_ops_per_s,frac_of_7.86e13\n");
+    for (int bpc : {8, 4, 2}) {
+        const int wps = bpc;    // 256-thread blocks: bpc blocks/CU = bpc waves per SIMD
+#define ROW(NAME, MODE, LO) { const double r = run<MODE>(bpc, ncu, d_out, LO); printf("%s,%d,%.4g,%.3f\n", NAME, wps, r, r / 7.86e13); }
+        ROW("v_fma_f32", 0, 64)
+        ROW("v_pk_fma_f32(x2 lanes-ops)", 1, 128)
+        ROW("v_max_f32", 2, 64)
+        ROW("v_add_f32", 3, 64)
+        ROW("v_pk_add_f32(x2)", 4, 128)
+        ROW("v_pk_mul_f32(x2)", 5, 128)
+        ROW("v_cmp_ge_f32+v_addc_co_u32", 6, 64)
+        ROW("v_add_u32", 7, 64)
+        ROW("v_lshrrev_b32+v_and_b32", 8, 64)
+        ROW("v_max_f32+v_min_f32", 9, 64)
+#undef ROW
+    }
+    CHK(hipFree(d_out));
+    return 0;
+}

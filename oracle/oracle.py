@@ -321,9 +321,17 @@ def _iou_f32_row(cur, boxes):
 def iou_link_rows(boxes, anchor_frame0, anchor_box, link_thres=0.5, max_frames=0):
     """The build's tracker plug-in on arrays (parity UNPINNED: the reference's trackers are external
     MATLAB code).  boxes [F,B,4]; returns rows [F,5] (x1,y1,x2,y2,score), NaN where no box."""
+    return iou_link_rows_box(boxes, anchor_frame0, np.trunc(boxes[anchor_frame0, anchor_box]), link_thres, max_frames)
+
+
+def iou_link_rows_box(boxes, anchor_frame0, anchor_bbox, link_thres=0.5, max_frames=0):
+    """iou_link_rows from the (int-truncated) anchor BOX, the form a ``track_method`` plug-in receives
+    (vdet/track.py:225-226: track_method(vid_proto, anchor_frame_id, map(int, bbox), opts)).
+    tests/golden/make_golden.py hands exactly this function (+ the reference's own
+    tracks_proto_from_boxes) to the reference's greedily_track_from_raw_dets to pin the LINK stage."""
     F = boxes.shape[0]
     rows = np.full((F, 5), np.nan, dtype=np.float32)
-    anchor = np.trunc(boxes[anchor_frame0, anchor_box]).astype(np.float32)
+    anchor = np.asarray(anchor_bbox, dtype=np.float32)
     rows[anchor_frame0] = [anchor[0], anchor[1], anchor[2], anchor[3], 1.0]
     reach = F if max_frames <= 0 else int(np.ceil((max_frames + 1) / 2.)) - 1
     for direction in (1, -1):
@@ -418,7 +426,8 @@ def tcn_forward(x, layers):
     return (e / ssum).astype(f)
 
 
-def rescored_tubelets(boxes, scores, nms_thres, thres, max_tracks, link_thres, pool_thres, window):
+def rescored_tubelets(boxes, scores, nms_thres, thres, max_tracks, link_thres, pool_thres, window, max_frames=0,
+                      return_det=False):
     """greedy_track_volume for every class, then raw_dets_spatial_max_pooling + do_score_completion +
     score_proto_temporal_maxpool(window) of every tubelet (vdet/track.py:189-252,
     vdet/tubelet_cls.py:493-535, :284-303, :386-414) -- the array form of what
@@ -430,9 +439,10 @@ def rescored_tubelets(boxes, scores, nms_thres, thres, max_tracks, link_thres, p
     wtr = np.full((C, T, F, 5), np.nan, np.float32)
     wnt = np.zeros(C, np.int32)
     wsc = np.full((C, T, F), np.nan)
+    wdet = np.full((C, T, F), np.nan)
     wbx = np.full((C, T, F, 4), np.nan, np.float32)
     for c in range(C):
-        t_, a_, n_ = greedy_track_volume(boxes, scores[:, :, c], nms_thres, thres, T, link_thres, 0)
+        t_, a_, n_ = greedy_track_volume(boxes, scores[:, :, c], nms_thres, thres, T, link_thres, max_frames)
         wtr[c], wnt[c] = t_, n_
         for t in range(n_):
             fr = [f for f in range(F) if not np.isnan(t_[t, f, 0])]
@@ -444,5 +454,8 @@ def rescored_tubelets(boxes, scores, nms_thres, thres, max_tracks, link_thres, p
             comp = score_completion(s)
             pool = [max(comp[g] if 0 <= g < len(comp) else -1e5 for g in range(i - h, i + h + 1)) for i in range(len(comp))]
             wsc[c, t, fr] = pool
+            wdet[c, t, fr] = comp
             wbx[c, t, fr] = np.asarray(bx, np.float32)
+    if return_det:
+        return wtr, wnt, wsc, wbx, wdet
     return wtr, wnt, wsc, wbx

@@ -359,8 +359,76 @@ def g5_to_g12_protos(R, out):
     out['score_conv_cls'] = to_py(dict(inp=spr, blobs=net.calls, out=res))
 
 
+def g14_link(R):
+    """LINK + re-scoring pinned to the REFERENCE: its own greedily_track_from_raw_dets
+    (vdet/track.py:189-252) driven with a python track_method that is exactly the build's IoU-linking
+    tracker (oracle.iou_link_rows_box) wrapped in the reference's tracks_proto_from_boxes
+    (utils/protocol.py:389-414), then the reference's raw_dets_spatial_max_pooling (+ do_score_completion,
+    vdet/tubelet_cls.py:493-535, :284-303) and score_proto_temporal_maxpool (:386-414) on those tracks.
+    Only the outputs are stored (tests/golden/link_golden.npz); inputs come from tests/synth.py seeds."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import oracle
+    P, T, K, Cm = R['P'], R['T'], R['K'], R['Cm']
+    import io
+    import contextlib
+    npz = {}
+    for case in synth.LINK_CASES:
+        boxes, scores = synth.link_case_video(case)
+        F, B, C = scores.shape
+        name = 'link_' + case['name']
+        vid = synth.make_vid_proto(name, F)
+        frames = np.repeat(np.arange(1, F + 1), B).astype(np.float64)
+        det_info = np.hstack([frames[:, None], boxes.reshape(-1, 4).astype(np.float64), scores.reshape(-1, C).astype(np.float64)])
+        frame_to_det = {f + 1: (boxes[f], scores[f]) for f in range(F)}
+
+        def iou_link_tracker(vid_proto, anchor_frame_id, anchor_bbox, opts, boxes=boxes, case=case):
+            rows = oracle.iou_link_rows_box(boxes, anchor_frame_id - 1, np.asarray(list(anchor_bbox), np.float32),
+                                            case['link'], case['max_frames'])
+            return P.tracks_proto_from_boxes(rows, vid_proto['video'], anchor_frame_id, 1, 1)
+
+        Tm = case['max_tracks']
+        tracks = np.full((C, Tm, F, 5), np.nan, np.float32)
+        ntracks = np.zeros(C, np.int32)
+        anchor_frames = np.zeros((C, Tm), np.int32)
+        det = np.full((C, Tm, F), np.nan)
+        pooled = np.full((C, Tm, F), np.nan)
+        obox = np.full((C, Tm, F, 4), np.nan, np.float32)
+        for c in range(C):
+            opts = Cm.options({'max_tracks': Tm, 'thres': case['thres'], 'nms_thres': case['nms_thres']})
+            tp = K.greedily_track_from_raw_dets(vid, det_info, iou_link_tracker, c + 1, opts)
+            assert len(tp['tracks']) <= Tm
+            ntracks[c] = len(tp['tracks'])
+            for t, tracklet in enumerate(tp['tracks']):
+                for box in tracklet:
+                    tracks[c, t, box['frame'] - 1] = box['bbox'] + [box['score']]
+                    anchor_frames[c, t] = box['frame'] - box['anchor']
+            if not tp['tracks']:
+                continue
+            with contextlib.redirect_stdout(io.StringIO()):
+                sp = T.raw_dets_spatial_max_pooling(vid, copy.deepcopy(tp), frame_to_det, c + 1, case['pool'])
+            for t, tub in enumerate(sp['tubelets']):
+                for box in tub['boxes']:
+                    det[c, t, box['frame'] - 1] = box['det_score']
+                    obox[c, t, box['frame'] - 1] = box['bbox']
+            sp2 = T.score_proto_temporal_maxpool(copy.deepcopy(sp), case['window'])
+            for t, tub in enumerate(sp2['tubelets']):
+                for box in tub['boxes']:
+                    pooled[c, t, box['frame'] - 1] = box['det_score']
+        npz[name + '_tracks'] = tracks
+        npz[name + '_ntracks'] = ntracks
+        npz[name + '_anchor_frames'] = anchor_frames
+        npz[name + '_det'] = det
+        npz[name + '_pooled'] = pooled
+        npz[name + '_boxes'] = obox
+        print('  %-12s ntracks %s' % (case['name'], ntracks.tolist()))
+    np.savez_compressed(os.path.join(HERE, 'link_golden.npz'), **npz)
+
+
 def main():
     R = load_reference()
+    if '--link-only' in sys.argv:
+        g14_link(R)
+        return
     npz, index = {}, {}
     g1_nms(R, npz, index)
     g2_vid_nms(R, npz, index)
@@ -373,6 +441,7 @@ def main():
     g5_to_g12_protos(R, out)
     with gzip.open(os.path.join(HERE, 'proto_golden.json.gz'), 'wt') as f:
         json.dump(out, f, separators=(',', ':'), sort_keys=True)
+    g14_link(R)
     for fn in sorted(os.listdir(HERE)):
         print('%8d  %s' % (os.path.getsize(os.path.join(HERE, fn)), fn))
 

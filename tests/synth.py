@@ -251,3 +251,45 @@ def vid_with_objects(seed, F, B, C, n_obj=3):
                 boxes[f, b] = gtb + rng.randint(-6, 7, 4)
                 scores[f, b, o['cls'] - 1] = 0.6 + 0.39 * rng.rand()
     return np.round(boxes).astype(np.float32), scores, annot
+
+
+def coherent_video(seed, F, B, C, jitter=3, frac=False):
+    """Proposals that persist over time (frame f = frame 0 drifting + jitter) so that IoU links continue
+    from frame to frame; scores ~U(0,1) f32.  frac: fractional coordinates (int truncation matters)."""
+    rng = np.random.RandomState(seed)
+    base = boxes_1(rng, B)
+    boxes = np.stack([base + np.float32(f) * np.array([3, 2, 3, 2], np.float32) +
+                      rng.randint(-jitter, jitter + 1, (B, 4)).astype(np.float32) for f in range(F)], 0)
+    if frac:
+        boxes = boxes + rng.uniform(0, 0.99, boxes.shape).astype(np.float32)
+    scores = rng.rand(F, B, C).astype(np.float32)
+    return boxes.astype(np.float32), scores
+
+
+# LINK-stage golden cases (tests/golden/make_golden.py g14 <-> tests/test_link_golden*.py)
+LINK_CASES = [
+    dict(name='plain', seed=1401, F=8, B=200, C=3, max_tracks=4, thres=0.0, max_frames=0, nms_thres=0.3, link=0.5, pool=0.7, window=3),
+    dict(name='ties', seed=1402, F=5, B=64, C=2, max_tracks=6, thres=0.5, max_frames=0, nms_thres=0.3, link=0.5, pool=0.5, window=3, frame_ranks=True),
+    dict(name='max_frames', seed=1403, F=12, B=300, C=2, max_tracks=5, thres=0.0, max_frames=5, nms_thres=0.3, link=0.5, pool=0.7, window=5),
+    dict(name='thres_stop', seed=1404, F=9, B=250, C=2, max_tracks=12, thres=0.997, max_frames=0, nms_thres=0.3, link=0.5, pool=0.7, window=3),
+    dict(name='frac', seed=1405, F=7, B=180, C=2, max_tracks=4, thres=0.0, max_frames=0, nms_thres=0.4, link=0.45, pool=0.6, window=3, frac=True),
+    dict(name='multi_class', seed=1406, F=10, B=500, C=4, max_tracks=3, thres=0.0, max_frames=0, nms_thres=0.3, link=0.5, pool=0.7, window=7),
+    dict(name='incoherent', seed=1407, F=6, B=400, C=2, max_tracks=5, thres=0.0, max_frames=0, nms_thres=0.3, link=0.5, pool=0.7, window=3, random=True),
+    dict(name='loose_link', seed=1408, F=8, B=150, C=2, max_tracks=12, thres=0.0, max_frames=3, nms_thres=0.5, link=0.2, pool=0.3, window=3),
+]
+
+
+def link_case_video(case):
+    if case.get('random'):
+        boxes, scores = video(case['seed'], case['F'], case['B'], case['C'], kind='randn')
+        scores = (1.0 / (1.0 + np.exp(-scores))).astype(np.float32)
+    else:
+        boxes, scores = coherent_video(case['seed'], case['F'], case['B'], case['C'], frac=bool(case.get('frac')))
+    if case.get('frame_ranks'):
+        # every frame holds the SAME set of score values (ranks / B): the anchor order ties across frames at every
+        # level (vdet/track.py:200's stable sort decides: lowest flat index first) while no two detections of one
+        # frame tie -- ties inside a frame would hit the reference's unstable argsort in vid_nms (utils/nms.pyx:80),
+        # which no implementation can reproduce (SURVEY section 7, hard part 2)
+        ranks = np.argsort(np.argsort(scores, axis=1), axis=1)
+        scores = ((ranks + 0.5) / scores.shape[1]).astype(np.float32)
+    return boxes, scores

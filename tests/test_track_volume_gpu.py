@@ -9,13 +9,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _coherent_video(seed, F, B, C, jitter=3):
-    """Proposals that persist over time (frame f = frame 0 drifting + jitter) so links continue."""
-    rng = np.random.RandomState(seed)
-    base = synth.boxes_1(rng, B)
-    boxes = np.stack([base + np.float32(f) * np.array([3, 2, 3, 2], np.float32) +
-                      rng.randint(-jitter, jitter + 1, (B, 4)).astype(np.float32) for f in range(F)], 0)
-    scores = rng.rand(F, B, C).astype(np.float32)
-    return boxes.astype(np.float32), scores
+    return synth.coherent_video(seed, F, B, C, jitter)
 
 
 @pytest.mark.parametrize("cfg", [dict(seed=1, F=8, B=200, C=5, max_tracks=4, thres=0.0, max_frames=0),

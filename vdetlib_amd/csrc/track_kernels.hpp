@@ -233,14 +233,14 @@ __device__ __forceinline__ float4 trunc4(float4 b)   // int(cor) of utils/protoc
 // buffered LDS slot, every thread finishes the reduction redundantly.  The step is a serial chain
 // executed by every wave, so a SMALL block wins: with 1024 threads the replicated serial part cost
 // ~7 us per frame (measured), the x-window leaves only ~2 000 candidates per frame anyway.
-constexpr int LT = 256;      // (512 threads: 14.8 vs 13.2 ms per video -- every wave replays the serial part)
+// LT = threads per chain (template parameter; 256 by default, VDET_LINK_THREADS selects 64 / 128 for A-B runs)
 
 // One batch of the x-window scan of track_link_kernel: WB boxes per thread starting at rank rb0.
 // All loads are issued before the first use (a load inside the ballot-branching loop body is waited
 // for immediately: one full memory latency per box, ~7 us per frame measured), and the boxes'
 // original indices (tie rule) come with them: fetching the index inside the passing branch was a
 // second, serialised memory round trip per passing iteration (16.4 -> 13.6 ms per video).
-template <int WB>
+template <int WB, int LT>
 __device__ __forceinline__ void link_scan(const float4 *__restrict__ xb, const uint16_t *__restrict__ xo, int rb0, int r1,
                                           int B, int tid, float4 cur, float carea, float link_t32, float t32e, float &bv,
                                           int &bi, float4 &bb)
@@ -266,7 +266,7 @@ __device__ __forceinline__ void link_scan(const float4 *__restrict__ xb, const u
         }
     }
 }
-static_assert(LT >= 256 && LT % 64 == 0, "the bucket-table prefetch of track_link_kernel needs at least 256 threads");
+template <int LT>
 __global__ __launch_bounds__(LT) void track_link_kernel(const float4 *__restrict__ boxes, int F, int B, int max_tracks,
                                                           float link_t32, int reach, const TrackState *__restrict__ st,
                                                           float *__restrict__ tracks,
@@ -277,6 +277,8 @@ __global__ __launch_bounds__(LT) void track_link_kernel(const float4 *__restrict
     __shared__ int si[2][LT / 64];
     __shared__ float4 sb[2][LT / 64];          // the winning box travels with its score: no dependent global load
     __shared__ uint32_t scum[2][260];     // next frame's bucket table + (xmin, scale, wmax), prefetched
+    static_assert(LT % 64 == 0 && LT >= 64 && LT <= 1024, "whole waves");
+    constexpr int NPF = (260 + LT - 1) / LT;   // table entries prefetched per thread
 
     const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int dir = blockIdx.y == 0 ? 1 : -1;
@@ -319,7 +321,7 @@ __global__ __launch_bounds__(LT) void track_link_kernel(const float4 *__restrict
         const float v2 = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(-1.0f), __float_as_int(bv), CTRL, ROWMASK, 0xf, false)); \
         const int i2 = __builtin_amdgcn_update_dpp(-1, bi, CTRL, ROWMASK, 0xf, false); \
         if (i2 >= 0 && (bi < 0 || v2 > bv || (v2 == bv && i2 < bi))) { bv = v2; bi = i2; } }
-#define LSCAN(W) link_scan<W>(xb, xo, rb0, r1, B, tid, cur, carea, link_t32, t32e, bv, bi, bb);
+#define LSCAN(W) link_scan<W, LT>(xb, xo, rb0, r1, B, tid, cur, carea, link_t32, t32e, bv, bi, bb);
     for (int step = 1; step <= reach; ++step) {
         const int f = s.anchor_frame + dir * step;
         if (f < 0 || f >= F) break;
@@ -340,11 +342,16 @@ __global__ __launch_bounds__(LT) void track_link_kernel(const float4 *__restrict
         // issued here, together with the box loads below, and stored to the other parity slot only
         // after the boxes were processed (the slot is read after this step's barrier; it was last
         // read one full step ago)
-        uint32_t pf0 = 0u, pf1 = 0u;
+        uint32_t pf[NPF];
+#pragma unroll
+        for (int j = 0; j < NPF; ++j) pf[j] = 0u;
         if (use_ix) {
             const int f2 = min(max(f + dir, 0), F - 1);
-            pf0 = ix.cum[(int64_t)f2 * 257 + min(tid, 255)];
-            pf1 = tid == 0 ? ix.cum[(int64_t)f2 * 257 + 256] : __float_as_uint(ix.info[f2 * 4 + min(tid - 1, 2)]);
+#pragma unroll
+            for (int j = 0; j < NPF; ++j) {
+                const int i = tid + j * LT;          // entries 0..256: cum, 257..259: xmin / scale / wmax
+                pf[j] = i < 257 ? ix.cum[(int64_t)f2 * 257 + i] : __float_as_uint(ix.info[f2 * 4 + min(i - 257, 2)]);
+            }
         }
         if (fast && use_ix) {
             // indexed frame: only the x-window that can reach IoU >= link_thres is read
@@ -398,8 +405,9 @@ __global__ __launch_bounds__(LT) void track_link_kernel(const float4 *__restrict
                 if (v > bv) { bv = v; bi = b; bb = x; }
             }
         if (use_ix) {
-            if (tid < 256) scum[par ^ 1][tid] = pf0;            // entries 0..255
-            if (tid < 4) scum[par ^ 1][tid == 0 ? 256 : 256 + tid] = pf1;   // 256, then xmin/scale/wmax
+#pragma unroll
+            for (int j = 0; j < NPF; ++j)
+                if (tid + j * LT < 260) scum[par ^ 1][tid + j * LT] = pf[j];
         }
         const int my_bi = bi;
         if (!use_ix) {   // prefetch frame f + dir

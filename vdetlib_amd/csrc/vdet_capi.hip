@@ -128,6 +128,7 @@ struct vdet_ctx {
     bool no_transpose = false;    // VDET_NO_TRANSPOSE=1 (tests / A-B)
     bool force_general = false;   // VDET_FORCE_GENERAL=1: disable the symmetric fast kernel (tests)
     bool topk_attr_set = false;
+    int link_threads = 256;       // VDET_LINK_THREADS=64|128|256: threads per link chain (A-B knob)
     size_t dyn_lds_max = 0;
 };
 
@@ -725,6 +726,7 @@ int vdet_create(vdet_ctx **out, int device)
     if (const char *e = getenv("VDET_NO_TRANSPOSE")) c->no_transpose = atoi(e) != 0;
     if (const char *e = getenv("VDET_NO_INDEX")) c->no_index = atoi(e) != 0;
     if (const char *e = getenv("VDET_NO_LAZY")) c->no_lazy = atoi(e) != 0;
+    if (const char *e = getenv("VDET_LINK_THREADS")) { const int v = atoi(e); if (v == 64 || v == 128 || v == 256) c->link_threads = v; }
     if (const char *e = getenv("VDET_DEBUG_SYNC")) c->debug_sync = atoi(e) != 0;
     {   // probe: do returning LDS atomics resolve same-address lanes in ascending lane order?
         const int npat = 4096;
@@ -1232,9 +1234,11 @@ int vdet_nms_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scor
         if (c->debug_sync) { fprintf(stderr, "[vdet] iter %d pick...\n", t); HIPCHK(c, hipStreamSynchronize(c->stream)); fprintf(stderr, "[vdet] iter %d pick ok\n", t); }
         {
             StageTimer tm(c, ST_TLINK);
-            hipLaunchKernelGGL(track_link_kernel, dim3((unsigned)C, 2), dim3(LT), 0, c->stream,
-                               reinterpret_cast<const float4 *>(d_boxes), (int)F, (int)B, max_tracks, link_t32, reach, st,
-                               d_tracks, sp.group_flags, sp.ix, link_thres);
+#define VDET_LINK(LTV) hipLaunchKernelGGL(track_link_kernel<LTV>, dim3((unsigned)C, 2), dim3(LTV), 0, c->stream, \
+                               reinterpret_cast<const float4 *>(d_boxes), (int)F, (int)B, max_tracks, link_t32, reach, st, \
+                               d_tracks, sp.group_flags, sp.ix, link_thres)
+            if (c->link_threads == 64) VDET_LINK(64); else if (c->link_threads == 128) VDET_LINK(128); else VDET_LINK(256);
+#undef VDET_LINK
         }
         if (c->debug_sync) { fprintf(stderr, "[vdet] iter %d link...\n", t); HIPCHK(c, hipStreamSynchronize(c->stream)); fprintf(stderr, "[vdet] iter %d link ok\n", t); }
         if (need_suppress) {
