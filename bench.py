@@ -31,17 +31,19 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK = 8.0e12          # B/s, MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
-def synth_video_cuda(torch, seed, F, B, C, device):
-    """boxes [F,B,4] (integer-valued f32, 1280x720, SURVEY 8d recipe), scores [F,B,C] f32 ~U(0,1)."""
+def synth_video_cuda(torch, seed, F, B, C, device, kind="rand"):
+    """boxes [F,B,4] (integer-valued f32, 1280x720, SURVEY 8d recipe), scores [F,B,C] f32 ~U(0,1) (softmax-like) or,
+    kind="randn", ~N(0,1) (SVM-margin-like: both signs, many exponents -- another radix-digit distribution for the sort)."""
     g = torch.Generator(device=device).manual_seed(seed)
     x1 = torch.rand(F, B, generator=g, device=device) * 1230
     y1 = torch.rand(F, B, generator=g, device=device) * 670
     w = 10 + torch.rand(F, B, generator=g, device=device) * 290
     h = 10 + torch.rand(F, B, generator=g, device=device) * 290
     boxes = torch.stack([x1, y1, torch.clamp(x1 + w, max=1279), torch.clamp(y1 + h, max=719)], -1).round().contiguous()
-    scores = torch.rand(F, B, C, generator=g, device=device)
-    if os.environ.get("VDET_BENCH_SCORES") == "randn":      # experiment: SVM-margin-like scores (many exponents, both signs)
+    if kind == "randn" or os.environ.get("VDET_BENCH_SCORES") == "randn":
         scores = torch.randn(F, B, C, generator=g, device=device)
+    else:
+        scores = torch.rand(F, B, C, generator=g, device=device)
     return boxes, scores
 
 
@@ -66,6 +68,10 @@ def main():
     ap.add_argument("--streams", type=int, default=4, help="videos in flight per GPU (one HIP stream + context each)")
     ap.add_argument("--cpu-problems", type=int, default=1200, help="(frame,class) problems timed on the CPU oracle")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--scores", choices=["rand", "randn"], default="rand", help="synthetic score distribution")
+    ap.add_argument("--separate-pass", action="store_true", help="temporal kernels + key transpose instead of the one volume pass")
+    ap.add_argument("--sync-build", action="store_true", help="synchronous graph builds (no vdet_set_async)")
+    ap.add_argument("--no-upload", action="store_true", help="skip the PCIe-fed pipeline leg (reported next to value, never part of it)")
     args = ap.parse_args()
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
         args.no_cpu = True       # the CPU baseline / mAP-parity / PCIe legs are reported at N = 1 only
@@ -90,46 +96,62 @@ def main():
     TOPK = 100
     TAPS = [0.25, 0.5, 0.25]     # the temporal convolution of the score volume (stand-in for the external TCN's first layer)
 
-    boxes, scores = synth_video_cuda(torch, 2000 + rank, F, B, C, dev)
-    ctx = _lib.get_context(local)
-    gathered = None
     # Consecutive videos are independent units of work: keep `--streams` of them in flight, each on its
     # own HIP stream with its own context (scratch buffers), so the latency-bound LINK kernels of one
-    # video overlap the VALU-bound graph build / walk of the next.  All results of all K steps are
-    # complete before the timed region ends (fence() synchronises the device).
+    # video overlap the VALU-bound graph build / walk of the next.  Every stream works on its OWN video
+    # (different boxes and scores).  All results of all K steps are complete before the timed region ends
+    # (fence() synchronises the device).
     nstreams = max(1, args.streams)
+    vids = [synth_video_cuda(torch, 2000 + 100 * rank + k, F, B, C, dev, args.scores) for k in range(nstreams)]
+    boxes, scores = vids[0]
+    ctx = _lib.get_context(local)
+    gathered = None
     ctxs = [ctx] + [_lib.Context(local) for _ in range(nstreams - 1)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
     for cx in ctxs:
-        cx.set_cache(True)   # NMS and LINK of one step share the suppression graph and the sorted lists
+        cx.set_cache(True)   # the volume pass, NMS and LINK of one step share keys, suppression graph and sorted lists
+        cx.set_async(not args.sync_build)   # no host synchronisation inside a step once the first graph was built
     step_no = [0]
+    upload_src = [None]      # --with-upload leg: pinned host videos fed over PCIe at the head of every step
 
     def step(exchange=True):
         nonlocal gathered
         k = step_no[0] % nstreams
+        n = step_no[0]
         step_no[0] += 1
         cx = ctxs[k]
+        vb, vs = vids[k]
         with torch.cuda.stream(streams[k]):
+            if upload_src[0] is not None:     # PCIe-fed pipeline: this stream's copy runs under the other streams' kernels
+                hb, hs = upload_src[0][n % len(upload_src[0])]
+                vb.copy_(hb, non_blocking=True)
+                vs.copy_(hs, non_blocking=True)
             cx.invalidate()     # a new video: nothing may be reused from the previous step
             tub = None
+            taps = None if (args.no_conv or args.window != len(TAPS)) else TAPS
+            if not args.separate_pass:   # ONE read of the score volume: temporal max-pool + convolution + the sort keys
+                pooled, conv = ops.volume_pass(vs, args.window, taps, ctx=cx)
             if args.no_link:
-                keep_idx, keep_cnt = ops.nms_volume(boxes, scores, args.thresh, cap=args.cap, sync=False, ctx=cx)
+                keep_idx, keep_cnt = ops.nms_volume(vb, vs, args.thresh, cap=args.cap, sync=False, ctx=cx, pad=False)
             elif args.separate:
-                keep_idx, keep_cnt = ops.nms_volume(boxes, scores, args.thresh, cap=args.cap, sync=False, ctx=cx)
-                tracks, anchors, ntracks = ops.track_volume(boxes, scores, nms_thres=args.thresh, thres=args.track_thres,
+                keep_idx, keep_cnt = ops.nms_volume(vb, vs, args.thresh, cap=args.cap, sync=False, ctx=cx, pad=False)
+                tracks, anchors, ntracks = ops.track_volume(vb, vs, nms_thres=args.thresh, thres=args.track_thres,
                                                             max_tracks=args.max_tracks, link_thres=args.link_thres,
                                                             sync=False, ctx=cx)
-            else:   # NMS survivors + tubelets from one call (one fused walk serves both greedy runs)
+            else:   # NMS survivors + tubelets from one call (same graph, same sorted lists)
                 keep_idx, keep_cnt, tracks, anchors, ntracks = ops.nms_track_volume(
-                    boxes, scores, nms_thres=args.thresh, thres=args.track_thres, max_tracks=args.max_tracks,
-                    link_thres=args.link_thres, cap=args.cap, sync=False, ctx=cx)
-            if args.no_conv or args.window != len(TAPS):
-                pooled = ops.temporal_maxpool(scores, args.window, ctx=cx)
-                conv = None if args.no_conv else ops.temporal_conv(scores, TAPS, bias=0.0, pad=0.0, ctx=cx)
-            else:   # both temporal operators from one read of the volume
-                pooled, conv = ops.temporal_maxpool_conv(scores, args.window, TAPS, ctx=cx)
+                    vb, vs, nms_thres=args.thresh, thres=args.track_thres, max_tracks=args.max_tracks,
+                    link_thres=args.link_thres, cap=args.cap, sync=False, ctx=cx, pad=False)
+            if args.separate_pass:
+                if taps is None:
+                    pooled = ops.temporal_maxpool(vs, args.window, ctx=cx)
+                    conv = None if args.no_conv else ops.temporal_conv(vs, TAPS, bias=0.0, pad=0.0, ctx=cx)
+                else:   # both temporal operators from one read of the volume
+                    pooled, conv = ops.temporal_maxpool_conv(vs, args.window, TAPS, ctx=cx)
+            elif conv is None and not args.no_conv:
+                conv = ops.temporal_conv(vs, TAPS, bias=0.0, pad=0.0, ctx=cx)
             if not args.no_link:
-                det, tpool, tboxes = ops.rescore_tracks(tracks, ntracks, boxes, scores, overlap_thres=args.pool_thres,
+                det, tpool, tboxes = ops.rescore_tracks(tracks, ntracks, vb, vs, overlap_thres=args.pool_thres,
                                                         window=args.window, sync=False, ctx=cx)
                 tub = (tracks, ntracks, tpool, tboxes)
             if world > 1 and exchange:   # the one exchange step: RCCL all-gather of the per-video results over xGMI
@@ -148,12 +170,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(max(args.warmup, nstreams)):
-        out = step()
-    fence()
-    for cx in ctxs:
-        cx.sync()
-    fence()
+    def warm():
+        for _ in range(max(args.warmup, nstreams)):
+            step()
+        fence()
+        for cx in ctxs:
+            cx.sync()
+        fence()
+
+    try:
+        warm()
+    except _lib.RetryError:      # an asynchronous graph build outgrew the scratch sized by the first video: enlarged, again
+        for cx in ctxs:
+            try:
+                cx.sync()
+            except _lib.RetryError:
+                pass
+        warm()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
@@ -177,7 +210,7 @@ def main():
         reps = 3
         for _ in range(reps):
             step_no[0] = 0          # per-kernel timing: one video at a time on stream 0
-            step(exchange=False)    # (rank 0 only: no collective here)
+            out = step(exchange=False)    # (rank 0 only: no collective here); video 0: the CPU parity sample below checks it
             torch.cuda.synchronize()
         ctx.sync()
         agg = {k: [ms, n] for k, (ms, n) in ctx.last_timing().items()}
@@ -195,6 +228,13 @@ def main():
                 traffic = json.load(open(pj)).get(dom, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        # what bounds each stage (VALU ceiling measured by devtools/valu_bench, profiles/)
+        BOUND = {"iou_bits": "valu", "adj_build": "latency/lds", "sort": "lds", "walk": "valu-issue", "temporal": "hbm",
+                 "transpose_keys": "hbm", "track_link": "latency (serial chain)", "track_pick": "latency", "rescore_spatial": "l2/valu",
+                 "rescore_series": "latency", "track_suppress": "valu-issue", "iou_bits_general": "valu", "other": "latency"}
+        for k, v in stages.items():
+            v["bound"] = BOUND.get(k, "")
+            v["hbm_frac_algorithmic"] = bytes_per_box * F * B / (v["ms_per_step"] * 1e-3) / HBM_PEAK
         roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK, "traffic": traffic,
                     "algorithmic_bytes_per_box": bytes_per_box,
@@ -203,9 +243,11 @@ def main():
         # the temporal kernel is the one genuinely HBM-bound stage: report its own stream rate too
         if "temporal" in stages:
             fused_t = (not args.no_conv) and args.window == len(TAPS)
-            # max-pool alone: read 4 B + write 4 B per element; fused with the convolution: read 4 + write 8
-            tb = (12.0 if fused_t else 8.0) * F * B * C
-            roofline["temporal_GBps"] = tb / (stages["temporal"]["avg_launch_ms"] * 1e-3) / 1e9
+            # bytes this stage really moves per element: read 4 + max-pool 4 (+ convolution 4) (+ the sort keys 4
+            # when it is the one volume pass)
+            tb = (8.0 + (4.0 if fused_t else 0.0) + (0.0 if args.separate_pass or C % 4 else 4.0)) * F * B * C
+            roofline["temporal_GBps"] = tb / (stages["temporal"]["ms_per_step"] * 1e-3) / 1e9
+            stages["temporal"]["hbm_frac_actual_bytes"] = roofline["temporal_GBps"] * 1e9 / HBM_PEAK
 
         cpu = None
         if not args.no_cpu:
@@ -249,7 +291,15 @@ def main():
                                               max_tracks=args.max_tracks, link_thres=args.link_thres)
                 ctx.invalidate()
                 parity = parity and int(gn[0]) == wn and bool(np.array_equal(gt[0, :wn].cpu().numpy(), wt[:wn], equal_nan=True))
+            ref_ratio = None
+            rj = os.path.join(ROOT, "oracle", "reference_ratio.json")
+            if os.path.isfile(rj):       # C port vs the reference's Cython module, measured in the build container
+                try:
+                    ref_ratio = json.load(open(rj))
+                except Exception:
+                    ref_ratio = None
             cpu = {"value": 1.0 / (t_nms_per_box + t_link_per_box), "unit": "boxes/s", "cores": 1, "kind": "port",
+                   "reference_ratio": ref_ratio,
                    "sample": sample + "; oracle/vdet_oracle.c + oracle/oracle.py, single thread; per-box times of the "
                                       "stages are added (value = boxes/s through the same stages as the GPU step)",
                    "nms_temp_boxes_per_s": 1.0 / t_nms_per_box, "parity_checked": parity}
@@ -266,7 +316,11 @@ def main():
                 if not args.no_conv:
                     oracle.temporal_conv(hs, TAPS, 0.0, 0.0)
                 mdt = time.perf_counter() - t4
+                same = [k for k in stages if not k.startswith(("track_", "rescore_"))]
+                gpu_same_ms = sum(stages[k]["ms_per_step"] for k in same)
                 cpu_all = {"value": cpu_boxes / mdt, "unit": "boxes/s", "cores": nthr, "kind": "port",
+                           "gpu_same_stages_boxes_per_s": F * B / (gpu_same_ms * 1e-3),
+                           "gpu_same_stages": "NMS+TEMP kernels of one video, one at a time (%s): %.2f ms" % ("+".join(sorted(same)), gpu_same_ms),
                            "sample": "NMS+TEMP only (no LINK), same %d nms problems on %d host threads in %.2f s"
                                      % (nf * nc, nthr, mdt),
                            "parity_checked": bool(np.array_equal(midx, widx) and np.array_equal(mcnt, wcnt))}
@@ -321,6 +375,45 @@ def main():
             except Exception as e:       # a host without enough lockable memory: report, do not fail the bench
                 pcie = {"error": str(e)[:200]}
 
+        upload = None
+        if not args.no_cpu and not args.no_upload and world == 1:
+            # the PCIe-fed pipeline -- every step first uploads its video (pinned host -> HBM on the
+            # step's own stream, so the copy of one video runs under the kernels of the others), then processes it.
+            # Reported NEXT to `value` (which is measured with HBM-resident inputs), never instead of it.
+            try:
+                nsrc = 2
+                src = []
+                for i in range(nsrc):
+                    hb = torch.empty(boxes.shape, dtype=torch.float32).pin_memory()
+                    hs = torch.empty(scores.shape, dtype=torch.float32).pin_memory()
+                    hb.copy_(vids[i % nstreams][0]); hs.copy_(vids[i % nstreams][1])
+                    src.append((hb, hs))
+                torch.cuda.synchronize()
+                upload_src[0] = src
+                step_no[0] = 0
+                for _ in range(nstreams):
+                    step(exchange=False)
+                torch.cuda.synchronize()
+                usteps = max(args.steps, 2 * nstreams)
+                t5 = time.perf_counter()
+                for _ in range(usteps):
+                    step(exchange=False)
+                torch.cuda.synchronize()
+                udt = time.perf_counter() - t5
+                for cx in ctxs:
+                    cx.sync()
+                upload_src[0] = None
+                nbytes = (scores.numel() + boxes.numel()) * 4
+                upload = {"boxes_per_s": F * B * usteps / udt, "ms_per_step": udt / usteps * 1e3, "steps": usteps,
+                          "h2d_GBps_sustained": nbytes * usteps / udt / 1e9,
+                          "pcie_bound_boxes_per_s": (pcie or {}).get("h2d_GBps", 0) * 1e9 / (nbytes / (F * B)) if pcie and "h2d_GBps" in pcie else None,
+                          "note": "every step uploads its own video from pinned host memory (%d videos in flight, copies overlap "
+                                  "the other streams' kernels), then runs the same step as `value`" % nstreams}
+                del src
+            except Exception as e:
+                upload_src[0] = None
+                upload = {"error": str(e)[:200]}
+
         result = {
             "metric": METRIC,
             "value": boxes_per_s, "unit": "boxes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -333,8 +426,10 @@ def main():
                                     ">= %.2f, spatial max-pool IoU > %.2f + completion + temporal max-pool" %
                                     (args.max_tracks, args.track_thres, args.link_thres, args.pool_thres),
                                     "; RCCL all-gather of the final tubelets + kept counts" if world > 1 else ""),
-                       "frames": F, "boxes": B, "classes": C, "parallelism": "video-per-gpu x%d, %d videos in flight per GPU" % (world, nstreams)},
+                       "frames": F, "boxes": B, "classes": C, "scores": args.scores,
+                       "parallelism": "video-per-gpu x%d, %d distinct videos in flight per GPU" % (world, nstreams)},
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_allcores": cpu_all, "map_parity": map_par, "pcie": pcie,
+            "upload_pipeline": upload,
         }
     if world > 1:
         dist.barrier()

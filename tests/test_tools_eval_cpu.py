@@ -9,7 +9,6 @@ import synth
 from vdetlib_amd import io as vio
 from vdetlib_amd import eval as vev
 from vdetlib_amd.tools import imagenet_annotation_processor as iap
-from vdetlib_amd.tools import gen_vid_proto_file as gvp
 from vdetlib_amd.utils import protocol as P
 
 XML = """<annotation><folder>v</folder><filename>{fn}</filename><source><database>ILSVRC_2015</database></source>
@@ -41,17 +40,6 @@ def test_annotation_processor(tmp_path):
     # the gt tracks feed the rest of the API
     tp = P.track_proto_from_annot_proto(a)
     assert tp['method'] == 'gt' and len(tp['tracks']) == 2
-
-
-def test_gen_vid_proto_cli(tmp_path):
-    d = tmp_path / 'frames'
-    d.mkdir()
-    for n in ('2.JPEG', '10.JPEG', '1.JPEG'):
-        (d / n).write_text('x')
-    out = tmp_path / 'p' / 'v.vid'
-    assert gvp.main(['myvid', str(d), str(out)]) == 0
-    v = P.proto_load(str(out))
-    assert v['video'] == 'myvid' and [f['path'] for f in v['frames']] == ['1.JPEG', '2.JPEG', '10.JPEG']
 
 
 def test_array_transport_roundtrip(tmp_path):

@@ -1,13 +1,17 @@
-"""Per-frame scoring glue, video NMS wrapper and the Fast R-CNN per-class threshold / top-k
-collection of the reference's vdet/video_det.py.  The CNN (``det_fun`` / ``net``) and the image
-reader are external plug-ins; the selection and NMS run on the GPU."""
-import copy
+"""Video-level detection stage (the API of the reference's vdet/video_det.py: same function names, argument
+order, defaults, dict keys and return containers), organised around ARRAYS instead of per-detection python
+lists: detections are grouped by frame once, the rows handed to the native NMS are assembled column-wise,
+and the per-class candidate selection of every frame runs on the GPU (``hot.threshold_topk`` ->
+``vdet_threshold_topk``; for device-resident score volumes the whole threshold -> top-k -> NMS chain is
+``ops.nms_volume(..., score_thresh=, topk=)``).  The CNN (``det_fun`` / ``net``) and the image reader are
+external plug-ins, exactly as in the reference."""
 import os
+from collections import defaultdict
 
 import numpy as np
 
 from .dataset import imagenet_vdet_classes
-from ..utils.protocol import empty_det_from_box, score_proto, det_score, boxes_at_frame, frame_path_at
+from ..utils.protocol import empty_det_from_box, score_proto, boxes_at_frame, frame_path_at
 from ..utils.common import imread
 from ..utils.log import logger as logging
 from ..utils.timer import Timer
@@ -15,76 +19,96 @@ from ..utils.cython_nms import vid_nms
 from .. import hot
 
 
+def _by_frame(items):
+    """{frame id: [items of that frame, in their original order]} -- one pass, instead of a rescan per frame."""
+    groups = defaultdict(list)
+    for it in items:
+        groups[it['frame']].append(it)
+    return groups
+
+
 def det_vid_with_box(vid_proto, box_proto, det_fun, net, class_names=imagenet_vdet_classes):
-    """:14-31 -- scores every proposal of every frame with ``det_fun(img, boxes, net)``."""
+    """Score every proposal with ``det_fun(img, boxes, net)`` (reference vdet/video_det.py:14-31).  Like the
+    reference, the returned det_proto REUSES the box dicts of ``box_proto`` (each gains a 'scores' list),
+    and frames without proposals are not read."""
     assert vid_proto['video'] == box_proto['video']
-    root = vid_proto['root_path']
     det_proto = empty_det_from_box(box_proto)
+    per_frame = _by_frame(det_proto['detections'])
     for frame in vid_proto['frames']:
-        frame_id, path = frame['frame'], frame['path']
-        det_cur_frame = [i for i in det_proto['detections'] if i['frame'] == frame_id]
-        if len(det_cur_frame) > 0:
-            logging.info("Detecting in frame {}, {} boxes...".format(frame_id, len(det_cur_frame)))
-            img = imread(os.path.join(root, path))
-            boxes = [det['bbox'] for det in det_cur_frame]
-            det_scores = det_fun(img, boxes, net)
-            for det, scores in zip(det_cur_frame, det_scores):
-                det['scores'] = score_proto(class_names, scores)
+        dets = per_frame.get(frame['frame'])
+        if not dets:
+            continue
+        logging.info("Detecting in frame {}, {} boxes...".format(frame['frame'], len(dets)))
+        img = imread(os.path.join(vid_proto['root_path'], frame['path']))
+        for det, scores in zip(dets, det_fun(img, [d['bbox'] for d in dets], net)):
+            det['scores'] = score_proto(class_names, scores)
     return det_proto
 
 
 def det_vid_without_box(vid_proto, det_fun, net, class_names=imagenet_vdet_classes):
-    """:34-40 -- proposals come from the external MATLAB selective search (vdet/proposal.py),
-    which is outside this build: supply a box_proto instead."""
+    """Reference :34-40 generates the proposals with MATLAB selective search (vdet/proposal.py), an external
+    engine outside this build: supply a box_proto."""
     raise RuntimeError("region proposals are an external engine (MATLAB selective search, "
                        "reference vdet/proposal.py); call det_vid_score with a box_proto")
 
 
 def det_vid_score(vid_proto, det_fun, net, box_proto=None, class_names=imagenet_vdet_classes):
-    if box_proto:
-        return det_vid_with_box(vid_proto, box_proto, det_fun, net, class_names)
-    return det_vid_without_box(vid_proto, det_fun, net, class_names)
+    """Reference :43-48."""
+    scorer = det_vid_with_box if box_proto else det_vid_without_box
+    args = (vid_proto, box_proto, det_fun, net) if box_proto else (vid_proto, det_fun, net)
+    return scorer(*args, class_names=class_names)
+
+
+def _vid_nms_rows(detections, class_index):
+    """float32 [N,6] rows (frame, x1,y1,x2,y2, score of ``class_index``) of a det_proto, assembled by column.
+    The class score is looked up BY KEY; a detection without that class scores -inf
+    (utils/protocol.py:323-327)."""
+    n = len(detections)
+    rows = np.empty((n, 6), dtype=np.float32)
+    if n:
+        rows[:, 0] = np.fromiter((d['frame'] for d in detections), dtype=np.float64, count=n)
+        rows[:, 1:5] = np.asarray([d['bbox'] for d in detections], dtype=np.float64).reshape(n, 4)
+        rows[:, 5] = np.fromiter((next((s['score'] for s in d['scores'] if s['class_index'] == class_index), float('-inf'))
+                                  for d in detections), dtype=np.float64, count=n)
+    return rows
 
 
 def apply_vid_nms(det_proto, class_index, thres=0.3):
-    """:51-61 -- NOTE the reference ignores ``thres`` and always uses 0.3 (:57); kept."""
+    """Per-class video NMS (reference :51-61): detections of different frames never suppress each other; the
+    survivors come back in descending score order.  NOTE: the reference ignores ``thres`` and always
+    suppresses at 0.3 (:57) -- kept, callers get the reference's results."""
     logging.info('Apply NMS on video: {}'.format(det_proto['video']))
-    boxes = np.asarray([[det['frame'], ] + det['bbox'] + [det_score(det, class_index), ]
-                        for det in det_proto['detections']], dtype='float32')
-    if boxes.ndim != 2:
-        boxes = boxes.reshape(0, 6)
-    keep = vid_nms(boxes, thresh=0.3)
-    new_det = {'video': det_proto['video'],
-               'detections': [det_proto['detections'][i] for i in keep]}
-    logging.info("{} / {} windows kept.".format(len(new_det['detections']), len(det_proto['detections'])))
-    return new_det
+    dets = det_proto['detections']
+    keep = vid_nms(_vid_nms_rows(dets, class_index), thresh=0.3)
+    kept = {'video': det_proto['video'], 'detections': [dets[i] for i in keep]}
+    logging.info("{} / {} windows kept.".format(len(kept['detections']), len(dets)))
+    return kept
 
 
 def fast_rcnn_det_vid(net, vid_proto, box_proto, det_fun, class_names=imagenet_vdet_classes,
                       max_per_image=100, thresh=0.05):
-    """:64-106 -- all_boxes[cls][frame] = float32 [n,5] (x1,y1,x2,y2,score) of the boxes with
-    score > thresh, cut to the max_per_image best.  ``det_fun(net, im, boxes) -> (scores
-    [B,C+1], boxes [B,4(C+1)])`` is the external CNN."""
-    num_images = len(vid_proto['frames'])
+    """Fast R-CNN over a video (reference :64-106): ``det_fun(net, im, boxes) -> (scores [B,C+1],
+    boxes [B,4(C+1)])`` is the external CNN; returns all_boxes[cls][frame] = float32 [n,5]
+    (x1,y1,x2,y2,score) of the proposals scoring > thresh, cut to the max_per_image best (class 0 =
+    background stays empty).  The selection of all classes of a frame is one GPU call."""
+    frames = vid_proto['frames']
     num_classes = len(class_names)
-    all_boxes = [[[] for _ in range(num_images)] for _ in range(num_classes)]
-    _t = {'im_detect': Timer(), 'misc': Timer()}
-    for i, frame in enumerate(vid_proto['frames']):
+    all_boxes = [[[] for _ in frames] for _ in range(num_classes)]
+    timers = {'im_detect': Timer(), 'misc': Timer()}
+    for i, frame in enumerate(frames):
         im = imread(frame_path_at(vid_proto, frame['frame']))
-        _t['im_detect'].tic()
-        orig_boxes = np.array([box['bbox'] for box in boxes_at_frame(box_proto, frame['frame'])])
-        scores, boxes = det_fun(net, im, orig_boxes)
-        _t['im_detect'].toc()
+        timers['im_detect'].tic()
+        proposals = np.array([box['bbox'] for box in boxes_at_frame(box_proto, frame['frame'])])
+        scores, boxes = (np.asarray(a) for a in det_fun(net, im, proposals))
+        timers['im_detect'].toc()
 
-        _t['misc'].tic()
-        scores = np.asarray(scores)
-        boxes = np.asarray(boxes)
-        selected = hot.threshold_topk(scores[:, :num_classes], thresh, max_per_image, col0=1)
-        for j in range(1, num_classes):
-            inds = selected[j - 1]
-            all_boxes[j][i] = np.hstack((boxes[inds, j * 4:(j + 1) * 4], scores[inds, j][:, np.newaxis])) \
+        timers['misc'].tic()
+        # per class j >= 1: indices of the boxes with score > thresh, best max_per_image first when cut
+        picked = hot.threshold_topk(scores[:, :num_classes], thresh, max_per_image, col0=1)
+        for j, inds in enumerate(picked, start=1):
+            all_boxes[j][i] = np.concatenate((boxes[inds, 4 * j:4 * j + 4], scores[inds, j, None]), axis=1) \
                 .astype(np.float32, copy=False)
-        _t['misc'].toc()
+        timers['misc'].toc()
         logging.info('im_detect: {:d}/{:d} {:.3f}s {:.3f}s'.format(
-            i + 1, num_images, _t['im_detect'].average_time, _t['misc'].average_time))
+            i + 1, len(frames), timers['im_detect'].average_time, timers['misc'].average_time))
     return all_boxes
