@@ -16,7 +16,9 @@ constexpr int ITER = 4096;
 #define REP8(OP) OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7)
 
 // mode: 0 v_fma_f32  1 v_pk_fma_f32  2 v_max_f32  3 v_add_f32  4 v_pk_add_f32  5 v_pk_mul_f32
-//       6 v_cmp_ge_f32 + v_addc_co_u32 (K1s's bit accumulator)  7 v_add_u32  8 v_and_b32/v_lshlrev mix  9 v_min_f32+v_max_f32+v_sub
+//       6 v_cmp_ge_f32 + v_addc_co_u32 (K1s's bit accumulator)  7 v_add_u32  8 v_and_b32/v_lshlrev mix  9 v_min_f32+v_max_f32
+//       10 v_max_i32  11 v_min_u32  12 v_cmp_ge_f32 into 4 SGPR pairs  13 v_mul_f32  14 v_max3_f32  15 v_cndmask_b32  16 v_min_f32
+//       17 v_med3_f32  18 v_sub_f32
 template <int MODE>
 __global__ __launch_bounds__(256) void valu_kernel(float *out, float seed)
 {
@@ -63,9 +65,49 @@ __global__ __launch_bounds__(256) void valu_kernel(float *out, float seed)
 #define OP(i) asm volatile("v_lshrrev_b32 %0, 5, %0\n v_and_b32 %0, 0x3ff, %0" : "+v"(u[i]));
             REP8(OP)
 #undef OP
-        } else {
+        } else if (MODE == 9) {
 #define OP(i) asm volatile("v_max_f32 %0, %0, %1\n v_min_f32 %0, %0, %2" : "+v"(a[i]) : "v"(c), "v"(b));
             REP8(OP)
+#undef OP
+        } else if (MODE == 10) {
+#define OP(i) asm volatile("v_max_i32 %0, %0, %1" : "+v"(u[i]) : "v"(u[(i + 1) & 7]));
+            REP8(OP) REP8(OP)
+#undef OP
+        } else if (MODE == 11) {
+#define OP(i) asm volatile("v_min_u32 %0, %0, %1" : "+v"(u[i]) : "v"(u[(i + 1) & 7]));
+            REP8(OP) REP8(OP)
+#undef OP
+        } else if (MODE == 12) {
+            unsigned long long m0, m1, m2, m3;
+            asm volatile("v_cmp_ge_f32 %0, %4, %8\n v_cmp_ge_f32 %1, %5, %8\n v_cmp_ge_f32 %2, %6, %8\n v_cmp_ge_f32 %3, %7, %8\n"
+                         "v_cmp_ge_f32 %0, %5, %8\n v_cmp_ge_f32 %1, %6, %8\n v_cmp_ge_f32 %2, %7, %8\n v_cmp_ge_f32 %3, %4, %8\n"
+                         "v_cmp_ge_f32 %0, %6, %8\n v_cmp_ge_f32 %1, %7, %8\n v_cmp_ge_f32 %2, %4, %8\n v_cmp_ge_f32 %3, %5, %8\n"
+                         "v_cmp_ge_f32 %0, %7, %8\n v_cmp_ge_f32 %1, %4, %8\n v_cmp_ge_f32 %2, %5, %8\n v_cmp_ge_f32 %3, %6, %8\n"
+                         : "=s"(m0), "=s"(m1), "=s"(m2), "=s"(m3) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(c));
+            u[0] += (unsigned)(m0 ^ m1 ^ m2 ^ m3);
+        } else if (MODE == 13) {
+#define OP(i) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+            REP8(OP) REP8(OP)
+#undef OP
+        } else if (MODE == 14) {
+#define OP(i) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(c), "v"(b));
+            REP8(OP) REP8(OP)
+#undef OP
+        } else if (MODE == 15) {
+#define OP(i) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(u[i]) : "v"(u[(i + 1) & 7]) : "vcc");
+            REP8(OP) REP8(OP)
+#undef OP
+        } else if (MODE == 16) {
+#define OP(i) asm volatile("v_min_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+            REP8(OP) REP8(OP)
+#undef OP
+        } else if (MODE == 17) {
+#define OP(i) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(c), "v"(b));
+            REP8(OP) REP8(OP)
+#undef OP
+        } else {
+#define OP(i) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
+            REP8(OP) REP8(OP)
 #undef OP
         }
     }
@@ -101,7 +143,7 @@ int main()
     CHK(hipMalloc(&d_out, 4096));
     printf("# %s, %d CUs, clock %d MHz; guide figure 256*4*32*2.4e9 = 7.86e13 lane-ops/s\n", prop.gcnArchName, ncu, prop.clockRate / 1000);
     printf("variant,waves_per_simd,lane_ops_per_s,frac_of_7.86e13\n");
-    for (int bpc : {8, 4, 2}) {
+    for (int bpc : {8, 2}) {
         const int wps = bpc;    // 256-thread blocks: bpc blocks/CU = bpc waves per SIMD
 #define ROW(NAME, MODE, LO) { const double r = run<MODE>(bpc, ncu, d_out, LO); printf("%s,%d,%.4g,%.3f\n", NAME, wps, r, r / 7.86e13); }
         ROW("v_fma_f32", 0, 64)
@@ -114,6 +156,15 @@ int main()
         ROW("v_add_u32", 7, 64)
         ROW("v_lshrrev_b32+v_and_b32", 8, 64)
         ROW("v_max_f32+v_min_f32", 9, 64)
+        ROW("v_max_i32", 10, 64)
+        ROW("v_min_u32", 11, 64)
+        ROW("v_cmp_ge_f32->sgpr", 12, 64)
+        ROW("v_mul_f32", 13, 64)
+        ROW("v_max3_f32", 14, 64)
+        ROW("v_cndmask_b32", 15, 64)
+        ROW("v_min_f32", 16, 64)
+        ROW("v_med3_f32", 17, 64)
+        ROW("v_sub_f32", 18, 64)
 #undef ROW
     }
     CHK(hipFree(d_out));

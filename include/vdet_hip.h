@@ -94,7 +94,9 @@ int vdet_set_async(vdet_ctx *ctx, int enable);
  * what = 1 -> number of compute units;
  * what = 2 -> 1 if every frame of the last SYNCHRONOUS suppression-graph build was "regular" (finite
  * boxes, positive width / height / area); 0 after an asynchronous build (not known on the host);
- * what = 3 -> 1 if the 64x64 in-wave bit transpose passed its self-test at vdet_create. */
+ * what = 3 -> 1 if the 64x64 in-wave bit transpose passed its self-test at vdet_create;
+ * what = 4 / 5 -> link steps of the last tracking call that were served by the link memo / that scanned their
+ * frame (synchronises the stream). */
 int vdet_query(vdet_ctx *ctx, int what);
 /* Per-stage HIP-event timing: 0 off (default), 1 on (events of the most recent call), 2 on and
  * accumulating over calls until vdet_last_timing_ms reads them. */

@@ -17,7 +17,7 @@ import sqlite3
 import sys
 
 STAGES = [("iou_bits_sym_kernel", "iou_bits"), ("iou_bits_kernel", "iou_bits_general"), ("adj_build_kernel", "adj_build"),
-          ("sort_kernel", "sort"), ("walk_kernel", "walk"), ("temporal_both_vec4_kernel", "temporal"), ("temporal_vec4_kernel", "temporal"),
+          ("sort_kernel", "sort"), ("walk_kernel", "walk"), ("volume_pass_kernel", "temporal"), ("temporal_both_vec4_kernel", "temporal"), ("temporal_vec4_kernel", "temporal"),
           ("transpose_keys_kernel", "transpose_keys"), ("track_pick_kernel", "track_pick"),
           ("track_link_kernel", "track_link"), ("track_suppress_kernel", "track_suppress"),
           ("rescore_spatial_kernel", "rescore_spatial"), ("rescore_series_kernel", "rescore_series")]

@@ -36,7 +36,7 @@ def test_bench_two_ranks_one_gpu_dry_run():
 def test_eight_virtual_ranks_reproduce_the_serial_result():
     import torch
     from vdetlib_amd import ops, dist as vd
-    C, K = 4, 64
+    C, K = 4, 640            # K >= the largest frame: every survivor list fits
     shapes = [(3 + (v % 4), 200 + 37 * v) for v in range(11)]          # (frames, boxes) per video
     vids = [synth.video(7000 + v, f, b, C) for v, (f, b) in enumerate(shapes)]
 

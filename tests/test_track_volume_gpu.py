@@ -290,7 +290,8 @@ def test_track_volume_random_sweep(oracle, seed):
 
 
 @pytest.mark.parametrize("knob", ["VDET_FORCE_GENERAL", "VDET_NO_INDEX", "VDET_NO_TRANSPOSE", "VDET_NO_LAZY",
-                                  "VDET_WAVE_TRANSPOSE=0", "VDET_ATOMIC_RANK=0"])
+                                  "VDET_WAVE_TRANSPOSE=0", "VDET_ATOMIC_RANK=0", "VDET_LINK_MEMO=0", "VDET_LINK_THREADS=64",
+                                  "VDET_LINK_THREADS=128"])
 def test_alternative_kernel_paths_agree(monkeypatch, knob):
     """Every A/B knob selects a different kernel path for the same result (general predicate kernel,
     no x-index, strided key reads, eager track_det_nms, ballot transposition in K1s, ballot ranks in
@@ -309,3 +310,20 @@ def test_alternative_kernel_paths_agree(monkeypatch, knob):
     got_r = ops.rescore_tracks(got[2], got[4], tb, ts, overlap_thres=0.6, window=3, ctx=cx)
     for a, b in zip(list(ref) + list(ref_r), list(got) + list(got_r)):
         assert np.array_equal(a.cpu().numpy(), b.cpu().numpy(), equal_nan=True), knob
+
+
+def test_link_memo_shares_steps_across_chains(oracle):
+    """Coherent proposals, several classes: chains of different classes / tracks run through the same nodes, so the
+    link memo serves a large share of the steps (vdet_query 4 / 5) -- with tubelets identical to the oracle's."""
+    import torch
+    from vdetlib_amd import ops, _lib
+    boxes, scores = synth.coherent_video(77, 40, 300, 6)
+    cx = _lib.Context(torch.cuda.current_device())
+    tr, an, nt = ops.track_volume(torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda(), thres=0.0, max_tracks=8, ctx=cx)
+    hits, misses = cx.query(4), cx.query(5)
+    assert hits + misses > 0 and misses > 0
+    assert hits > 0          # 48 chains on 300 coherent proposals do meet
+    for c in (0, 5):
+        wt, wa, wn = oracle.greedy_track_volume(boxes, scores[:, :, c], 0.3, 0.0, 8, 0.5, 0)
+        assert int(nt[c]) == wn and np.array_equal(tr[c, :wn].cpu().numpy(), wt[:wn], equal_nan=True)
+    cx.close()

@@ -112,3 +112,23 @@ def test_volume_pass_fallback_shapes(oracle):
     p7, _ = ops.volume_pass(s8, 7, ctx=cx)
     assert np.array_equal(p7.cpu().numpy(), oracle.temporal_maxpool(scores[:, :, :8], 7))
     cx.close()
+
+
+@pytest.mark.parametrize("knob", ["256,16", "512,32", "256,32", "512,64"])
+def test_volume_pass_tilings_agree(monkeypatch, oracle, knob):
+    """VDET_VPASS = threads,boxes-per-tile: every tiling of the pass gives the same three outputs."""
+    import torch
+    from vdetlib_amd import ops
+    F, B, C = 6, 211, 40 if knob in ("256,32", "512,64") else 200
+    boxes, scores = synth.video(4400, F, B, C)
+    tb, ts = torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda()
+    monkeypatch.setenv("VDET_VPASS", knob)
+    cx = _ctx()
+    cx.set_cache(True)
+    pooled, conv = ops.volume_pass(ts, 3, TAPS, ctx=cx)
+    idx, cnt = ops.nms_volume(tb, ts, 0.3, ctx=cx)
+    assert np.array_equal(pooled.cpu().numpy(), oracle.temporal_maxpool(scores, 3))
+    assert np.array_equal(conv.cpu().numpy(), oracle.temporal_conv(scores, TAPS, 0.0, 0.0))
+    widx, wcnt = oracle.nms_volume(boxes, scores, 0.3)
+    assert np.array_equal(cnt.cpu().numpy(), wcnt) and np.array_equal(idx.cpu().numpy(), widx)
+    cx.close()

@@ -148,21 +148,21 @@ __global__ __launch_bounds__(256) void temporal_both_vec4_kernel(const float4 *_
 //                     transpose_keys_kernel produced from a second read of the volume)
 // = 4 B in, 12 B out per element instead of 8 B in, 12 B out (and no strided 256-B reads: a block
 // owns TB whole rows of C scores, which are contiguous in memory).
-// Block = 256 threads, tile = TB boxes x C classes (C % 4 == 0), item i of thread t is float4
-// number t + 256*i of the tile; a thread walks the frames of its chunk with the window of every
+// Block = NT threads, tile = TB boxes x C classes (C % 4 == 0), item i of thread t is float4
+// number t + NT*i of the tile; a thread walks the frames of its chunk with the window of every
 // item in registers (same arithmetic as temporal_both_vec4_kernel).  The keys of the centre frame
-// go through a double-buffered LDS tile [C/4][TB + 1] of uint4 (one barrier per frame) and leave as
-// TB*4-byte row segments.
+// go through a double-buffered LDS tile [C][TB] (one barrier per frame; columns XOR-swizzled against bank
+// conflicts) and leave as 16-byte stores, TB*4 contiguous bytes per class row.
 // ------------------------------------------------------------------------------------------------
-template <int W, int ITEMS, bool CONV>
-__global__ __launch_bounds__(256) void volume_pass_kernel(const float4 *__restrict__ in, float4 *__restrict__ out_max,
-                                                          float4 *__restrict__ out_conv, uint32_t *__restrict__ keys,
-                                                          int F, int B, int C4, int TB, int tb_shift, int fchunk,
-                                                          float pad_max, float pad_conv, float bias, Taps taps,
-                                                          int use_thr, float thr)
+template <int W, int ITEMS, bool CONV, int NT>
+__global__ __launch_bounds__(NT) void volume_pass_kernel(const float4 *__restrict__ in, float4 *__restrict__ out_max,
+                                                         float4 *__restrict__ out_conv, uint32_t *__restrict__ keys,
+                                                         int F, int B, int C4, int TB, int tb_shift, int fchunk,
+                                                         float pad_max, float pad_conv, float bias, Taps taps,
+                                                         int use_thr, float thr)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char vp_smem[];
-    uint4 *tile = reinterpret_cast<uint4 *>(vp_smem);            // [2][C4][TB + 1]
+    uint32_t *tile = reinterpret_cast<uint32_t *>(vp_smem);      // [2][C][TB] keys, columns XOR-swizzled per class group
     constexpr int H = W / 2;
     const int tid = threadIdx.x;
     const int b0 = blockIdx.x * TB;
@@ -172,30 +172,44 @@ __global__ __launch_bounds__(256) void volume_pass_kernel(const float4 *__restri
     const int f1 = min(F, f0 + fchunk);
     if (f0 >= f1) return;
     const int64_t S4 = (int64_t)B * C4;
-    const int pitch = TB + 1;
-    const int tile_sz = C4 * pitch;
+    const int tile_sz = C4 * 4 * TB;
+    const int qmask = (TB >> 2) - 1;                             // 16-byte chunks per key row - 1
+    // everything per item is a 32-bit offset from a per-frame (wave-uniform) base: the frame's slab is < 2^31 B
+    const float4 *in_t = in + (int64_t)b0 * C4;
+    float4 *om_t = out_max + (int64_t)b0 * C4;
+    float4 *oc_t = CONV ? out_conv + (int64_t)b0 * C4 : nullptr;
 
-    int64_t goff[ITEMS];      // float4 offset inside a frame
+    int goff[ITEMS];          // float4 offset inside the tile (clamped: every load address is valid)
     int loff[ITEMS];          // LDS slot of the item's keys: [c4][b]
     bool on[ITEMS];
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
-        const int idx = tid + 256 * i;
+        const int idx = tid + NT * i;
         on[i] = idx < n4;
-        const int idc = on[i] ? idx : 0;
+        const int idc = min(idx, n4 - 1);
         const int b = idc / C4, c4 = idc - b * C4;
-        goff[i] = (int64_t)b0 * C4 + idc;
-        loff[i] = c4 * pitch + b;
+        goff[i] = idc;
+        // key (class 4*c4 + j, box b) sits at dword [(4*c4 + j) * TB + (b ^ s)], s = (c4 mod TB/4) * 4: the lanes of a wave
+        // (consecutive c4, same b) then spread over the banks (4-way instead of 32-way), and the 4 boxes of a 16-byte chunk
+        // stay together for the ds_read_b128 of the copy-out
+        loff[i] = 4 * c4 * TB + (b ^ ((c4 & qmask) << 2));
     }
     float4 win[ITEMS][W];
+    float4 nxt[ITEMS];        // frame f + H + 1, in flight while frame f is processed
     bool ok[W];
 #pragma unroll
     for (int k = 0; k < W - 1; ++k) {
         const int g = f0 - H + k;
         const int gc = min(max(g, 0), F - 1);
+        const float4 *fin = in_t + (int64_t)gc * S4;
 #pragma unroll
-        for (int i = 0; i < ITEMS; ++i) win[i][k + 1] = in[(int64_t)gc * S4 + goff[i]];
+        for (int i = 0; i < ITEMS; ++i) win[i][k + 1] = fin[goff[i]];
         ok[k + 1] = (g == gc);
+    }
+    {
+        const float4 *fin = in_t + (int64_t)min(f0 + H, F - 1) * S4;
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) nxt[i] = fin[goff[i]];
     }
     const float4 pm = splat4(pad_max), pc = splat4(pad_conv);
     for (int f = f0; f < f1; ++f) {
@@ -205,14 +219,17 @@ __global__ __launch_bounds__(256) void volume_pass_kernel(const float4 *__restri
 #pragma unroll
             for (int i = 0; i < ITEMS; ++i) win[i][k] = win[i][k + 1];
         }
-        {
-            const int g = f + H;
-            const int gc = min(g, F - 1);
+        ok[W - 1] = (f + H <= F - 1);
 #pragma unroll
-            for (int i = 0; i < ITEMS; ++i) win[i][W - 1] = in[(int64_t)gc * S4 + goff[i]];
-            ok[W - 1] = (g == gc);
+        for (int i = 0; i < ITEMS; ++i) win[i][W - 1] = nxt[i];
+        {   // next iteration's newest frame: issued now, first used after this iteration's stores and barrier
+            const float4 *fin = in_t + (int64_t)min(f + 1 + H, F - 1) * S4;
+#pragma unroll
+            for (int i = 0; i < ITEMS; ++i) nxt[i] = fin[goff[i]];
         }
-        uint4 *tb = tile + (f & 1) * tile_sz;
+        uint32_t *tb = tile + (f & 1) * tile_sz;
+        float4 *om = om_t + (int64_t)f * S4;
+        float4 *oc = CONV ? oc_t + (int64_t)f * S4 : nullptr;
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) {
             if (!on[i]) continue;
@@ -220,7 +237,7 @@ __global__ __launch_bounds__(256) void volume_pass_kernel(const float4 *__restri
             a.init(ok[0] ? win[i][0] : pm);
 #pragma unroll
             for (int k = 1; k < W; ++k) a.add(ok[k] ? win[i][k] : pm);
-            out_max[(int64_t)f * S4 + goff[i]] = a.get();
+            om[goff[i]] = a.get();
             if (CONV) {
                 float4 r = splat4(bias);
 #pragma unroll
@@ -230,7 +247,7 @@ __global__ __launch_bounds__(256) void volume_pass_kernel(const float4 *__restri
                     r.x = r.x + t * v.x; r.y = r.y + t * v.y;
                     r.z = r.z + t * v.z; r.w = r.w + t * v.w;
                 }
-                out_conv[(int64_t)f * S4 + goff[i]] = r;
+                oc[goff[i]] = r;
             }
             const float4 s = win[i][H];
             uint4 k4 = make_uint4(score_key(s.x), score_key(s.y), score_key(s.z), score_key(s.w));
@@ -240,18 +257,27 @@ __global__ __launch_bounds__(256) void volume_pass_kernel(const float4 *__restri
                 if (!(s.z > thr)) k4.z = 0u;
                 if (!(s.w > thr)) k4.w = 0u;
             }
-            tb[loff[i]] = k4;
+            tb[loff[i]] = k4.x; tb[loff[i] + TB] = k4.y; tb[loff[i] + 2 * TB] = k4.z; tb[loff[i] + 3 * TB] = k4.w;
         }
+        if (!keys) continue;   // (timing experiments only: VDET_VPASS_NOKEYS)
         __syncthreads();       // (the other buffer was last read one iteration ago, before this barrier's predecessor)
         uint32_t *kf = keys + (int64_t)f * C4 * 4 * B + b0;
+        const bool vec_ok = (B & 3) == 0;                        // every key row starts 16-byte aligned
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) {
-            const int idx = tid + 256 * i;                       // now (c4, b) with b fastest
-            const int c4 = idx >> tb_shift, b = idx & (TB - 1);
-            if (c4 < C4 && b < rows) {
-                const uint4 k4 = tb[c4 * pitch + b];
-                uint32_t *kr = kf + (int64_t)(c4 * 4) * B + b;
-                kr[0] = k4.x; kr[B] = k4.y; kr[2 * (int64_t)B] = k4.z; kr[3 * (int64_t)B] = k4.w;
+            const int idx = tid + NT * i;                        // now (class c, 16-byte chunk q of its row), q fastest:
+            const int cc = idx >> (tb_shift - 2), q = idx & qmask;   // a quad of lanes stores 64 contiguous bytes
+            if (cc < C4 * 4 && 4 * q < rows) {
+                const uint4 k4 = *reinterpret_cast<const uint4 *>(tb + cc * TB + ((4 * q) ^ (((cc >> 2) & qmask) << 2)));
+                const int o = cc * B + 4 * q;
+                if (vec_ok && 4 * q + 3 < rows) {
+                    *reinterpret_cast<uint4 *>(kf + o) = k4;
+                } else {
+                    kf[o] = k4.x;
+                    if (4 * q + 1 < rows) kf[o + 1] = k4.y;
+                    if (4 * q + 2 < rows) kf[o + 2] = k4.z;
+                    if (4 * q + 3 < rows) kf[o + 3] = k4.w;
+                }
             }
         }
     }

@@ -444,6 +444,274 @@ __global__ __launch_bounds__(LT) void track_link_kernel(const float4 *__restrict
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same tracker with a LINK MEMO.  One link step is a pure function of the node it starts from:
+//     next(f, j, dir) = argmax_k IoU(trunc(box[f][j]), box[f + dir][k])   (>= link_thres, first index on ties)
+// -- it depends neither on the class nor on the track, and every chain (2 000 per config-2 video: 200
+// classes x 10 tracks, ~300 steps each) walks the same functional graph.  Chains that meet stay
+// together, so most steps of most chains were already computed by another chain: memo[dir][f][j]
+// holds (valid | index + 1 | IoU bits) of every step taken so far in this video, a step first looks
+// there (ONE 8-byte load instead of a scan of the frame's ~2 400-box IoU window) and only scans on a
+// miss.  Values are deterministic, so concurrent chains racing on an entry write the same 8 bytes
+// (relaxed agent-scope 64-bit atomics: never torn; a stale "unknown" only costs a redundant scan).
+// The memo lives for one vdet_track_volume call (cleared at its start).
+// ------------------------------------------------------------------------------------------------
+constexpr unsigned long long kMemoValid = 1ull << 63;
+
+__device__ __forceinline__ unsigned long long memo_load(const unsigned long long *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// WARM = true: the chain starts at warm[blockIdx.x] (a flat detection index, < 0: nothing to do) and only
+// fills the memo (no track rows): see track_warm_anchors_kernel.
+//
+// Structure: KNOWN steps are walked by wave 0 alone, one 8-byte load per step and no barrier (the row of the
+// previous step is written while the next memo word is in flight); an UNKNOWN step is scanned by the whole
+// block like track_link_kernel and its result published.
+template <int LT, bool WARM>
+__global__ __launch_bounds__(LT) void track_link_memo_kernel(const float4 *__restrict__ boxes, int F, int B, int max_tracks,
+                                                             float link_t32, int reach, const TrackState *__restrict__ st,
+                                                             float *__restrict__ tracks,
+                                                             const uint32_t *__restrict__ group_flags,
+                                                             const FrameIndex ix, double link_thres,
+                                                             unsigned long long *memo, unsigned int *__restrict__ stats,
+                                                             const int32_t *__restrict__ warm)
+{
+    __shared__ float sv[2][LT / 64];
+    __shared__ int si[2][LT / 64];
+    __shared__ float4 sb[2][LT / 64];
+    __shared__ uint32_t scum[2][260];          // bucket table + (xmin, scale, wmax) of frame f in slot f & 1
+    __shared__ int sstate[4];                  // node, fprev, step, done -- where wave 0's run of known steps ended
+    static_assert(LT % 64 == 0 && LT >= 64 && LT <= 1024, "whole waves");
+    constexpr int NPF = (260 + LT - 1) / LT;
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int dir = blockIdx.y == 0 ? 1 : -1;
+    int anchor_frame, anchor_box;
+    float *trk = nullptr;
+    if (WARM) {
+        const int flat = warm[blockIdx.x];
+        if (flat < 0) return;
+        anchor_frame = flat / B;
+        anchor_box = flat - anchor_frame * B;
+    } else {
+        const int c = blockIdx.x;
+        const TrackState s = st[c];
+        if (!s.active) return;
+        anchor_frame = s.anchor_frame;
+        anchor_box = s.anchor_box;
+        trk = tracks + ((int64_t)c * max_tracks + s.ntracks) * F * 5;
+        const float qnan = __uint_as_float(0x7FC00000u);
+        if (dir > 0) { for (int i = anchor_frame * 5 + tid; i < F * 5; i += LT) trk[i] = qnan; }
+        else { for (int i = tid; i < anchor_frame * 5; i += LT) trk[i] = qnan; }
+        __syncthreads();
+        if (dir > 0 && tid == 0) {
+            const float4 anchor = trunc4(boxes[(int64_t)anchor_frame * B + anchor_box]);
+            float *r = trk + (int64_t)anchor_frame * 5;
+            r[0] = anchor.x; r[1] = anchor.y; r[2] = anchor.z; r[3] = anchor.w; r[4] = 1.0f;
+        }
+    }
+    unsigned long long *mm = memo + (int64_t)(dir > 0 ? 0 : 1) * F * B;
+    const bool use_ix = ix.xbox != nullptr;
+    const float omt = (float)(1.0 - link_thres) * 1.002f + 1.0e-6f;
+    const float inv_t = (float)(1.002 / fmax(link_thres, 1.0e-6));
+    const float t32e = link_t32 * 4.76837158203125e-7f;
+    int node = anchor_box, fprev = anchor_frame, step = 1;
+    int tbl[2] = {-1, -1};           // which frame's table sits in scum[0] / scum[1]
+    unsigned int nhit = 0, nmiss = 0;
+    for (;;) {
+        // ---- wave 0: the run of known steps from (fprev, node)
+        if (w == 0) {
+            int done = 0;
+            int pend_f = -1;                     // row not yet written: frame, IoU bits, box (load in flight)
+            uint32_t pend_s = 0u;
+            float4 pend_b = make_float4(0.f, 0.f, 0.f, 0.f);
+            unsigned long long m = 0ull;
+            bool have = false;
+            for (;;) {
+                const int f = anchor_frame + dir * step;
+                if (step > reach || f < 0 || f >= F) { done = 1; break; }
+                if (!have) m = memo_load(&mm[(int64_t)fprev * B + node]);
+                m = __builtin_amdgcn_readfirstlane((uint32_t)m) | ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(m >> 32)) << 32);
+                have = false;
+                if (!(m & kMemoValid)) break;                              // unknown: the block scans this step
+                const int bidx = (int)((m >> 32) & 0x7FFFFFFFull) - 1;
+                if (bidx < 0) { done = 1; break; }                         // known: the chain ends here
+                float4 nb = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (!WARM) nb = boxes[(int64_t)f * B + bidx];              // (issued before the next memo word ...
+                const uint32_t sbits = (uint32_t)m;
+                node = bidx; fprev = f; ++step; ++nhit;
+                const int f2 = anchor_frame + dir * step;
+                if (step <= reach && f2 >= 0 && f2 < F) { m = memo_load(&mm[(int64_t)fprev * B + node]); have = true; }
+                if (!WARM) {                                               //  ... and written one step later)
+                    if (pend_f >= 0 && lane == 0) {
+                        const float4 t = trunc4(pend_b);
+                        float *r = trk + (int64_t)pend_f * 5;
+                        r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w; r[4] = __uint_as_float(pend_s);
+                    }
+                    pend_f = f; pend_s = sbits; pend_b = nb;
+                }
+            }
+            if (!WARM && pend_f >= 0 && lane == 0) {
+                const float4 t = trunc4(pend_b);
+                float *r = trk + (int64_t)pend_f * 5;
+                r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w; r[4] = __uint_as_float(pend_s);
+            }
+            if (lane == 0) { sstate[0] = node; sstate[1] = fprev; sstate[2] = step; sstate[3] = done; }
+        }
+        __syncthreads();
+        node = sstate[0]; fprev = sstate[1]; step = sstate[2];
+        if (sstate[3]) break;
+        // ---- unknown step: scan frame f with the whole block (as track_link_kernel)
+        ++nmiss;
+        const int f = anchor_frame + dir * step;
+        const int par = step & 1;
+        float4 cur = trunc4(boxes[(int64_t)fprev * B + node]);
+        const float carea = box_area(cur);
+        const float4 *fb = boxes + (int64_t)f * B;
+        float bv = -1.0f;
+        int bi = -1;
+        float4 bb = cur;
+        const bool fast = group_flags && (group_flags[f] & kFlagRegular) && link_t32 > 1e-30f &&
+                          carea > 0.0f && carea < __uint_as_float(0x7F800000u);
+        if (fast && use_ix) {
+            const int slot = f & 1;
+            const int f2 = min(max(f + dir, 0), F - 1);
+            if (tbl[slot] != f) {    // (after a run of known steps) this frame's table was not prefetched
+                for (int i = tid; i < 260; i += LT)
+                    scum[slot][i] = i < 257 ? ix.cum[(int64_t)f * 257 + i] : __float_as_uint(ix.info[f * 4 + (i - 257)]);
+                __syncthreads();
+                tbl[slot] = f;
+            }
+            uint32_t pf[NPF];        // the next frame's table: loads issued here, stored to the other slot after the scan
+#pragma unroll
+            for (int j = 0; j < NPF; ++j) {
+                const int i = tid + j * LT;
+                pf[j] = i < 257 ? ix.cum[(int64_t)f2 * 257 + min(i, 256)] : __float_as_uint(ix.info[f2 * 4 + min(i - 257, 2)]);
+            }
+            int r0, r1;
+            {
+                const float xmin = __uint_as_float(scum[slot][257]), scale = __uint_as_float(scum[slot][258]);
+                const float wmax = __uint_as_float(scum[slot][259]);
+                const float wc = (cur.z - cur.x) + 1.0f;
+                const float lo = cur.x - omt * fminf(wmax, wc * inv_t) - 2.0f;
+                const float hi = cur.x + omt * wc + 2.0f;
+                r0 = (int)scum[slot][xbucket(fmaxf(lo, -3.0e38f), xmin, scale)];
+                r1 = (int)scum[slot][xbucket(fminf(hi, 3.0e38f), xmin, scale) + 1];
+            }
+            const float4 *xb = ix.xbox + (int64_t)f * B;
+            const uint16_t *xo = ix.xord + (int64_t)f * B;
+            int rb0 = r0;
+            while (r1 - rb0 > 16 * LT) { LSCAN(16) rb0 += 16 * LT; }
+            const int nb = (r1 - rb0 + LT - 1) / LT;
+            if (nb > 12) { LSCAN(16) } else if (nb > 8) { LSCAN(12) } else if (nb > 4) { LSCAN(8) } else if (nb > 0) { LSCAN(4) }
+            if (f2 != f) {
+#pragma unroll
+                for (int j = 0; j < NPF; ++j)
+                    if (tid + j * LT < 260) scum[slot ^ 1][tid + j * LT] = pf[j];
+                tbl[slot ^ 1] = f2;
+            }
+        } else {
+            // irregular frame / no index / degenerate current box: the plain arg-max (NaN never wins, lowest index on ties)
+            for (int b = tid; b < B; b += LT) {
+                const float4 x = fb[b];
+                const float v = link_iou(cur, carea, x);
+                if (v > bv) { bv = v; bi = b; bb = x; }
+            }
+        }
+        const int my_bi = bi;
+        LINK_DPP_STEP(0x111, 0xf) LINK_DPP_STEP(0x112, 0xf) LINK_DPP_STEP(0x114, 0xf) LINK_DPP_STEP(0x118, 0xf)
+        LINK_DPP_STEP(0x142, 0xa) LINK_DPP_STEP(0x143, 0xc)
+        bv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bv), 63));
+        bi = __builtin_amdgcn_readlane(bi, 63);
+        if (lane == 0) { sv[par][w] = bv; si[par][w] = bi; }
+        if (bi >= 0 && my_bi == bi) sb[par][w] = bb;
+        __syncthreads();
+        float best = sv[par][0];
+        int bidx = si[par][0];
+        int bw = 0;
+#pragma unroll
+        for (int k = 1; k < LT / 64; ++k) {
+            const float v2 = sv[par][k];
+            const int i2 = si[par][k];
+            if (i2 >= 0 && (bidx < 0 || v2 > best || (v2 == best && i2 < bidx))) { best = v2; bidx = i2; bw = k; }
+        }
+        const bool linked = bidx >= 0 && best >= link_t32;
+        if (tid == 0)
+            __hip_atomic_store(&mm[(int64_t)fprev * B + node],
+                               kMemoValid | ((unsigned long long)(linked ? bidx + 1 : 0) << 32) | (linked ? __float_as_uint(best) : 0u),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!linked) break;
+        if (!WARM && tid == 0) {
+            const float4 t = trunc4(sb[par][bw]);
+            float *r = trk + (int64_t)f * 5;
+            r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w; r[4] = best;
+        }
+        node = bidx; fprev = f; ++step;
+    }
+    if (stats && tid == 0) { atomicAdd(&stats[WARM ? 2 : 0], nhit); atomicAdd(&stats[WARM ? 3 : 1], nmiss); }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Likely anchors of a class, for warming the link memo: the best `m` detections of the class in the
+// global order of vdet/track.py:200 (score descending, flat index ascending) that score >= thres --
+// taken from the first two entries of every (frame, class) sorted list.  The tracking loop's real
+// anchors are (almost always) among them: a detection only stops being an anchor candidate when an earlier
+// track or a better detection of its own frame overlaps it.  Whatever is predicted wrongly costs time,
+// never correctness: the memo only ever holds next(f, j, dir), which no prediction can change.
+// One block per class; warm[c * m + k] = flat index or -1.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void track_warm_anchors_kernel(const uint32_t *__restrict__ keys, const uint16_t *__restrict__ lists,
+                                                                 const int32_t *__restrict__ cnt, int F, int B, int C,
+                                                                 const float *__restrict__ scores, double thres, int m,
+                                                                 int32_t *__restrict__ warm)
+{
+    __shared__ uint32_t sk[256];
+    __shared__ int sf[256];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    uint32_t lk = 0xFFFFFFFFu;       // cursor: the last candidate taken (key, flat); everything at or before it is out
+    int lf = -1;
+    for (int k = 0; k < m; ++k) {
+        uint32_t bk = 0;
+        int bflat = -1;
+        for (int f = tid; f < F; f += 256) {
+            const int p = f * C + c;
+            const int n = min(cnt[p], 2);
+            for (int q = 0; q < n; ++q) {
+                const int e = lists[(int64_t)p * B + q];
+                const uint32_t kk = keys[(int64_t)p * B + e];
+                const int flat = f * B + e;
+                if (lf >= 0 && (kk > lk || (kk == lk && flat <= lf))) continue;       // already taken
+                if (bflat < 0 || kk > bk || (kk == bk && flat < bflat)) { bk = kk; bflat = flat; }
+            }
+        }
+        sk[tid] = bk; sf[tid] = bflat;
+        __syncthreads();
+        for (int d = 128; d > 0; d >>= 1) {
+            if (tid < d) {
+                const uint32_t k2 = sk[tid + d];
+                const int f2 = sf[tid + d];
+                if (f2 >= 0 && (sf[tid] < 0 || k2 > sk[tid] || (k2 == sk[tid] && f2 < sf[tid]))) { sk[tid] = k2; sf[tid] = f2; }
+            }
+            __syncthreads();
+        }
+        lk = sk[0]; lf = sf[0];
+        __syncthreads();
+        if (lf < 0) {                 // nothing left
+            if (tid == 0) for (int r = k; r < m; ++r) warm[c * m + r] = -1;
+            return;
+        }
+        const int f = lf / B, b = lf - f * B;
+        const bool below = (double)scores[((int64_t)f * B + b) * C + c] < thres;      // the loop stops at the first such anchor
+        if (tid == 0) warm[c * m + k] = below ? -1 : lf;
+        if (below) {
+            if (tid == 0) for (int r = k + 1; r < m; ++r) warm[c * m + r] = -1;
+            return;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // track_det_nms of the new track against every frame it crosses: one wave per (frame, class).
 // ------------------------------------------------------------------------------------------------
 struct SuppressParams {

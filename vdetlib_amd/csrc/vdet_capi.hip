@@ -129,6 +129,9 @@ struct vdet_ctx {
     bool force_general = false;   // VDET_FORCE_GENERAL=1: disable the symmetric fast kernel (tests)
     bool topk_attr_set = false;
     int link_threads = 256;       // VDET_LINK_THREADS=64|128|256: threads per link chain (A-B knob)
+    bool link_memo = true;        // VDET_LINK_MEMO=0: every link step scans (A-B knob / tests)
+    int link_warm = -1;           // VDET_LINK_WARM=m: chains warmed per class (-1: max_tracks + 2; 0: none)
+    DevBuf linkmemo, linkstats, linkwarm;
     size_t dyn_lds_max = 0;
 };
 
@@ -726,6 +729,8 @@ int vdet_create(vdet_ctx **out, int device)
     if (const char *e = getenv("VDET_NO_TRANSPOSE")) c->no_transpose = atoi(e) != 0;
     if (const char *e = getenv("VDET_NO_INDEX")) c->no_index = atoi(e) != 0;
     if (const char *e = getenv("VDET_NO_LAZY")) c->no_lazy = atoi(e) != 0;
+    if (const char *e = getenv("VDET_LINK_MEMO")) c->link_memo = atoi(e) != 0;
+    if (const char *e = getenv("VDET_LINK_WARM")) c->link_warm = atoi(e);
     if (const char *e = getenv("VDET_LINK_THREADS")) { const int v = atoi(e); if (v == 64 || v == 128 || v == 256) c->link_threads = v; }
     if (const char *e = getenv("VDET_DEBUG_SYNC")) c->debug_sync = atoi(e) != 0;
     {   // probe: do returning LDS atomics resolve same-address lanes in ascending lane order?
@@ -797,7 +802,7 @@ int vdet_destroy(vdet_ctx *c)
     DevBuf *bufs[] = {&c->boxes, &c->scores, &c->keys, &c->excl, &c->frames, &c->groups, &c->tiles, &c->bits,
                       &c->rowz, &c->rowmeta, &c->groupz, &c->adj, &c->comp, &c->origidx, &c->out64,
                       &c->trk_frames, &c->trk_boxes, &c->b1, &c->b2, &c->iou_out, &c->order, &c->ncand, &c->keepidx,
-                      &c->keepcnt, &c->gflags, &c->pairs, &c->tkeys, &c->tstate, &c->visited, &c->heads, &c->xkeys, &c->xord, &c->xncand,
+                      &c->keepcnt, &c->gflags, &c->pairs, &c->tkeys, &c->tstate, &c->visited, &c->heads, &c->xkeys, &c->xord, &c->xncand, &c->linkmemo, &c->linkstats, &c->linkwarm,
                       &c->xbox, &c->xcum, &c->xinfo};
     for (DevBuf *b : bufs) b->release();
     for (DevBuf &b : c->tmp) b.release();
@@ -846,6 +851,13 @@ int vdet_query(vdet_ctx *c, int what)
     if (what == 1) return c->n_cu;
     if (what == 2) return c->all_regular ? 1 : 0;
     if (what == 3) return c->wave_transpose ? 1 : 0;
+    if (what >= 4 && what <= 7) {     // link steps of the last tracking call served by the memo (4) / scanned (5); 6 / 7: the warm-up's
+        unsigned int h[4] = {0, 0, 0, 0};
+        if (!c->linkstats.p) return 0;
+        if (hipMemcpyAsync(h, c->linkstats.p, 16, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            hipStreamSynchronize(c->stream) != hipSuccess) return VDET_EHIP;
+        return (int)std::min<unsigned int>(h[what - 4], 0x7FFFFFFFu);
+    }
     return VDET_EINVAL;
 }
 
@@ -1224,6 +1236,26 @@ int vdet_nms_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scor
     const bool need_suppress = !sp.lazy || !sp.group_flags || !c->all_regular;
     sp.n_irregular = &c->d_cnt->irregular;
     const float link_t32 = thresh_to_f32(link_thres);
+    if (c->link_memo) {      // one memo per call: a link step depends on the video's boxes and link_thres only
+        HIPCHK(c, c->linkmemo.reserve((size_t)2 * F * B * 8));
+        HIPCHK(c, c->linkstats.reserve(16));
+        HIPCHK(c, hipMemsetAsync(c->linkmemo.p, 0, (size_t)2 * F * B * 8, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->linkstats.p, 0, 16, c->stream));
+        // warm the memo: the chains of every class's likely anchors, all at once (the chip is full instead of running
+        // 2 C latency-bound blocks per track); the tracking loop below then mostly walks known steps
+        const int wm = c->link_warm < 0 ? std::min(max_tracks + 2, 16) : std::min(c->link_warm, 64);
+        if (wm > 0 && max_tracks > 0) {
+            HIPCHK(c, c->linkwarm.reserve((size_t)C * wm * 4));
+            StageTimer tm(c, ST_TLINK);
+            hipLaunchKernelGGL(track_warm_anchors_kernel, dim3((unsigned)C), dim3(256), 0, c->stream, c->tkeys.as<uint32_t>(),
+                               c->order.as<uint16_t>(), c->ncand.as<int32_t>(), (int)F, (int)B, (int)C, d_scores, thres, wm,
+                               c->linkwarm.as<int32_t>());
+            hipLaunchKernelGGL((track_link_memo_kernel<256, true>), dim3((unsigned)(C * wm), 2), dim3(256), 0, c->stream,
+                               reinterpret_cast<const float4 *>(d_boxes), (int)F, (int)B, max_tracks, link_t32, reach,
+                               (const TrackState *)nullptr, (float *)nullptr, sp.group_flags, sp.ix, link_thres,
+                               c->linkmemo.as<unsigned long long>(), c->linkstats.as<unsigned int>(), c->linkwarm.as<int32_t>());
+        }
+    }
     for (int t = 0; t < max_tracks; ++t) {
         {
             StageTimer tm(c, ST_TPICK);
@@ -1237,8 +1269,17 @@ int vdet_nms_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scor
 #define VDET_LINK(LTV) hipLaunchKernelGGL(track_link_kernel<LTV>, dim3((unsigned)C, 2), dim3(LTV), 0, c->stream, \
                                reinterpret_cast<const float4 *>(d_boxes), (int)F, (int)B, max_tracks, link_t32, reach, st, \
                                d_tracks, sp.group_flags, sp.ix, link_thres)
-            if (c->link_threads == 64) VDET_LINK(64); else if (c->link_threads == 128) VDET_LINK(128); else VDET_LINK(256);
+#define VDET_LINKM(LTV) hipLaunchKernelGGL((track_link_memo_kernel<LTV, false>), dim3((unsigned)C, 2), dim3(LTV), 0, c->stream, \
+                               reinterpret_cast<const float4 *>(d_boxes), (int)F, (int)B, max_tracks, link_t32, reach, st, \
+                               d_tracks, sp.group_flags, sp.ix, link_thres, c->linkmemo.as<unsigned long long>(), c->linkstats.as<unsigned int>(), \
+                               (const int32_t *)nullptr)
+            if (c->link_memo) {
+                if (c->link_threads == 64) VDET_LINKM(64); else if (c->link_threads == 128) VDET_LINKM(128); else VDET_LINKM(256);
+            } else {
+                if (c->link_threads == 64) VDET_LINK(64); else if (c->link_threads == 128) VDET_LINK(128); else VDET_LINK(256);
+            }
 #undef VDET_LINK
+#undef VDET_LINKM
         }
         if (c->debug_sync) { fprintf(stderr, "[vdet] iter %d link...\n", t); HIPCHK(c, hipStreamSynchronize(c->stream)); fprintf(stderr, "[vdet] iter %d link ok\n", t); }
         if (need_suppress) {
@@ -1628,17 +1669,23 @@ int vdet_volume_pass(vdet_ctx *c, const float *d_scores, int64_t F, int64_t B, i
         return fail(c, VDET_EINVAL, "bad volume_pass arguments");
     if (B > 32767 || F * C > 0x7FFFFFF0ll || F * B > 0x7FFFFFF0ll) return fail(c, VDET_EINVAL, "volume too large");
     c->keys_valid = false;
-    // tile: TB boxes (a power of two, >= 16 so that a key row segment is >= 64 B) x C classes in <= 256 * ITEMS float4
+    // tile: TB boxes (a power of two, >= 16 so that a key row segment is >= 64 B) x C classes in <= NT * ITEMS float4;
+    // 4 items per thread (the window of every item lives in registers: more would cost occupancy), 256 or 512 threads
     const int64_t C4 = C / 4;
-    int items = 0, TB = 0;
+    int items = 0, TB = 0, NT = 0;
     if (C % 4 == 0 && (window == 3 || window == 5) && !c->no_transpose &&
         (((uintptr_t)d_scores | (uintptr_t)d_out_max | (uintptr_t)(conv ? d_out_conv : d_out_max)) & 15) == 0) {
-        for (int it : {4, 8}) {
+        for (int nt : {256, 512}) {
             int tb = 64;
-            while (tb >= 16 && (int64_t)tb * C4 > 256 * it) tb >>= 1;
-            if (tb >= 16 && (it == 8 || tb >= 32)) { items = it; TB = tb; break; }
+            while (tb >= 16 && (int64_t)tb * C4 > (int64_t)nt * 4) tb >>= 1;
+            if (tb >= 16 && (nt == 512 || tb >= 32)) { items = 4; TB = tb; NT = nt; break; }
         }
-        if (items && (size_t)2 * C4 * (TB + 1) * 16 > c->max_lds) items = 0;
+        if (items && (size_t)2 * C4 * TB * 16 > c->max_lds / 2) items = 0;
+        if (const char *e = getenv("VDET_VPASS")) {   // A-B knob: "NT,TB" (e.g. 256,16)
+            int nt = 0, tb = 0;
+            if (sscanf(e, "%d,%d", &nt, &tb) == 2 && (nt == 256 || nt == 512) && (tb == 16 || tb == 32 || tb == 64) &&
+                (int64_t)tb * C4 <= (int64_t)nt * 4 && items) { NT = nt; TB = tb; }
+        }
     }
     if (!items) {
         // shapes the fused kernel does not cover: the temporal pass(es) now, the key transpose with the sort
@@ -1655,16 +1702,16 @@ int vdet_volume_pass(vdet_ctx *c, const float *d_scores, int64_t F, int64_t B, i
     chunks = std::max<int64_t>(1, std::min<int64_t>(chunks, 65535));
     const int fchunk = (int)((F + chunks - 1) / chunks);
     const dim3 grid((unsigned)ntiles, (unsigned)((F + fchunk - 1) / fchunk));
-    const size_t lds = (size_t)2 * C4 * (TB + 1) * 16;
+    const size_t lds = (size_t)2 * C4 * TB * 16;
     int tb_shift = 0;
     while ((1 << tb_shift) < TB) ++tb_shift;
     const void *fn = nullptr;
-#define VDET_VP(WW, IT, CV) reinterpret_cast<const void *>(volume_pass_kernel<WW, IT, CV>)
-    if (window == 3) fn = items == 4 ? (conv ? VDET_VP(3, 4, true) : VDET_VP(3, 4, false)) : (conv ? VDET_VP(3, 8, true) : VDET_VP(3, 8, false));
-    else fn = items == 4 ? (conv ? VDET_VP(5, 4, true) : VDET_VP(5, 4, false)) : (conv ? VDET_VP(5, 8, true) : VDET_VP(5, 8, false));
+#define VDET_VP(WW, CV, NTV) reinterpret_cast<const void *>(volume_pass_kernel<WW, 4, CV, NTV>)
+    if (window == 3) fn = NT == 256 ? (conv ? VDET_VP(3, true, 256) : VDET_VP(3, false, 256)) : (conv ? VDET_VP(3, true, 512) : VDET_VP(3, false, 512));
+    else fn = NT == 256 ? (conv ? VDET_VP(5, true, 256) : VDET_VP(5, false, 256)) : (conv ? VDET_VP(5, true, 512) : VDET_VP(5, false, 512));
     if (!c->vpass_attr_set) {
-        for (const void *f : {VDET_VP(3, 4, true), VDET_VP(3, 4, false), VDET_VP(3, 8, true), VDET_VP(3, 8, false),
-                              VDET_VP(5, 4, true), VDET_VP(5, 4, false), VDET_VP(5, 8, true), VDET_VP(5, 8, false)})
+        for (const void *f : {VDET_VP(3, true, 256), VDET_VP(3, false, 256), VDET_VP(3, true, 512), VDET_VP(3, false, 512),
+                              VDET_VP(5, true, 256), VDET_VP(5, false, 256), VDET_VP(5, true, 512), VDET_VP(5, false, 512)})
             HIPCHK(c, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->max_lds));
         c->vpass_attr_set = true;
     }
@@ -1672,17 +1719,19 @@ int vdet_volume_pass(vdet_ctx *c, const float *d_scores, int64_t F, int64_t B, i
     const float4 *in4 = reinterpret_cast<const float4 *>(d_scores);
     float4 *om = reinterpret_cast<float4 *>(d_out_max), *oc = reinterpret_cast<float4 *>(d_out_conv);
     uint32_t *keys = c->tkeys.as<uint32_t>();
+    const bool nokeys = getenv("VDET_VPASS_NOKEYS") != nullptr;      // timing experiments only: results are NOT valid
+    if (nokeys) keys = nullptr;
     int Fi = (int)F, Bi = (int)B, C4i = (int)C4;
     void *args[] = {&in4, &om, &oc, &keys, &Fi, &Bi, &C4i, &TB, &tb_shift, (void *)&fchunk, &pad_max, &pad_conv, &bias, &taps,
                     &use_score_thresh, &score_thresh};
     {
         StageTimer tm(c, ST_TEMPORAL);
-        HIPCHK(c, hipLaunchKernel(fn, grid, dim3(256), args, lds, c->stream));
+        HIPCHK(c, hipLaunchKernel(fn, grid, dim3((unsigned)NT), args, lds, c->stream));
     }
     HIPCHK(c, hipGetLastError());
     c->keysrc.scores = d_scores; c->keysrc.F = F; c->keysrc.B = B; c->keysrc.C = C;
     c->keysrc.use_thr = use_score_thresh ? 1 : 0; c->keysrc.thr = score_thresh;
-    c->keys_valid = true;
+    c->keys_valid = !nokeys;
     return VDET_OK;
 }
 
