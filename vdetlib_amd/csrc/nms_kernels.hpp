@@ -560,13 +560,17 @@ __global__ __launch_bounds__(256) void iou_bits_sym_kernel(const float4 *__restr
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2: bit rows -> adjacency lists.  grid = n_tiles; block = 256 (one lane per row).
-// Each tile reserves one contiguous slab of the u16 pool with a single atomicAdd; the slab layout
+// K2: bit rows -> adjacency lists.  grid = 2 * n_tiles; block = 128 (one lane per row).
+// Each block reserves one contiguous slab of the u16 pool with a single atomicAdd; the slab layout
 // is irrelevant to the result (lists are sets).  Zero-union partners are appended with kZTag.
 // ------------------------------------------------------------------------------------------------
-constexpr int kAdjStage = 24576;     // u16 entries staged in LDS per 256-row tile (48 KB)
+// One block = kAdjRows rows = HALF a 256-row tile (grid = 2 * n_tiles): the rows' lists are staged in LDS and leave in
+// one coalesced copy; a slab that does not fit takes the slow direct path (a dependent index load per edge), so the
+// stage is sized for ~2x the graph degree of 10 000 random boxes (92) while leaving room for 4 blocks per CU.
+constexpr int kAdjRows = 128;
+constexpr int kAdjStage = 16384;     // u16 entries staged in LDS per block (32 KB)
 
-__global__ __launch_bounds__(256) void adj_build_kernel(const float4 *__restrict__ boxes,
+__global__ __launch_bounds__(kAdjRows) void adj_build_kernel(const float4 *__restrict__ boxes,
                                                         const GroupDesc *__restrict__ groups,
                                                         const TileDesc *__restrict__ tiles,
                                                         const uint64_t *__restrict__ bits,
@@ -578,14 +582,14 @@ __global__ __launch_bounds__(256) void adj_build_kernel(const float4 *__restrict
                                                         const uint32_t *__restrict__ group_flags,
                                                         const FrameIndex ix, float one_minus_t, int pool_bits)
 {
-    __shared__ uint32_t sscan[256];
+    __shared__ uint32_t sscan[8];
     __shared__ unsigned long long sbase;
     __shared__ uint16_t sstage[kAdjStage];
-    const TileDesc td = tiles[blockIdx.x];
+    const TileDesc td = tiles[blockIdx.x >> 1];
     const GroupDesc gd = groups[td.group];
     const int B = gd.nbox;
     const int tid = threadIdx.x;
-    const int v = td.row_tile * kRowsPerTile + tid;
+    const int v = td.row_tile * kRowsPerTile + (blockIdx.x & 1) * kAdjRows + tid;
     const int W = (B + 63) >> 6;
     const uint64_t *col = bits + gd.bits_off + v;
     // regular groups were evaluated in x1-rank space (iou_bits_sym_kernel): translate back
@@ -641,7 +645,7 @@ __global__ __launch_bounds__(256) void adj_build_kernel(const float4 *__restrict
         for (int k = 0; k < wv; ++k) carry += sscan[k];
         incl += carry;
     }
-    if (tid == 255) { sscan[4] = incl; sbase = atomicAdd(pool_used, (unsigned long long)incl); }
+    if (tid == kAdjRows - 1) { sscan[4] = incl; sbase = atomicAdd(pool_used, (unsigned long long)incl); }
     __syncthreads();
     const unsigned long long base = sbase;
     const uint32_t tile_total = sscan[4];
@@ -696,9 +700,9 @@ __global__ __launch_bounds__(256) void adj_build_kernel(const float4 *__restrict
     if (staged) {   // one coalesced copy of the tile's slab instead of 256 interleaved 2-byte streams
         __syncthreads();
         if (tr) {   // (zero-union entries only exist on irregular frames, which have no x-index: tr == null)
-            for (uint32_t i = tid; i < tile_total; i += 256) adj[base + i] = tr[sstage[i]];
+            for (uint32_t i = tid; i < tile_total; i += kAdjRows) adj[base + i] = tr[sstage[i]];
         } else {
-            for (uint32_t i = tid; i < tile_total; i += 256) adj[base + i] = sstage[i];
+            for (uint32_t i = tid; i < tile_total; i += kAdjRows) adj[base + i] = sstage[i];
         }
     }
 }

@@ -468,7 +468,7 @@ __device__ __forceinline__ unsigned long long memo_load(const unsigned long long
 // Structure: KNOWN steps are walked by wave 0 alone, one 8-byte load per step and no barrier (the row of the
 // previous step is written while the next memo word is in flight); an UNKNOWN step is scanned by the whole
 // block like track_link_kernel and its result published.
-template <int LT, bool WARM>
+template <int LT, bool WARM, int MAXB>
 __global__ __launch_bounds__(LT) void track_link_memo_kernel(const float4 *__restrict__ boxes, int F, int B, int max_tracks,
                                                              float link_t32, int reach, const TrackState *__restrict__ st,
                                                              float *__restrict__ tracks,
@@ -601,10 +601,12 @@ __global__ __launch_bounds__(LT) void track_link_memo_kernel(const float4 *__res
             }
             const float4 *xb = ix.xbox + (int64_t)f * B;
             const uint16_t *xo = ix.xord + (int64_t)f * B;
+            // batches of at most MAXB boxes per thread: 16 = one memory round trip for a typical window at the price of
+            // ~180 registers (2 waves / SIMD); 8 = two round trips at twice the occupancy -- what the chip-filling warm-up wants
             int rb0 = r0;
-            while (r1 - rb0 > 16 * LT) { LSCAN(16) rb0 += 16 * LT; }
+            while (r1 - rb0 > MAXB * LT) { LSCAN(MAXB) rb0 += MAXB * LT; }
             const int nb = (r1 - rb0 + LT - 1) / LT;
-            if (nb > 12) { LSCAN(16) } else if (nb > 8) { LSCAN(12) } else if (nb > 4) { LSCAN(8) } else if (nb > 0) { LSCAN(4) }
+            if (MAXB >= 16 && nb > 12) { LSCAN(16) } else if (MAXB >= 16 && nb > 8) { LSCAN(12) } else if (nb > 4) { LSCAN(8) } else if (nb > 0) { LSCAN(4) }
             if (f2 != f) {
 #pragma unroll
                 for (int j = 0; j < NPF; ++j)

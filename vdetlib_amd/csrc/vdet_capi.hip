@@ -130,6 +130,7 @@ struct vdet_ctx {
     bool topk_attr_set = false;
     int link_threads = 256;       // VDET_LINK_THREADS=64|128|256: threads per link chain (A-B knob)
     bool link_memo = true;        // VDET_LINK_MEMO=0: every link step scans (A-B knob / tests)
+    int link_maxb = 8;            // VDET_LINK_MAXB=8|16: boxes per thread and batch in the warm-up's window scans (A-B knob)
     int link_warm = -1;           // VDET_LINK_WARM=m: chains warmed per class (-1: max_tracks + 2; 0: none)
     DevBuf linkmemo, linkstats, linkwarm;
     size_t dyn_lds_max = 0;
@@ -404,7 +405,7 @@ int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32, doub
             }
             {
                 StageTimer tm(c, ST_ADJ);
-                hipLaunchKernelGGL(adj_build_kernel, dim3(nt), dim3(256), 0, c->stream, d_boxes,
+                hipLaunchKernelGGL(adj_build_kernel, dim3(2 * nt), dim3(kAdjRows), 0, c->stream, d_boxes,
                                    c->groups.as<GroupDesc>(), c->tiles.as<TileDesc>() + bt.first,
                                    c->bits.as<uint64_t>(), c->rowz.as<uint32_t>(), c->rowmeta.as<uint2>(),
                                    c->adj.as<uint16_t>(), &c->d_cnt->pool_used, pool_cap,
@@ -731,6 +732,7 @@ int vdet_create(vdet_ctx **out, int device)
     if (const char *e = getenv("VDET_NO_LAZY")) c->no_lazy = atoi(e) != 0;
     if (const char *e = getenv("VDET_LINK_MEMO")) c->link_memo = atoi(e) != 0;
     if (const char *e = getenv("VDET_LINK_WARM")) c->link_warm = atoi(e);
+    if (const char *e = getenv("VDET_LINK_MAXB")) c->link_maxb = atoi(e) == 16 ? 16 : 8;
     if (const char *e = getenv("VDET_LINK_THREADS")) { const int v = atoi(e); if (v == 64 || v == 128 || v == 256) c->link_threads = v; }
     if (const char *e = getenv("VDET_DEBUG_SYNC")) c->debug_sync = atoi(e) != 0;
     {   // probe: do returning LDS atomics resolve same-address lanes in ascending lane order?
@@ -1250,10 +1252,12 @@ int vdet_nms_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scor
             hipLaunchKernelGGL(track_warm_anchors_kernel, dim3((unsigned)C), dim3(256), 0, c->stream, c->tkeys.as<uint32_t>(),
                                c->order.as<uint16_t>(), c->ncand.as<int32_t>(), (int)F, (int)B, (int)C, d_scores, thres, wm,
                                c->linkwarm.as<int32_t>());
-            hipLaunchKernelGGL((track_link_memo_kernel<256, true>), dim3((unsigned)(C * wm), 2), dim3(256), 0, c->stream,
-                               reinterpret_cast<const float4 *>(d_boxes), (int)F, (int)B, max_tracks, link_t32, reach,
-                               (const TrackState *)nullptr, (float *)nullptr, sp.group_flags, sp.ix, link_thres,
-                               c->linkmemo.as<unsigned long long>(), c->linkstats.as<unsigned int>(), c->linkwarm.as<int32_t>());
+#define VDET_WARM(MB) hipLaunchKernelGGL((track_link_memo_kernel<256, true, MB>), dim3((unsigned)(C * wm), 2), dim3(256), 0, c->stream, \
+                               reinterpret_cast<const float4 *>(d_boxes), (int)F, (int)B, max_tracks, link_t32, reach, \
+                               (const TrackState *)nullptr, (float *)nullptr, sp.group_flags, sp.ix, link_thres, \
+                               c->linkmemo.as<unsigned long long>(), c->linkstats.as<unsigned int>(), c->linkwarm.as<int32_t>())
+            if (c->link_maxb == 16) VDET_WARM(16); else VDET_WARM(8);
+#undef VDET_WARM
         }
     }
     for (int t = 0; t < max_tracks; ++t) {
@@ -1269,7 +1273,7 @@ int vdet_nms_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scor
 #define VDET_LINK(LTV) hipLaunchKernelGGL(track_link_kernel<LTV>, dim3((unsigned)C, 2), dim3(LTV), 0, c->stream, \
                                reinterpret_cast<const float4 *>(d_boxes), (int)F, (int)B, max_tracks, link_t32, reach, st, \
                                d_tracks, sp.group_flags, sp.ix, link_thres)
-#define VDET_LINKM(LTV) hipLaunchKernelGGL((track_link_memo_kernel<LTV, false>), dim3((unsigned)C, 2), dim3(LTV), 0, c->stream, \
+#define VDET_LINKM(LTV) hipLaunchKernelGGL((track_link_memo_kernel<LTV, false, 8>), dim3((unsigned)C, 2), dim3(LTV), 0, c->stream, \
                                reinterpret_cast<const float4 *>(d_boxes), (int)F, (int)B, max_tracks, link_t32, reach, st, \
                                d_tracks, sp.group_flags, sp.ix, link_thres, c->linkmemo.as<unsigned long long>(), c->linkstats.as<unsigned int>(), \
                                (const int32_t *)nullptr)
