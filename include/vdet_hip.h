@@ -96,7 +96,9 @@ int vdet_set_async(vdet_ctx *ctx, int enable);
  * boxes, positive width / height / area); 0 after an asynchronous build (not known on the host);
  * what = 3 -> 1 if the 64x64 in-wave bit transpose passed its self-test at vdet_create;
  * what = 4 / 5 -> link steps of the last tracking call that were served by the link memo / that scanned their
- * frame (synchronises the stream). */
+ * frame (synchronises the stream); 6 / 7 -> the same for the memo warm-up launch;
+ * what = 8 -> number of host waits (hipStreamSynchronize) this context has made so far: the asynchronous video
+ * step (vdet_set_async) adds none between the entry and the return of the volume entry points. */
 int vdet_query(vdet_ctx *ctx, int what);
 /* Per-stage HIP-event timing: 0 off (default), 1 on (events of the most recent call), 2 on and
  * accumulating over calls until vdet_last_timing_ms reads them. */

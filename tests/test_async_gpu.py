@@ -124,3 +124,35 @@ def test_host_entry_points_do_not_poison_the_cache(oracle):
         assert torch.equal(idx, idx2)
     finally:
         cx.set_cache(False)
+
+
+def test_async_step_never_waits_for_the_device():
+    """vdet_query(ctx, 8) counts every hipStreamSynchronize the library issues: once a context has built one graph,
+    an asynchronous step (volume pass + NMS + tubelets + re-scoring of a NEW video) adds none."""
+    import torch
+    from vdetlib_amd import ops
+    cx = _ctx()
+    cx.set_cache(True)
+    cx.set_async(True)
+    vids = [synth.coherent_video(6300 + i, 10, 500, 8) for i in range(4)]
+    dev = [(torch.from_numpy(b).cuda(), torch.from_numpy(s).cuda()) for b, s in vids]
+
+    def step(tb, ts):
+        cx.invalidate()
+        pooled, conv = ops.volume_pass(ts, 3, [0.25, 0.5, 0.25], ctx=cx)
+        r = ops.nms_track_volume(tb, ts, thres=0.3, max_tracks=4, sync=False, ctx=cx, pad=False)
+        rr = ops.rescore_tracks(r[2], r[4], tb, ts, sync=False, ctx=cx)
+        return r + rr + (pooled, conv)
+
+    step(*dev[0])                 # the first graph of a context is built synchronously (learns the scratch size)
+    cx.sync()
+    before = cx.query(8)
+    outs = [step(tb, ts) for tb, ts in dev[1:]]
+    assert cx.query(8) == before, "an asynchronous step waited for the device"
+    cx.sync()
+    assert cx.query(8) == before + 1
+    for (tb, ts), got in zip(dev[1:], outs):      # and the results are the synchronous ones
+        want = ops.nms_track_volume(tb, ts, thres=0.3, max_tracks=4)
+        for a, b in zip(want[1:], got[1:5]):
+            assert torch.equal(a.nan_to_num(-7.0), b.nan_to_num(-7.0))
+    cx.close()

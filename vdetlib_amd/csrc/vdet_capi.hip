@@ -122,6 +122,7 @@ struct vdet_ctx {
     int64_t vplan_F = 0, vplan_B = 0;
     size_t vplan_budget = 0;
     // asynchronous video step (vdet_set_async): no host synchronisation inside the d_* entry points
+    long long n_host_syncs = 0;   // hipStreamSynchronize calls made by this context so far
     bool async_enabled = false;
     unsigned long long pool_hint = 0;   // adjacency entries used by the largest graph built so far
     bool atomic_rank = false;     // LDS returning atomics serve same-address lanes in lane order (probed)
@@ -137,6 +138,14 @@ struct vdet_ctx {
 };
 
 namespace {
+
+// every host wait of the library goes through here (counted: vdet_query(ctx, 8); the asynchronous video step is
+// tested to add none)
+hipError_t host_sync(vdet_ctx *c)
+{
+    ++c->n_host_syncs;
+    return hipStreamSynchronize(c->stream);
+}
 
 int fail(vdet_ctx *c, int code, const char *fmt, ...)
 {
@@ -281,7 +290,7 @@ FrameIndex frame_index_of(vdet_ctx *c)
 NmsPlan &volume_plan(vdet_ctx *c, int64_t F, int64_t B)
 {
     if (c->vplan_F == F && c->vplan_B == B && c->vplan_budget == c->bits_budget && !c->vplan.groups.empty()) return c->vplan;
-    (void)hipStreamSynchronize(c->stream);     // (rare: geometry change) copies from the old tables may be in flight
+    (void)host_sync(c);     // (rare: geometry change) copies from the old tables may be in flight
     c->vplan = NmsPlan();
     c->vplan.groups.resize((size_t)F);
     for (int64_t f = 0; f < F; ++f) c->vplan.groups[(size_t)f] = {(int32_t)(f * B), (int32_t)B, 0};
@@ -340,7 +349,7 @@ int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32, doub
         // earlier asynchronous call before the status word is cleared below
         Counters h0;
         HIPCHK(c, hipMemcpyAsync(&h0, c->d_cnt, sizeof h0, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, host_sync(c));
         if (h0.status && !c->latched) c->latched = translate_status(c, h0.status);
         if (h0.eindex && !c->latched) c->latched = fail(c, VDET_EINDEX, "list index out of range");
         if (c->adj.cap < min_pool * 2) HIPCHK(c, c->adj.reserve((size_t)min_pool * 2 + 4096));
@@ -421,7 +430,7 @@ int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32, doub
         }
         Counters h;
         HIPCHK(c, hipMemcpyAsync(&h, c->d_cnt, sizeof h, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, host_sync(c));
         c->all_regular = use_sym && h.irregular == 0;
         if (!(h.status & kStPool)) {
             c->pool_hint = std::max(c->pool_hint, h.pool_used);
@@ -637,7 +646,7 @@ int nms_grouped_tail(vdet_ctx *c, NmsPlan &pl, const float *d_scores, const uint
     HIPCHK(c, hipGetLastError());
     Counters h;
     HIPCHK(c, hipMemcpyAsync(&h, c->d_cnt, sizeof h, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, host_sync(c));
     rc = translate_status(c, h.status);
     if (rc) return rc;
     const uint32_t nk = h.glob_cnt;
@@ -648,7 +657,7 @@ int nms_grouped_tail(vdet_ctx *c, NmsPlan &pl, const float *d_scores, const uint
         hipLaunchKernelGGL(comp_to_index_kernel, dim3((nk + 255) / 256), dim3(256), 0, c->stream,
                            c->comp.as<unsigned long long>(), nk, c->out64.as<int64_t>());
         HIPCHK(c, hipMemcpyAsync(h_keep, c->out64.p, (size_t)nk * 8, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, host_sync(c));
     }
     *n_keep = nk;
     return VDET_OK;
@@ -758,7 +767,7 @@ int vdet_create(vdet_ctx **out, int device)
                                &c->d_cnt->status);
             Counters h;
             if (hipMemcpyAsync(&h, c->d_cnt, sizeof h, hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
-                hipStreamSynchronize(c->stream) == hipSuccess)
+                host_sync(c) == hipSuccess)
                 ok = (h.status == 0);
         }
         pb.release();
@@ -780,7 +789,7 @@ int vdet_create(vdet_ctx **out, int device)
             hipMemcpyAsync(bi.p, hin.data(), hin.size() * 8, hipMemcpyHostToDevice, c->stream) == hipSuccess) {
             hipLaunchKernelGGL(wave_transpose_probe, dim3(16), dim3(64), 0, c->stream, bi.as<uint64_t>(), bo.as<uint64_t>(), n);
             if (hipMemcpyAsync(hout.data(), bo.p, hout.size() * 8, hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
-                hipStreamSynchronize(c->stream) == hipSuccess) {
+                host_sync(c) == hipSuccess) {
                 ok = true;
                 for (int t = 0; t < n && ok; ++t)
                     for (int r = 0; r < 64 && ok; ++r)
@@ -800,7 +809,7 @@ int vdet_destroy(vdet_ctx *c)
 {
     if (!c) return VDET_OK;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    (void)host_sync(c);
     DevBuf *bufs[] = {&c->boxes, &c->scores, &c->keys, &c->excl, &c->frames, &c->groups, &c->tiles, &c->bits,
                       &c->rowz, &c->rowmeta, &c->groupz, &c->adj, &c->comp, &c->origidx, &c->out64,
                       &c->trk_frames, &c->trk_boxes, &c->b1, &c->b2, &c->iou_out, &c->order, &c->ncand, &c->keepidx,
@@ -853,11 +862,12 @@ int vdet_query(vdet_ctx *c, int what)
     if (what == 1) return c->n_cu;
     if (what == 2) return c->all_regular ? 1 : 0;
     if (what == 3) return c->wave_transpose ? 1 : 0;
+    if (what == 8) return (int)std::min<long long>(c->n_host_syncs, 0x7FFFFFFF);
     if (what >= 4 && what <= 7) {     // link steps of the last tracking call served by the memo (4) / scanned (5); 6 / 7: the warm-up's
         unsigned int h[4] = {0, 0, 0, 0};
         if (!c->linkstats.p) return 0;
         if (hipMemcpyAsync(h, c->linkstats.p, 16, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-            hipStreamSynchronize(c->stream) != hipSuccess) return VDET_EHIP;
+            host_sync(c) != hipSuccess) return VDET_EHIP;
         return (int)std::min<unsigned int>(h[what - 4], 0x7FFFFFFFu);
     }
     return VDET_EINVAL;
@@ -876,7 +886,7 @@ int vdet_last_timing_ms(vdet_ctx *c, float *out16)
 {
     float *out8 = out16;
     if (!c || !out8) return VDET_EINVAL;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, host_sync(c));
     for (int i = 0; i < ST_COUNT; ++i) { c->last_ms[i] = 0; c->last_launches[i] = 0; }
     for (size_t i = 0; i < c->ev_used; ++i) {
         float ms = 0;
@@ -902,7 +912,7 @@ int vdet_sync(vdet_ctx *c)
     if (!c) return VDET_EINVAL;
     Counters h;
     HIPCHK(c, hipMemcpyAsync(&h, c->d_cnt, sizeof h, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, host_sync(c));
     HIPCHK(c, hipMemsetAsync(&c->d_cnt->status, 0, sizeof(int), c->stream));
     HIPCHK(c, hipMemsetAsync(&c->d_cnt->eindex, 0, sizeof(int), c->stream));
     const int l = c->latched;
@@ -987,7 +997,7 @@ int vdet_nms_f32(vdet_ctx *c, const float *h_dets, int64_t n, int64_t ld, int nc
         HIPCHK(c, hipMemcpyAsync(c->keys.p, hkeys.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
         d_keys = c->keys.as<uint32_t>();
     }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, host_sync(c));
     // the graph / lists / index of an earlier d_* call are overwritten below (shared scratch)
     c->graph_valid = c->lists_valid = c->index_valid = false;
     HostGroupsGuard guard(c);
@@ -1040,7 +1050,7 @@ int vdet_track_det_nms_f32(vdet_ctx *c, const float *h_tracks, int64_t t, int64_
     HIPCHK(c, hipMemcpyAsync(c->origidx.p, hidx.data(), (size_t)m * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->trk_boxes.p, tb.data(), tb.size() * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->trk_frames.p, tf.data(), tf.size() * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, host_sync(c));
     c->graph_valid = c->lists_valid = c->index_valid = false;     // shared scratch is overwritten below
     HostGroupsGuard guard(c);
     // build_graph clears the status word, so round 1 runs after it (inside the same stream order):
@@ -1076,7 +1086,7 @@ int vdet_iou_f64(vdet_ctx *c, const double *h_b1, int64_t n1, const double *h_b2
     }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(h_out, c->iou_out.p, (size_t)n1 * n2 * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, host_sync(c));
     return VDET_OK;
 }
 
@@ -1267,7 +1277,7 @@ int vdet_nms_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scor
                                c->order.as<uint16_t>(), c->ncand.as<int32_t>(), (int)F, (int)B, (int)C, d_scores, thres,
                                max_tracks, st, d_anchors, lz);
         }
-        if (c->debug_sync) { fprintf(stderr, "[vdet] iter %d pick...\n", t); HIPCHK(c, hipStreamSynchronize(c->stream)); fprintf(stderr, "[vdet] iter %d pick ok\n", t); }
+        if (c->debug_sync) { fprintf(stderr, "[vdet] iter %d pick...\n", t); HIPCHK(c, host_sync(c)); fprintf(stderr, "[vdet] iter %d pick ok\n", t); }
         {
             StageTimer tm(c, ST_TLINK);
 #define VDET_LINK(LTV) hipLaunchKernelGGL(track_link_kernel<LTV>, dim3((unsigned)C, 2), dim3(LTV), 0, c->stream, \
@@ -1285,14 +1295,14 @@ int vdet_nms_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scor
 #undef VDET_LINK
 #undef VDET_LINKM
         }
-        if (c->debug_sync) { fprintf(stderr, "[vdet] iter %d link...\n", t); HIPCHK(c, hipStreamSynchronize(c->stream)); fprintf(stderr, "[vdet] iter %d link ok\n", t); }
+        if (c->debug_sync) { fprintf(stderr, "[vdet] iter %d link...\n", t); HIPCHK(c, host_sync(c)); fprintf(stderr, "[vdet] iter %d link ok\n", t); }
         if (need_suppress) {
             StageTimer tm(c, ST_TSUPP);
             const int64_t nblk = (F * C + 3) / 4;     // grid-stride: a video without irregular frames exits at once
             hipLaunchKernelGGL(track_suppress_kernel, dim3((unsigned)std::min<int64_t>(nblk, 8 * c->n_cu)), dim3(256),
                                (size_t)sp.mask_words * 16, c->stream, sp);
         }
-        if (c->debug_sync) { fprintf(stderr, "[vdet] iter %d suppress...\n", t); HIPCHK(c, hipStreamSynchronize(c->stream)); fprintf(stderr, "[vdet] iter %d suppress ok\n", t); }
+        if (c->debug_sync) { fprintf(stderr, "[vdet] iter %d suppress...\n", t); HIPCHK(c, host_sync(c)); fprintf(stderr, "[vdet] iter %d suppress ok\n", t); }
         hipLaunchKernelGGL(track_commit_kernel, dim3(cg), dim3(64), 0, c->stream, st, (int)C, d_ntracks);
     }
     HIPCHK(c, hipGetLastError());
@@ -1370,7 +1380,7 @@ static int status_word(vdet_ctx *c, int *out)
 {
     Counters h;
     HIPCHK(c, hipMemcpyAsync(&h, c->d_cnt, sizeof h, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, host_sync(c));
     *out = h.status;
     return VDET_OK;
 }
@@ -1405,7 +1415,7 @@ int vdet_spatial_maxpool_f64(vdet_ctx *c, const double *h_tub_boxes, const int32
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(h_out_idx, c->tmp[5].p, (size_t)T * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(h_out_score, c->tmp[6].p, (size_t)T * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, host_sync(c));
     return VDET_OK;
 }
 
@@ -1458,7 +1468,7 @@ int vdet_series_maxpool_f64(vdet_ctx *c, const double *h_in, double *h_out, cons
                        c->tmp[2].as<int32_t>(), n, window, pad);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(h_out, c->tmp[3].p, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, host_sync(c));
     return VDET_OK;
 }
 
@@ -1490,7 +1500,7 @@ int vdet_series_interp_f64(vdet_ctx *c, const double *h_x, const double *h_y, co
                        c->tmp[4].as<int64_t>(), c->tmp[5].as<int32_t>(), nq, K, c->tmp[6].as<double>());
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(h_out, c->tmp[6].p, (size_t)nq * K * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, host_sync(c));
     return VDET_OK;
 }
 
@@ -1527,7 +1537,7 @@ int vdet_threshold_topk(vdet_ctx *c, const void *h_scores, int is_f64, int64_t B
     HIPCHK(c, hipGetLastError());
     if (k > 0) HIPCHK(c, hipMemcpyAsync(h_idx, c->tmp[1].p, (size_t)ncls * k * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(h_cnt, c->tmp[2].p, (size_t)ncls * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, host_sync(c));
     return VDET_OK;
 }
 
@@ -1557,7 +1567,7 @@ int vdet_conv1d_f32(vdet_ctx *c, const float *h_in, int Cin, int L, const float 
     }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(h_out, res, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, host_sync(c));
     return VDET_OK;
 }
 
