@@ -334,7 +334,9 @@ __device__ __forceinline__ bool pred_regular(float4 br, float rarea, float4 bc, 
     const float xx2 = amin(br.z, bc.z);
     const float yy2 = amin(br.w, bc.w);
     const float w = amax(0.0f, (xx2 - xx1) + 1.0f);
-    const float h = amax(0.0f, (yy2 - yy1) + 1.0f);
+    // (h is NOT clamped: v_max_f32 issues at half rate on gfx950 -- profiles/r02_valu_bench.csv -- and a negative h
+    //  only makes inter <= 0, hence r <= -t32 * uni: "no", and never "borderline", exactly like the clamped form)
+    const float h = (yy2 - yy1) + 1.0f;
     const float inter = w * h;
     const float uni = (rarea + carea) - inter;
     const float r = __builtin_fmaf(-t32, uni, inter);

@@ -1713,6 +1713,7 @@ int vdet_volume_pass(vdet_ctx *c, const float *d_scores, int64_t F, int64_t B, i
     if (conv) for (int k = 0; k < window; ++k) taps.w[k] = h_taps[k];
     const int ntiles = (int)((B + TB - 1) / TB);
     int64_t chunks = std::min<int64_t>(std::max<int64_t>(F / 8, 1), (8 * c->n_cu + ntiles - 1) / ntiles);
+    if (const char *e = getenv("VDET_VPASS_CHUNKS")) { const int v = atoi(e); if (v > 0) chunks = std::min<int64_t>(v, F); }   // A-B knob
     chunks = std::max<int64_t>(1, std::min<int64_t>(chunks, 65535));
     const int fchunk = (int)((F + chunks - 1) / chunks);
     const dim3 grid((unsigned)ntiles, (unsigned)((F + fchunk - 1) / fchunk));
