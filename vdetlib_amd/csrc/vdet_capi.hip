@@ -131,6 +131,11 @@ struct vdet_ctx {
     bool topk_attr_set = false;
     int link_threads = 256;       // VDET_LINK_THREADS=64|128|256: threads per link chain (A-B knob)
     bool link_memo = true;        // VDET_LINK_MEMO=0: every link step scans (A-B knob / tests)
+    // second stream of the context: the memo warm-up runs on it, next to the NMS walk of the same video
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool use_aux = false;         // VDET_AUX_STREAM=1: warm-up next to the walk on a second stream (A-B knob; measured: no gain,
+                                  // 19.2 vs 19.7 ms one video at a time, 17.9 vs 16.9 with 3 in flight -- more streams than hardware queues)
     int link_maxb = 8;            // VDET_LINK_MAXB=8|16: boxes per thread and batch in the warm-up's window scans (A-B knob)
     int link_warm = -1;           // VDET_LINK_WARM=m: chains warmed per class (-1: max_tracks + 2; 0: none)
     DevBuf linkmemo, linkstats, linkwarm;
@@ -742,6 +747,7 @@ int vdet_create(vdet_ctx **out, int device)
     if (const char *e = getenv("VDET_LINK_MEMO")) c->link_memo = atoi(e) != 0;
     if (const char *e = getenv("VDET_LINK_WARM")) c->link_warm = atoi(e);
     if (const char *e = getenv("VDET_LINK_MAXB")) c->link_maxb = atoi(e) == 16 ? 16 : 8;
+    if (const char *e = getenv("VDET_AUX_STREAM")) c->use_aux = atoi(e) != 0;
     if (const char *e = getenv("VDET_LINK_THREADS")) { const int v = atoi(e); if (v == 64 || v == 128 || v == 256) c->link_threads = v; }
     if (const char *e = getenv("VDET_DEBUG_SYNC")) c->debug_sync = atoi(e) != 0;
     {   // probe: do returning LDS atomics resolve same-address lanes in ascending lane order?
@@ -819,6 +825,9 @@ int vdet_destroy(vdet_ctx *c)
     for (DevBuf &b : c->tmp) b.release();
     for (auto &e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (c->d_cnt) (void)hipFree(c->d_cnt);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return VDET_OK;
@@ -1198,6 +1207,49 @@ int vdet_nms_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scor
     // regular-frame fast paths (lazy lists, x-window link): only when THIS graph build (or the cached
     // one being reused) ran K0 + the frame index -- gflags / the index are stale otherwise
     const bool regular_ok = c->sym_built;
+    const float link_t32 = thresh_to_f32(link_thres);
+    const int reach = max_frames > 0 ? (int)std::ceil((max_frames + 1) / 2.0) - 1 : (int)F;
+    const uint32_t *w_flags = regular_ok ? c->gflags.as<uint32_t>() : nullptr;
+    FrameIndex w_ix{nullptr, nullptr, nullptr, nullptr};
+    if (w_flags && c->index_valid && !c->no_index) w_ix = frame_index_of(c);
+    bool forked = false;
+    if (c->link_memo) {      // one memo per call: a link step depends on the video's boxes and link_thres only
+        HIPCHK(c, c->linkmemo.reserve((size_t)2 * F * B * 8));
+        HIPCHK(c, c->linkstats.reserve(16));
+        // warm the memo: the chains of every class's likely anchors, all at once (the chip is full instead of running
+        // 2 C latency-bound blocks per track); the tracking loop below then mostly walks known steps.  The warm-up only
+        // reads the sorted lists, so it runs on the context's second stream NEXT TO the NMS walk of the same video
+        // (per-stage timing keeps everything on one stream: HIP events on two streams would not add up)
+        const int wm = c->link_warm < 0 ? std::min(max_tracks + 2, 16) : std::min(c->link_warm, 64);
+        hipStream_t ws = c->stream;
+        if (c->use_aux && want_nms && !c->timing && wm > 0 && max_tracks > 0) {
+            if (!c->aux_stream) {
+                HIPCHK(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+                HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+                HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+            }
+            HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+            HIPCHK(c, hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
+            ws = c->aux_stream;
+            forked = true;
+        }
+        HIPCHK(c, hipMemsetAsync(c->linkmemo.p, 0, (size_t)2 * F * B * 8, ws));
+        HIPCHK(c, hipMemsetAsync(c->linkstats.p, 0, 16, ws));
+        if (wm > 0 && max_tracks > 0) {
+            HIPCHK(c, c->linkwarm.reserve((size_t)C * wm * 4));
+            StageTimer tm(c, ST_TLINK);
+            hipLaunchKernelGGL(track_warm_anchors_kernel, dim3((unsigned)C), dim3(256), 0, ws, c->tkeys.as<uint32_t>(),
+                               c->order.as<uint16_t>(), c->ncand.as<int32_t>(), (int)F, (int)B, (int)C, d_scores, thres, wm,
+                               c->linkwarm.as<int32_t>());
+#define VDET_WARM(MB) hipLaunchKernelGGL((track_link_memo_kernel<256, true, MB>), dim3((unsigned)(C * wm), 2), dim3(256), 0, ws, \
+                               reinterpret_cast<const float4 *>(d_boxes), (int)F, (int)B, max_tracks, link_t32, reach, \
+                               (const TrackState *)nullptr, (float *)nullptr, w_flags, w_ix, link_thres, \
+                               c->linkmemo.as<unsigned long long>(), c->linkstats.as<unsigned int>(), c->linkwarm.as<int32_t>())
+            if (c->link_maxb == 16) VDET_WARM(16); else VDET_WARM(8);
+#undef VDET_WARM
+        }
+        if (forked) HIPCHK(c, hipEventRecord(c->ev_join, c->aux_stream));
+    }
     if (want_nms) {                  // the NMS survivors: one walk over the lists, before they are consumed
         SortWalkArgs a{};
         a.walk_only = true;
@@ -1213,7 +1265,6 @@ int vdet_nms_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scor
     const unsigned cg = (unsigned)((C + 63) / 64);
     hipLaunchKernelGGL(track_init_kernel, dim3(cg), dim3(64), 0, c->stream, st, (int)C);
     HIPCHK(c, hipMemsetAsync(d_ntracks, 0, (size_t)C * 4, c->stream));
-    const int reach = max_frames > 0 ? (int)std::ceil((max_frames + 1) / 2.0) - 1 : (int)F;
     SuppressParams sp{};
     sp.boxes = reinterpret_cast<const float4 *>(d_boxes);
     sp.F = (int)F; sp.B = (int)B; sp.C = (int)C; sp.max_tracks = max_tracks;
@@ -1247,29 +1298,7 @@ int vdet_nms_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scor
     // host does not know whether every frame is regular (asynchronous build) the kernel asks the device
     const bool need_suppress = !sp.lazy || !sp.group_flags || !c->all_regular;
     sp.n_irregular = &c->d_cnt->irregular;
-    const float link_t32 = thresh_to_f32(link_thres);
-    if (c->link_memo) {      // one memo per call: a link step depends on the video's boxes and link_thres only
-        HIPCHK(c, c->linkmemo.reserve((size_t)2 * F * B * 8));
-        HIPCHK(c, c->linkstats.reserve(16));
-        HIPCHK(c, hipMemsetAsync(c->linkmemo.p, 0, (size_t)2 * F * B * 8, c->stream));
-        HIPCHK(c, hipMemsetAsync(c->linkstats.p, 0, 16, c->stream));
-        // warm the memo: the chains of every class's likely anchors, all at once (the chip is full instead of running
-        // 2 C latency-bound blocks per track); the tracking loop below then mostly walks known steps
-        const int wm = c->link_warm < 0 ? std::min(max_tracks + 2, 16) : std::min(c->link_warm, 64);
-        if (wm > 0 && max_tracks > 0) {
-            HIPCHK(c, c->linkwarm.reserve((size_t)C * wm * 4));
-            StageTimer tm(c, ST_TLINK);
-            hipLaunchKernelGGL(track_warm_anchors_kernel, dim3((unsigned)C), dim3(256), 0, c->stream, c->tkeys.as<uint32_t>(),
-                               c->order.as<uint16_t>(), c->ncand.as<int32_t>(), (int)F, (int)B, (int)C, d_scores, thres, wm,
-                               c->linkwarm.as<int32_t>());
-#define VDET_WARM(MB) hipLaunchKernelGGL((track_link_memo_kernel<256, true, MB>), dim3((unsigned)(C * wm), 2), dim3(256), 0, c->stream, \
-                               reinterpret_cast<const float4 *>(d_boxes), (int)F, (int)B, max_tracks, link_t32, reach, \
-                               (const TrackState *)nullptr, (float *)nullptr, sp.group_flags, sp.ix, link_thres, \
-                               c->linkmemo.as<unsigned long long>(), c->linkstats.as<unsigned int>(), c->linkwarm.as<int32_t>())
-            if (c->link_maxb == 16) VDET_WARM(16); else VDET_WARM(8);
-#undef VDET_WARM
-        }
-    }
+    if (forked) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));      // the memo is warm
     for (int t = 0; t < max_tracks; ++t) {
         {
             StageTimer tm(c, ST_TPICK);
