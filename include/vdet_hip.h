@@ -132,6 +132,19 @@ int vdet_track_det_nms_f32(vdet_ctx *ctx, const float *h_tracks, int64_t t, int6
 int vdet_iou_f64(vdet_ctx *ctx, const double *h_boxes1, int64_t n1, const double *h_boxes2,
                  int64_t n2, double *h_out);
 
+/*
+ * svm_scores (vdet/image_det.py:109-114), the path's one dense contraction:
+ *     out[n, m] = feat[n, k] . W[k, m] + B[m]          (B may be NULL)
+ * as a hand-written MFMA kernel (v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32): the reference computes it in
+ * numpy's result dtype -- float64 with its .mat SVM models, float32 when features and W are float32.  The feature
+ * scaling `features * (20 / feat_norm_mean)` stays with the caller (it is rounded in the features' dtype first, :112).
+ * Row-major host buffers; per output element the products are accumulated in ascending k, one fma each.
+ */
+int vdet_svm_scores_f64(vdet_ctx *ctx, const double *h_feat, int64_t n, int64_t k, const double *h_W,
+                        const double *h_B, int64_t m, double *h_out);
+int vdet_svm_scores_f32(vdet_ctx *ctx, const float *h_feat, int64_t n, int64_t k, const float *h_W,
+                        const float *h_B, int64_t m, float *h_out);
+
 /* ---- tubelet re-scoring cores (host buffers, synchronous, float64 like the reference) --------- */
 
 /*

@@ -90,3 +90,28 @@ def test_vid_shape_ragged_map_parity(oracle):
     assert gpu_dets == cpu_dets
     assert aps_g == aps_c and map_g == map_c
     assert map_g > 0.5
+
+
+def test_file_to_hbm_pipeline(tmp_path, oracle):
+    """SURVEY 8(f) rank 1 end to end: videos on disk as raw .npy -> memory map -> pinned staging (the one host pass)
+    -> asynchronous upload on its own stream, double-buffered, while the previous video is processed."""
+    import torch
+    from vdetlib_amd import ops, io as vio
+    vids = []
+    for i in range(3):
+        vid, f2d, _ = vid_shape_video(9100 + i, F=60, Bmax=200, C=8)
+        b, s, n = vio.arrays_from_frame_to_det(vid, f2d)
+        vio.save_video_raw(str(tmp_path / ('v%d' % i)), b, s, n)
+        vids.append((b, s, n))
+    up = vio.VideoUploader('cuda', nbuf=2)
+    pending = up.submit(str(tmp_path / 'v0'))
+    for i in range(3):
+        tb, ts, counts, ev = pending
+        if i + 1 < 3:
+            pending = up.submit(str(tmp_path / ('v%d' % (i + 1))))       # next video: copy + upload under this one's kernels
+        up.acquire(tb, ts, ev)
+        idx, cnt = ops.nms_volume(tb, ts, 0.3, score_thresh=float('-inf'))
+        b, s, n = vids[i]
+        assert np.array_equal(counts, n) and torch.equal(ts.cpu(), torch.from_numpy(s))
+        widx, wcnt = oracle.nms_volume(b, s, 0.3, score_thresh=float('-inf'), frames=(0, 10))
+        assert np.array_equal(cnt[:10].cpu().numpy(), wcnt[:10]) and np.array_equal(idx[:10].cpu().numpy(), widx[:10])

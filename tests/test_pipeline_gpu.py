@@ -233,3 +233,25 @@ def test_svm_scores_matches_numpy():
     want32 = np.dot(feats[:, :, 0, 0] * (20. / model32['feat_norm_mean']), model32['W']) + model32['B']
     assert got32.dtype == want32.dtype
     assert np.allclose(got32, want32, rtol=1e-5, atol=1e-5)      # float scores: the 1e-5 bar of BASELINE.json
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("shape", [(1, 1, 1), (16, 4, 16), (37, 1023, 201), (300, 130, 64), (65, 7, 3)])
+def test_svm_scores_mfma_kernel_layouts(dtype, shape):
+    """The hand-written MFMA GEMM behind svm_scores (vdet_svm_scores_f64 / _f32): odd sizes (zero-filled fragments,
+    masked stores) and an ASYMMETRIC W, so a swapped row / column map of the accumulator tile cannot pass."""
+    from vdetlib_amd.vdet import image_det as I
+    n, k, m = shape
+    rng = np.random.RandomState(n * 7 + k + m)
+    feats = rng.randn(n, k).astype(dtype)
+    W = (rng.randn(k, m) * 0.1 + np.arange(m)[None, :] * 0.01 + np.arange(k)[:, None] * 0.001).astype(dtype)
+    B = (np.arange(m) * 0.5).astype(dtype)
+    got = I.svm_scores(feats, {'feat_norm_mean': dtype(20.0), 'W': W, 'B': B})
+    want = np.dot(feats * (20. / dtype(20.0)), W) + B
+    assert got.dtype == want.dtype and got.shape == want.shape
+    tol = 1e-11 if dtype == np.float64 else 2e-4
+    assert np.allclose(got, want, rtol=tol, atol=tol * max(1.0, float(np.abs(want).max())))
+    if n >= 16 and k >= 4:             # identity probe: features = unit rows pick single rows of W, exactly
+        eye = np.zeros((n, k), dtype); idx = rng.randint(0, k, n); eye[np.arange(n), idx] = 1
+        got = I.svm_scores(eye, {'feat_norm_mean': dtype(20.0), 'W': W, 'B': np.zeros(m, dtype)})
+        assert np.array_equal(got, W[idx])

@@ -133,3 +133,15 @@ def test_caffemodel_to_npz_roundtrip(tmp_path):
     assert [w.shape for w, _ in net2.layers] == [(8, 6, 3), (2, 8, 5)]
     net2.save_npz(str(tmp_path / 'again.npz'))
     assert np.array_equal(np.load(str(tmp_path / 'again.npz'))['w1'], w1.reshape(2, 8, 5))
+
+
+def test_raw_video_files_are_memory_mapped(tmp_path):
+    """save_video_raw / open_video_raw: uncompressed .npy per array, read back as read-only memory maps (no copy)."""
+    rng = np.random.RandomState(3)
+    boxes = rng.rand(4, 7, 4).astype(np.float32)
+    scores = rng.randn(4, 7, 5).astype(np.float32)
+    counts = np.array([7, 3, 0, 7], np.int32)
+    vio.save_video_raw(str(tmp_path / 'v'), boxes, scores, counts)
+    b, s, c = vio.open_video_raw(str(tmp_path / 'v'))
+    assert isinstance(b, np.memmap) and isinstance(s, np.memmap) and not s.flags.writeable
+    assert np.array_equal(b, boxes) and np.array_equal(s, scores) and np.array_equal(c, counts)

@@ -34,6 +34,8 @@ SYMBOLS = {
     "vdet_nms_f32": (_ci, [_vp, _vp, _i64, _i64, _ci, _f64, _vp, _vp, ctypes.POINTER(_i64)]),
     "vdet_track_det_nms_f32": (_ci, [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _f64, _vp, ctypes.POINTER(_i64)]),
     "vdet_iou_f64": (_ci, [_vp, _vp, _i64, _vp, _i64, _vp]),
+    "vdet_svm_scores_f64": (_ci, [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _vp]),
+    "vdet_svm_scores_f32": (_ci, [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _vp]),
     "vdet_spatial_maxpool_f64": (_ci, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _f64, _vp, _vp]),
     "vdet_series_completion_f64": (_ci, [_vp, _vp, _vp, _i64]),
     "vdet_series_maxpool_f64": (_ci, [_vp, _vp, _vp, _vp, _i64, _ci, _f64]),

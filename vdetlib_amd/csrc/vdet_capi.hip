@@ -18,6 +18,7 @@
 #include "temporal_kernels.hpp"
 #include "tubelet_kernels.hpp"
 #include "track_kernels.hpp"
+#include "gemm_kernels.hpp"
 
 using namespace vdet;
 
@@ -1777,6 +1778,46 @@ int vdet_volume_pass(vdet_ctx *c, const float *d_scores, int64_t F, int64_t B, i
     c->keysrc.use_thr = use_score_thresh ? 1 : 0; c->keysrc.thr = score_thresh;
     c->keys_valid = !nokeys;
     return VDET_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+extern "C++" {
+template <typename T>
+static int svm_scores_impl(vdet_ctx *c, const T *h_feat, int64_t n, int64_t k, const T *h_W, const T *h_B, int64_t m, T *h_out)
+{
+    if (!c || n < 0 || k < 0 || m < 0) return VDET_EINVAL;
+    if (n == 0 || m == 0) return VDET_OK;
+    if ((k > 0 && (!h_feat || !h_W)) || !h_out) return fail(c, VDET_EINVAL, "null buffer");
+    if (n * k > ((int64_t)1 << 34) || k * m > ((int64_t)1 << 34) || n * m > ((int64_t)1 << 34)) return fail(c, VDET_EINVAL, "matrix too large");
+    HIPCHK(c, hipSetDevice(c->device));
+    timing_reset(c);
+    int rc;
+    if ((rc = upload(c, c->tmp[0], h_feat, (size_t)(n * k) * sizeof(T)))) return rc;
+    if ((rc = upload(c, c->tmp[1], h_W, (size_t)(k * m) * sizeof(T)))) return rc;
+    if (h_B && (rc = upload(c, c->tmp[2], h_B, (size_t)m * sizeof(T)))) return rc;
+    HIPCHK(c, c->tmp[3].reserve((size_t)(n * m) * sizeof(T)));
+    {
+        StageTimer tm(c, ST_OTHER);
+        hipLaunchKernelGGL(svm_scores_kernel<T>, dim3((unsigned)((m + 63) / 64), (unsigned)((n + 63) / 64)), dim3(256), 0, c->stream,
+                           c->tmp[0].as<T>(), c->tmp[1].as<T>(), h_B ? c->tmp[2].as<T>() : (const T *)nullptr, n, k, m, c->tmp[3].as<T>());
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(h_out, c->tmp[3].p, (size_t)(n * m) * sizeof(T), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, host_sync(c));
+    return VDET_OK;
+}
+}  // extern "C++"
+
+int vdet_svm_scores_f64(vdet_ctx *c, const double *h_feat, int64_t n, int64_t k, const double *h_W, const double *h_B, int64_t m,
+                        double *h_out)
+{
+    return svm_scores_impl<double>(c, h_feat, n, k, h_W, h_B, m, h_out);
+}
+
+int vdet_svm_scores_f32(vdet_ctx *c, const float *h_feat, int64_t n, int64_t k, const float *h_W, const float *h_B, int64_t m,
+                        float *h_out)
+{
+    return svm_scores_impl<float>(c, h_feat, n, k, h_W, h_B, m, h_out);
 }
 
 }  // extern "C"

@@ -17,19 +17,33 @@ def apply_image_nms(boxes, scores, thres=0.3):
 
 
 def svm_scores(features, svm_model):
-    """reference vdet/image_det.py:109-114: ``features * (20 / feat_norm_mean) @ W + B``, the path's one
-    dense contraction ([n, 1024] x [1024, 200]).  A plain library GEMM: the product
-    runs on the GPU through torch.matmul (rocBLAS / hipBLASLt) in numpy's result dtype (float64 for the
-    reference's .mat models), everything around it is numpy as in the reference.  No CPU fallback."""
-    import torch
-    if not torch.cuda.is_available():
-        raise RuntimeError("vdetlib_amd.vdet.image_det.svm_scores needs a HIP device (no CPU fallback)")
+    """reference vdet/image_det.py:109-114: ``features * (20 / feat_norm_mean) @ W + B``, the path's one dense
+    contraction ([n, 1024] x [1024, 200]), on the GPU as a hand-written MFMA kernel
+    (``vdet_svm_scores_f64`` / ``_f32``: v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32) in numpy's result
+    dtype -- float64 for the reference's .mat models, float32 when features and W both are.  The scaling, the
+    squeeze of [n,k,1,1] features and the broadcast of B are the reference's; no CPU fallback."""
+    from .. import _lib
     features = np.asarray(features)
     if features.ndim == 4:
         features = np.squeeze(features, axis=(2, 3))
     features = np.asarray(features) * (20. / svm_model['feat_norm_mean'])
     W = np.asarray(svm_model['W'])
-    dt = np.result_type(features.dtype, W.dtype)
-    prod = torch.matmul(torch.from_numpy(np.ascontiguousarray(features, dtype=dt)).cuda(),
-                        torch.from_numpy(np.ascontiguousarray(W, dtype=dt)).cuda()).cpu().numpy()
-    return prod + svm_model['B']
+    B = np.asarray(svm_model['B'])
+    if features.ndim != 2 or W.ndim != 2 or features.shape[1] != W.shape[0]:
+        raise ValueError("shapes %s and %s not aligned" % (features.shape, W.shape))
+    dt = np.result_type(features.dtype, W.dtype, B.dtype)
+    dt = np.dtype(np.float32) if dt == np.float32 else np.dtype(np.float64)
+    a = np.ascontiguousarray(features, dtype=dt)
+    w = np.ascontiguousarray(W, dtype=dt)
+    n, k = a.shape
+    m = w.shape[1]
+    bias = None
+    if B.size == m:                     # the usual [m] / [1, m] row: added inside the kernel
+        bias = np.ascontiguousarray(B.reshape(m), dtype=dt)
+    out = np.empty((n, m), dtype=dt)
+    ctx = _lib.get_context()
+    ctx.reset_stream()
+    fn = ctx.lib.vdet_svm_scores_f32 if dt == np.float32 else ctx.lib.vdet_svm_scores_f64
+    ctx.check(fn(ctx.h, a.ctypes.data, n, k, w.ctypes.data, bias.ctypes.data if bias is not None else None, m,
+                 out.ctypes.data))
+    return out if bias is not None else out + B
