@@ -1078,6 +1078,7 @@ struct WalkParams {
     int64_t cap;
     int *status;
     int mask_words;           // u32 words per wave
+    const uint32_t *group_flags;   // kFlagRegular per group (the K1s path ran), or null
 };
 
 // LDS words through which the lanes of one wave talk to each other (the walks' dead masks): every
@@ -1156,6 +1157,43 @@ __device__ __forceinline__ void walk_group(lds_mask_t mask, const uint16_t *__re
 }
 
 
+// REGULAR frames (finite boxes, positive areas; graph built by iou_bits_sym_kernel): the suppression graph is
+// SYMMETRIC and has no zero-union tags.  Then a candidate that was alive when its chunk started is a survivor iff
+// its dead bit is still clear when the chunk is done -- a later survivor of the chunk can not set it (if j
+// suppressed i, i would have suppressed j) -- so the chunk's survivors are read off the mask once per chunk
+// instead of being book-kept per survivor, a suppressed candidate costs no branch (its list length is zeroed with
+// a scalar select), and the long-list test is hoisted out per chunk (LONG).  The walk issues as many SALU as VALU
+// instructions (profiles/r02_pmc_sq2.csv: the scalar unit is the busier one); this form drops ~6 of the ~15 scalar
+// instructions per survivor.
+template <bool LONG>
+__device__ __forceinline__ void walk_group_regular(lds_mask_t mask, const uint16_t *__restrict__ adj, int lane, int c,
+                                                   uint32_t off, int deg, const int (&ls)[kWalkGrp], int ng,
+                                                   const uint32_t (&pre)[kWalkGrp])
+{
+    // (measured and rejected: one look at the mask per GROUP + testing in registers whether an earlier member's list
+    //  contains a later member -- no LDS round trip on the chain, but 12 half-rate compares per group: 6.0 vs 4.6 ms)
+#pragma unroll
+    for (int k = 0; k < kWalkGrp; ++k) {
+        if (k >= ng) break;
+        const int cu = __builtin_amdgcn_readlane(c, ls[k]);
+        const uint32_t dead = __builtin_amdgcn_readfirstlane((mask[cu >> 5] >> (cu & 31)) & 1u);
+        int d = __builtin_amdgcn_readlane(deg, ls[k]);
+        d = dead ? 0 : d;                                  // (scalar select: no branch for a suppressed candidate)
+        if (2 * lane < d) {
+            const uint32_t e0 = pre[k] & 0xFFFFu, e1 = pre[k] >> 16;
+            lds_or(mask, e0 >> 5, 1u << (e0 & 31));
+            lds_or(mask, e1 >> 5, 1u << (e1 & 31));
+        }
+        if (LONG && d > 128) {   // rare: long lists
+            const uint32_t o = __builtin_amdgcn_readlane(off, ls[k]);
+            for (int e0 = 128; e0 < d; e0 += 64) {
+                const uint32_t e = adj[o + min(e0 + lane, d - 1)];
+                if (e0 + lane < d) lds_or(mask, e >> 5, 1u << (e & 31));
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void walk_kernel(const WalkParams prm)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1171,6 +1209,7 @@ __global__ __launch_bounds__(256) void walk_kernel(const WalkParams prm)
     const uint16_t *order = prm.order + pr.obase;
     const int ncand = prm.ncand[p];
     const bool has_z = prm.group_z[pr.g] != 0;
+    const bool regular = !has_z && prm.group_flags && (prm.group_flags[pr.g] & kFlagRegular);    // (wave-uniform)
     int32_t *out = prm.keep_idx + (prm.mode == 2 ? (int64_t)rb : (int64_t)p * prm.cap);
     const int64_t cap = prm.mode == 2 ? (int64_t)N : prm.cap;
 
@@ -1212,6 +1251,7 @@ __global__ __launch_bounds__(256) void walk_kernel(const WalkParams prm)
         unsigned long long kept_lanes = 0ull;
         const uint32_t off = m_cur.x;
         const int deg = (int)m_cur.y;
+        const bool any_long = regular && __ballot(alive && deg > 128) != 0ull;
         while (am) {
             int ls[kWalkGrp];
             int ng = 0;
@@ -1231,9 +1271,14 @@ __global__ __launch_bounds__(256) void walk_kernel(const WalkParams prm)
                 const int d = __builtin_amdgcn_readlane(deg, ls[k]);
                 pre[k] = adjw[(o >> 1) + min(lane, (max(d, 1) - 1) >> 1)];
             }
-            if (has_z) walk_group<true>(mask, prm.adj, lane, c, off, deg, ls, ng, pre, kept_lanes, bad);
+            if (regular) {
+                if (any_long) walk_group_regular<true>(mask, prm.adj, lane, c, off, deg, ls, ng, pre);
+                else walk_group_regular<false>(mask, prm.adj, lane, c, off, deg, ls, ng, pre);
+            } else if (has_z) walk_group<true>(mask, prm.adj, lane, c, off, deg, ls, ng, pre, kept_lanes, bad);
             else walk_group<false>(mask, prm.adj, lane, c, off, deg, ls, ng, pre, kept_lanes, bad);
         }
+        if (regular)    // the chunk's survivors: alive when it started, bit still clear now (see walk_group_regular)
+            kept_lanes = __ballot(alive && !((mask[c >> 5] >> (c & 31)) & 1u));
         if (kept_lanes) {   // the chunk's survivors, in lane (= descending score) order, with one compacting store
             const int pos = nk + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(kept_lanes >> 32),
                                                                __builtin_amdgcn_mbcnt_lo((uint32_t)kept_lanes, 0u));

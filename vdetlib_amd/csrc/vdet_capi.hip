@@ -131,6 +131,7 @@ struct vdet_ctx {
     bool force_general = false;   // VDET_FORCE_GENERAL=1: disable the symmetric fast kernel (tests)
     bool topk_attr_set = false;
     int link_threads = 256;       // VDET_LINK_THREADS=64|128|256: threads per link chain (A-B knob)
+    bool walk_careful = false;    // VDET_WALK_CAREFUL=1: per-survivor bookkeeping also on regular frames (A-B knob / tests)
     bool link_memo = true;        // VDET_LINK_MEMO=0: every link step scans (A-B knob / tests)
     // second stream of the context: the memo warm-up runs on it, next to the NMS walk of the same video
     hipStream_t aux_stream = nullptr;
@@ -585,6 +586,7 @@ int launch_sort_walk(vdet_ctx *c, const SortWalkArgs &a, int nmax, int64_t order
     wp.cap = a.cap;
     wp.status = &c->d_cnt->status;
     wp.mask_words = (int)(r16((size_t)4 * ((std::max(nmax, 1) + 31) / 32)) / 4);
+    wp.group_flags = (c->sym_built && !c->walk_careful) ? c->gflags.as<uint32_t>() : nullptr;   // frames whose graph is symmetric
     {
         const int nblk = (((a.P + 3) / 4) + 7) & ~7;
         StageTimer tm(c, ST_WALK);
@@ -745,6 +747,7 @@ int vdet_create(vdet_ctx **out, int device)
     if (const char *e = getenv("VDET_NO_TRANSPOSE")) c->no_transpose = atoi(e) != 0;
     if (const char *e = getenv("VDET_NO_INDEX")) c->no_index = atoi(e) != 0;
     if (const char *e = getenv("VDET_NO_LAZY")) c->no_lazy = atoi(e) != 0;
+    if (const char *e = getenv("VDET_WALK_CAREFUL")) c->walk_careful = atoi(e) != 0;
     if (const char *e = getenv("VDET_LINK_MEMO")) c->link_memo = atoi(e) != 0;
     if (const char *e = getenv("VDET_LINK_WARM")) c->link_warm = atoi(e);
     if (const char *e = getenv("VDET_LINK_MAXB")) c->link_maxb = atoi(e) == 16 ? 16 : 8;
