@@ -291,7 +291,7 @@ def test_track_volume_random_sweep(oracle, seed):
 
 @pytest.mark.parametrize("knob", ["VDET_FORCE_GENERAL", "VDET_NO_INDEX", "VDET_NO_TRANSPOSE", "VDET_NO_LAZY",
                                   "VDET_WAVE_TRANSPOSE=0", "VDET_ATOMIC_RANK=0", "VDET_LINK_MEMO=0", "VDET_LINK_THREADS=64",
-                                  "VDET_LINK_THREADS=128", "VDET_LINK_WARM=0", "VDET_LINK_MAXB=16", "VDET_AUX_STREAM=1", "VDET_WALK_CAREFUL=1"])
+                                  "VDET_LINK_THREADS=128", "VDET_LINK_WARM=0", "VDET_LINK_MAXB=16", "VDET_AUX_STREAM=1", "VDET_WALK_CAREFUL=1", "VDET_RESCORE_ADJ=0"])
 def test_alternative_kernel_paths_agree(monkeypatch, knob):
     """Every A/B knob selects a different kernel path for the same result (general predicate kernel,
     no x-index, strided key reads, eager track_det_nms, ballot transposition in K1s, ballot ranks in
@@ -301,11 +301,14 @@ def test_alternative_kernel_paths_agree(monkeypatch, knob):
     boxes, scores = _fused_case(61, 12, 1300, 6)
     tb, ts = torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda()
     kw = dict(nms_thres=0.3, thres=0.2, max_tracks=4, link_thres=0.5)
-    ref = ops.nms_track_volume(tb, ts, **kw)
-    ref_r = ops.rescore_tracks(ref[2], ref[4], tb, ts, overlap_thres=0.6, window=3)
+    cr = _lib.Context(torch.cuda.current_device())
+    cr.set_cache(True)           # (cache on: the default re-scoring path takes its candidates from the suppression graph)
+    ref = ops.nms_track_volume(tb, ts, ctx=cr, **kw)
+    ref_r = ops.rescore_tracks(ref[2], ref[4], tb, ts, overlap_thres=0.6, window=3, ctx=cr)
     name, _, val = knob.partition('=')
     monkeypatch.setenv(name, val or '1')
     cx = _lib.Context(torch.cuda.current_device())
+    cx.set_cache(True)
     got = ops.nms_track_volume(tb, ts, ctx=cx, **kw)
     got_r = ops.rescore_tracks(got[2], got[4], tb, ts, overlap_thres=0.6, window=3, ctx=cx)
     for a, b in zip(list(ref) + list(ref_r), list(got) + list(got_r)):

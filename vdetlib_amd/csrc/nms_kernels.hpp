@@ -933,13 +933,19 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 && CPW <= 10) ? 8 : 1) void s
             tot[lane * 4] = ex; tot[lane * 4 + 1] = ex + a0; tot[lane * 4 + 2] = ex + a0 + a1; tot[lane * 4 + 3] = ex + a0 + a1 + a2;
         }
         __syncthreads();
+        if (tid < 256) {   // fold the digit offsets into the per-wave bases: the scatter then makes ONE table look-up per
+            const uint32_t t = tot[tid];        // key instead of two (the kernel is LDS-bound: profiles/r02_pmc_sq2.csv)
+#pragma unroll
+            for (int ww = 0; ww < NW; ++ww) bases[ww * 256 + tid] += t;
+        }
+        __syncthreads();
 #pragma unroll
         for (int ch = 0; ch < CPW; ++ch) {
             const int q = (c0 + ch) * 64 + lane;
             const bool valid = (c0 + ch) < nchunks && q < N;
             if (valid) {
                 const uint32_t d = ra[ch] >> 16;
-                dst[bases[w * 256 + d] + tot[d] + rl[ch]] = (uint16_t)(ra[ch] & 0xFFFFu);
+                dst[bases[w * 256 + d] + rl[ch]] = (uint16_t)(ra[ch] & 0xFFFFu);
             }
         }
         __syncthreads();

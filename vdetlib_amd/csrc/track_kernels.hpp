@@ -475,7 +475,7 @@ __global__ __launch_bounds__(LT) void track_link_memo_kernel(const float4 *__res
                                                              const uint32_t *__restrict__ group_flags,
                                                              const FrameIndex ix, double link_thres,
                                                              unsigned long long *memo, unsigned int *__restrict__ stats,
-                                                             const int32_t *__restrict__ warm)
+                                                             const int32_t *__restrict__ warm, int32_t *__restrict__ nodes)
 {
     __shared__ float sv[2][LT / 64];
     __shared__ int si[2][LT / 64];
@@ -501,6 +501,7 @@ __global__ __launch_bounds__(LT) void track_link_memo_kernel(const float4 *__res
         anchor_frame = s.anchor_frame;
         anchor_box = s.anchor_box;
         trk = tracks + ((int64_t)c * max_tracks + s.ntracks) * F * 5;
+        if (nodes) nodes += ((int64_t)c * max_tracks + s.ntracks) * F;      // which proposal each row of the track is
         const float qnan = __uint_as_float(0x7FC00000u);
         if (dir > 0) { for (int i = anchor_frame * 5 + tid; i < F * 5; i += LT) trk[i] = qnan; }
         else { for (int i = tid; i < anchor_frame * 5; i += LT) trk[i] = qnan; }
@@ -509,6 +510,7 @@ __global__ __launch_bounds__(LT) void track_link_memo_kernel(const float4 *__res
             const float4 anchor = trunc4(boxes[(int64_t)anchor_frame * B + anchor_box]);
             float *r = trk + (int64_t)anchor_frame * 5;
             r[0] = anchor.x; r[1] = anchor.y; r[2] = anchor.z; r[3] = anchor.w; r[4] = 1.0f;
+            if (nodes) nodes[anchor_frame] = anchor_box;
         }
     }
     unsigned long long *mm = memo + (int64_t)(dir > 0 ? 0 : 1) * F * B;
@@ -549,6 +551,7 @@ __global__ __launch_bounds__(LT) void track_link_memo_kernel(const float4 *__res
                         float *r = trk + (int64_t)pend_f * 5;
                         r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w; r[4] = __uint_as_float(pend_s);
                     }
+                    if (nodes && lane == 0) nodes[f] = bidx;
                     pend_f = f; pend_s = sbits; pend_b = nb;
                 }
             }
@@ -648,6 +651,7 @@ __global__ __launch_bounds__(LT) void track_link_memo_kernel(const float4 *__res
             const float4 t = trunc4(sb[par][bw]);
             float *r = trk + (int64_t)f * 5;
             r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w; r[4] = best;
+            if (nodes) nodes[f] = bidx;
         }
         node = bidx; fprev = f; ++step;
     }
@@ -934,7 +938,9 @@ __global__ __launch_bounds__(256) void rescore_spatial_kernel(const float *__res
                                                               const float *__restrict__ scores, int F, int B, int C, int T,
                                                               double thres, double *__restrict__ out_score,
                                                               float *__restrict__ out_box, const FrameIndex ix,
-                                                              const uint32_t *__restrict__ group_flags)
+                                                              const uint32_t *__restrict__ group_flags,
+                                                              const int32_t *__restrict__ nodes, const uint2 *__restrict__ row_meta,
+                                                              const uint16_t *__restrict__ adj, double min_self_iou)
 {
     // waves are ordered frame-major ((f*C + c)*T + t): neighbours in the dispatch order read the same
     // frame's x-window, which then stays in L2
@@ -956,7 +962,38 @@ __global__ __launch_bounds__(256) void rescore_spatial_kernel(const float *__res
     double bs = 0.0;
     int64_t bi = -1;
     const float wc = (row[2] - row[0]) + 1.0f;
-    if (ix.xbox && group_flags && (group_flags[f] & kFlagRegular) && thres > 1e-6 && wc > 0.0f && wc < 3.0e38f) {
+    // The tubelet box is trunc(box of proposal j) and the link kernels recorded j (nodes): every detection with
+    // IoU(T, k) > thres then is j itself or one of j's NEIGHBOURS in the frame's suppression graph -- 1 - IoU is a
+    // metric (Jaccard distance), so IoU(b_j, b_k) >= IoU(T, b_k) + IoU(b_j, T) - 1 > nms_thres + margin whenever
+    // IoU(b_j, T) > min_self_iou = 1 - (thres - nms_thres) + margin (1.0 for integer boxes).  ~93 candidates from the
+    // adjacency list instead of the ~1 100 boxes of the x-window; the same f64 predicate and arg-max decide.
+    bool via_adj = false;
+    if (nodes && group_flags && (group_flags[f] & kFlagRegular)) {
+        const int j = nodes[e];
+        if (j >= 0 && j < B) {
+            const float4 bj = boxes[(int64_t)f * B + j];
+            const float4 tj = trunc4(bj);
+            if (tj.x == row[0] && tj.y == row[1] && tj.z == row[2] && tj.w == row[3]) {
+                const double q[4] = {(double)bj.x, (double)bj.y, (double)bj.z, (double)bj.w};
+                if (iou_f64_pair(p, q) > min_self_iou) {
+                    via_adj = true;
+                    const uint2 meta = row_meta[(int64_t)f * B + j];
+                    const int n = (int)meta.y + 1;            // the neighbours + j itself
+                    for (int i = tid; i < n; i += 64) {
+                        const int64_t k = i == 0 ? j : (int64_t)(adj[meta.x + (i - 1)] & 0x7FFF);
+                        const float4 bb = boxes[(int64_t)f * B + k];
+                        const double qq[4] = {(double)bb.x, (double)bb.y, (double)bb.z, (double)bb.w};
+                        if (iou_f64_pair(p, qq) > thres) {
+                            const double s = (double)scores[((int64_t)f * B + k) * C + c];
+                            if (argmax_better(s, k, bs, bi)) { bs = s; bi = k; }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (via_adj) {
+    } else if (ix.xbox && group_flags && (group_flags[f] & kFlagRegular) && thres > 1e-6 && wc > 0.0f && wc < 3.0e38f) {
         int r0, r1;
         xwindow(ix, f, row[0], wc, thres, r0, r1);
         // f32 screen before the float64 IoU (vdet/tubelet_cls.py:514-532 computes it in f64): the f32

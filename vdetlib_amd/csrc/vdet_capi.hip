@@ -140,7 +140,12 @@ struct vdet_ctx {
                                   // 19.2 vs 19.7 ms one video at a time, 17.9 vs 16.9 with 3 in flight -- more streams than hardware queues)
     int link_maxb = 8;            // VDET_LINK_MAXB=8|16: boxes per thread and batch in the warm-up's window scans (A-B knob)
     int link_warm = -1;           // VDET_LINK_WARM=m: chains warmed per class (-1: max_tracks + 2; 0: none)
-    DevBuf linkmemo, linkstats, linkwarm;
+    DevBuf linkmemo, linkstats, linkwarm, tracknode;
+    // which proposal every row of the last tracking call's tracks is (written by the link kernels; vdet_rescore_tracks
+    // then finds a tubelet box's overlapping detections among that proposal's graph neighbours)
+    struct NodeKey { const void *tracks = nullptr, *boxes = nullptr; int64_t F = 0, B = 0, C = 0; int T = 0; double nms_thres = 0; } nodekey;
+    bool nodes_valid = false;
+    bool rescore_adj = true;      // VDET_RESCORE_ADJ=0: always scan the x-window (A-B knob)
     size_t dyn_lds_max = 0;
 };
 
@@ -748,6 +753,7 @@ int vdet_create(vdet_ctx **out, int device)
     if (const char *e = getenv("VDET_NO_INDEX")) c->no_index = atoi(e) != 0;
     if (const char *e = getenv("VDET_NO_LAZY")) c->no_lazy = atoi(e) != 0;
     if (const char *e = getenv("VDET_WALK_CAREFUL")) c->walk_careful = atoi(e) != 0;
+    if (const char *e = getenv("VDET_RESCORE_ADJ")) c->rescore_adj = atoi(e) != 0;
     if (const char *e = getenv("VDET_LINK_MEMO")) c->link_memo = atoi(e) != 0;
     if (const char *e = getenv("VDET_LINK_WARM")) c->link_warm = atoi(e);
     if (const char *e = getenv("VDET_LINK_MAXB")) c->link_maxb = atoi(e) == 16 ? 16 : 8;
@@ -823,7 +829,7 @@ int vdet_destroy(vdet_ctx *c)
     DevBuf *bufs[] = {&c->boxes, &c->scores, &c->keys, &c->excl, &c->frames, &c->groups, &c->tiles, &c->bits,
                       &c->rowz, &c->rowmeta, &c->groupz, &c->adj, &c->comp, &c->origidx, &c->out64,
                       &c->trk_frames, &c->trk_boxes, &c->b1, &c->b2, &c->iou_out, &c->order, &c->ncand, &c->keepidx,
-                      &c->keepcnt, &c->gflags, &c->pairs, &c->tkeys, &c->tstate, &c->visited, &c->heads, &c->xkeys, &c->xord, &c->xncand, &c->linkmemo, &c->linkstats, &c->linkwarm,
+                      &c->keepcnt, &c->gflags, &c->pairs, &c->tkeys, &c->tstate, &c->visited, &c->heads, &c->xkeys, &c->xord, &c->xncand, &c->linkmemo, &c->linkstats, &c->linkwarm, &c->tracknode,
                       &c->xbox, &c->xcum, &c->xinfo};
     for (DevBuf *b : bufs) b->release();
     for (DevBuf &b : c->tmp) b.release();
@@ -864,7 +870,7 @@ int vdet_set_cache(vdet_ctx *c, int enable)
 int vdet_invalidate(vdet_ctx *c)
 {
     if (!c) return VDET_EINVAL;
-    c->graph_valid = c->lists_valid = c->index_valid = c->keys_valid = false;
+    c->graph_valid = c->lists_valid = c->index_valid = c->keys_valid = c->nodes_valid = false;
     return VDET_OK;
 }
 
@@ -1216,6 +1222,9 @@ int vdet_nms_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scor
     const uint32_t *w_flags = regular_ok ? c->gflags.as<uint32_t>() : nullptr;
     FrameIndex w_ix{nullptr, nullptr, nullptr, nullptr};
     if (w_flags && c->index_valid && !c->no_index) w_ix = frame_index_of(c);
+    c->nodes_valid = false;
+    HIPCHK(c, c->tracknode.reserve((size_t)std::max<int64_t>(C * max_tracks * F, 1) * 4));
+    HIPCHK(c, hipMemsetAsync(c->tracknode.p, 0xFF, (size_t)std::max<int64_t>(C * max_tracks * F, 1) * 4, c->stream));
     bool forked = false;
     if (c->link_memo) {      // one memo per call: a link step depends on the video's boxes and link_thres only
         HIPCHK(c, c->linkmemo.reserve((size_t)2 * F * B * 8));
@@ -1248,7 +1257,8 @@ int vdet_nms_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scor
 #define VDET_WARM(MB) hipLaunchKernelGGL((track_link_memo_kernel<256, true, MB>), dim3((unsigned)(C * wm), 2), dim3(256), 0, ws, \
                                reinterpret_cast<const float4 *>(d_boxes), (int)F, (int)B, max_tracks, link_t32, reach, \
                                (const TrackState *)nullptr, (float *)nullptr, w_flags, w_ix, link_thres, \
-                               c->linkmemo.as<unsigned long long>(), c->linkstats.as<unsigned int>(), c->linkwarm.as<int32_t>())
+                               c->linkmemo.as<unsigned long long>(), c->linkstats.as<unsigned int>(), c->linkwarm.as<int32_t>(), \
+                               (int32_t *)nullptr)
             if (c->link_maxb == 16) VDET_WARM(16); else VDET_WARM(8);
 #undef VDET_WARM
         }
@@ -1319,7 +1329,7 @@ int vdet_nms_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scor
 #define VDET_LINKM(LTV) hipLaunchKernelGGL((track_link_memo_kernel<LTV, false, 8>), dim3((unsigned)C, 2), dim3(LTV), 0, c->stream, \
                                reinterpret_cast<const float4 *>(d_boxes), (int)F, (int)B, max_tracks, link_t32, reach, st, \
                                d_tracks, sp.group_flags, sp.ix, link_thres, c->linkmemo.as<unsigned long long>(), c->linkstats.as<unsigned int>(), \
-                               (const int32_t *)nullptr)
+                               (const int32_t *)nullptr, c->tracknode.as<int32_t>())
             if (c->link_memo) {
                 if (c->link_threads == 64) VDET_LINKM(64); else if (c->link_threads == 128) VDET_LINKM(128); else VDET_LINKM(256);
             } else {
@@ -1339,6 +1349,11 @@ int vdet_nms_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scor
         hipLaunchKernelGGL(track_commit_kernel, dim3(cg), dim3(64), 0, c->stream, st, (int)C, d_ntracks);
     }
     HIPCHK(c, hipGetLastError());
+    if (c->link_memo) {
+        c->nodekey.tracks = d_tracks; c->nodekey.boxes = d_boxes; c->nodekey.F = F; c->nodekey.B = B; c->nodekey.C = C;
+        c->nodekey.T = max_tracks; c->nodekey.nms_thres = nms_thres;
+        c->nodes_valid = true;
+    }
     return VDET_OK;
 }
 
@@ -1385,9 +1400,19 @@ int vdet_rescore_tracks(vdet_ctx *c, const float *d_tracks, const int32_t *d_ntr
     }
     {
         StageTimer tm(c, ST_RSPATIAL);
+        // the tracks of the last tracking call on this context, same boxes, graph still in place (cache contract):
+        // candidates from the suppression graph (see the kernel); needs overlap_thres well above the graph's threshold
+        const bool use_adj = c->rescore_adj && flags && c->cache_enabled && c->nodes_valid && c->graph_valid &&
+                             c->nodekey.tracks == d_tracks && c->nodekey.boxes == d_boxes && c->prep.boxes == d_boxes &&
+                             c->nodekey.F == F && c->nodekey.B == B && c->nodekey.C == C && c->nodekey.T == max_tracks &&
+                             c->prep.F == F && c->prep.B == B && overlap_thres - c->nodekey.nms_thres > 0.05 &&
+                             c->nodekey.nms_thres > 0.0 && overlap_thres < 1.0;
+        const double min_self = use_adj ? 1.0 - (overlap_thres - c->nodekey.nms_thres) + 0.02 : 2.0;
         hipLaunchKernelGGL(rescore_spatial_kernel, dim3((unsigned)((nb + 3) / 4)), dim3(256), 0, c->stream, d_tracks, d_ntracks,
                            reinterpret_cast<const float4 *>(d_boxes), d_scores, (int)F, (int)B, (int)C, max_tracks,
-                           overlap_thres, d_det_score, d_boxes_out, ix, flags);
+                           overlap_thres, d_det_score, d_boxes_out, ix, flags,
+                           use_adj ? c->tracknode.as<int32_t>() : (const int32_t *)nullptr, c->rowmeta.as<uint2>(),
+                           c->adj.as<uint16_t>(), min_self);
     }
     {
         StageTimer tm(c, ST_RSERIES);
