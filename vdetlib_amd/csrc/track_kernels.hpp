@@ -931,22 +931,14 @@ __global__ void track_init_kernel(TrackState *__restrict__ st, int C)
 //   out_score [C,T,F] f64 (NaN = no box), out_box [C,T,F,4] f32 (the "regressed" box)
 // ------------------------------------------------------------------------------------------------
 // one WAVE per (class, track, frame) (600 000 of them at c2: with one 256-thread block each the
-// kernel was bound by the block launch rate and an 8-barrier LDS reduction), 4 per block
-__global__ __launch_bounds__(256) void rescore_spatial_kernel(const float *__restrict__ tracks,
-                                                              const int32_t *__restrict__ ntracks,
-                                                              const float4 *__restrict__ boxes,
-                                                              const float *__restrict__ scores, int F, int B, int C, int T,
-                                                              double thres, double *__restrict__ out_score,
-                                                              float *__restrict__ out_box, const FrameIndex ix,
-                                                              const uint32_t *__restrict__ group_flags,
-                                                              const int32_t *__restrict__ nodes, const uint2 *__restrict__ row_meta,
-                                                              const uint16_t *__restrict__ adj, double min_self_iou)
+// kernel was bound by the block launch rate and an 8-barrier LDS reduction), 4 per block.
+// wv = (f * C + c) * T + t: neighbours in the dispatch order read the same frame's x-window (L2).
+__device__ __forceinline__ void rescore_one_scan(int64_t wv, int tid, const float *__restrict__ tracks,
+                                                 const int32_t *__restrict__ ntracks, const float4 *__restrict__ boxes,
+                                                 const float *__restrict__ scores, int F, int B, int C, int T, double thres,
+                                                 double *__restrict__ out_score, float *__restrict__ out_box,
+                                                 const FrameIndex &ix, const uint32_t *__restrict__ group_flags)
 {
-    // waves are ordered frame-major ((f*C + c)*T + t): neighbours in the dispatch order read the same
-    // frame's x-window, which then stays in L2
-    const int tid = threadIdx.x & 63;
-    const int64_t wv = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (wv >= (int64_t)F * C * T) return;
     const int t = (int)(wv % T);
     const int fc = (int)(wv / T);
     const int f = fc / C, c = fc - f * C;
@@ -962,38 +954,7 @@ __global__ __launch_bounds__(256) void rescore_spatial_kernel(const float *__res
     double bs = 0.0;
     int64_t bi = -1;
     const float wc = (row[2] - row[0]) + 1.0f;
-    // The tubelet box is trunc(box of proposal j) and the link kernels recorded j (nodes): every detection with
-    // IoU(T, k) > thres then is j itself or one of j's NEIGHBOURS in the frame's suppression graph -- 1 - IoU is a
-    // metric (Jaccard distance), so IoU(b_j, b_k) >= IoU(T, b_k) + IoU(b_j, T) - 1 > nms_thres + margin whenever
-    // IoU(b_j, T) > min_self_iou = 1 - (thres - nms_thres) + margin (1.0 for integer boxes).  ~93 candidates from the
-    // adjacency list instead of the ~1 100 boxes of the x-window; the same f64 predicate and arg-max decide.
-    bool via_adj = false;
-    if (nodes && group_flags && (group_flags[f] & kFlagRegular)) {
-        const int j = nodes[e];
-        if (j >= 0 && j < B) {
-            const float4 bj = boxes[(int64_t)f * B + j];
-            const float4 tj = trunc4(bj);
-            if (tj.x == row[0] && tj.y == row[1] && tj.z == row[2] && tj.w == row[3]) {
-                const double q[4] = {(double)bj.x, (double)bj.y, (double)bj.z, (double)bj.w};
-                if (iou_f64_pair(p, q) > min_self_iou) {
-                    via_adj = true;
-                    const uint2 meta = row_meta[(int64_t)f * B + j];
-                    const int n = (int)meta.y + 1;            // the neighbours + j itself
-                    for (int i = tid; i < n; i += 64) {
-                        const int64_t k = i == 0 ? j : (int64_t)(adj[meta.x + (i - 1)] & 0x7FFF);
-                        const float4 bb = boxes[(int64_t)f * B + k];
-                        const double qq[4] = {(double)bb.x, (double)bb.y, (double)bb.z, (double)bb.w};
-                        if (iou_f64_pair(p, qq) > thres) {
-                            const double s = (double)scores[((int64_t)f * B + k) * C + c];
-                            if (argmax_better(s, k, bs, bi)) { bs = s; bi = k; }
-                        }
-                    }
-                }
-            }
-        }
-    }
-    if (via_adj) {
-    } else if (ix.xbox && group_flags && (group_flags[f] & kFlagRegular) && thres > 1e-6 && wc > 0.0f && wc < 3.0e38f) {
+    if (ix.xbox && group_flags && (group_flags[f] & kFlagRegular) && thres > 1e-6 && wc > 0.0f && wc < 3.0e38f) {
         int r0, r1;
         xwindow(ix, f, row[0], wc, thres, r0, r1);
         // f32 screen before the float64 IoU (vdet/tubelet_cls.py:514-532 computes it in f64): the f32
@@ -1040,6 +1001,118 @@ __global__ __launch_bounds__(256) void rescore_spatial_kernel(const float *__res
         } else {   // no overlapping detection: sentinel score, box unchanged (:526-530)
             out_score[e] = -1e5;
             out_box[e * 4 + 0] = row[0]; out_box[e * 4 + 1] = row[1]; out_box[e * 4 + 2] = row[2]; out_box[e * 4 + 3] = row[3];
+        }
+    }
+}
+
+// TODO_LIST = false: every (class, track, frame); true: only the entries rescore_adj_kernel could not serve (grid-stride)
+template <bool TODO_LIST>
+__global__ __launch_bounds__(256) void rescore_spatial_kernel(const float *__restrict__ tracks,
+                                                              const int32_t *__restrict__ ntracks,
+                                                              const float4 *__restrict__ boxes,
+                                                              const float *__restrict__ scores, int F, int B, int C, int T,
+                                                              double thres, double *__restrict__ out_score,
+                                                              float *__restrict__ out_box, const FrameIndex ix,
+                                                              const uint32_t *__restrict__ group_flags,
+                                                              const int32_t *__restrict__ todo, const unsigned int *__restrict__ todo_cnt)
+{
+    const int tid = threadIdx.x & 63;
+    const int64_t w0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (!TODO_LIST) {
+        if (w0 < (int64_t)F * C * T) rescore_one_scan(w0, tid, tracks, ntracks, boxes, scores, F, B, C, T, thres, out_score, out_box, ix, group_flags);
+    } else {
+        const int64_t n = (int64_t)*todo_cnt;
+        for (int64_t i = w0; i < n; i += (int64_t)gridDim.x * 4)
+            rescore_one_scan(todo[i], tid, tracks, ntracks, boxes, scores, F, B, C, T, thres, out_score, out_box, ix, group_flags);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same spatial max-pool with the candidates taken from the suppression graph.  The tubelet box T is
+// trunc(box of proposal j) and the link kernels recorded j (nodes): every detection with IoU(T, k) > thres then
+// is j itself or one of j's NEIGHBOURS in the frame's graph -- 1 - IoU is a metric (Jaccard distance), so
+//     IoU(b_j, b_k) >= IoU(T, b_k) + IoU(b_j, T) - 1 > nms_thres + margin
+// whenever IoU(b_j, T) > min_self_iou = 1 - (thres - nms_thres) + margin (IoU(b_j, T) = 1 for integer boxes).
+// ~93 candidates from the adjacency list instead of the ~1 100 boxes of the x-window, the same f64 predicate and
+// arg-max decide.  16 lanes per tubelet box, 16 boxes per block (one wave per box spent its time in 5 dependent
+// memory round trips: 0.72 ms); entries this path can not serve (no recorded node, box mismatch, irregular frame,
+// IoU(b_j, T) too small) are appended to `todo` for rescore_spatial_kernel.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rescore_adj_kernel(const float *__restrict__ tracks, const int32_t *__restrict__ ntracks,
+                                                          const float4 *__restrict__ boxes, const float *__restrict__ scores,
+                                                          int F, int B, int C, int T, double thres, double *__restrict__ out_score,
+                                                          float *__restrict__ out_box, const uint32_t *__restrict__ group_flags,
+                                                          const int32_t *__restrict__ nodes, const uint2 *__restrict__ row_meta,
+                                                          const uint16_t *__restrict__ adj, double min_self_iou,
+                                                          int32_t *__restrict__ todo, unsigned int *__restrict__ todo_cnt)
+{
+    const int l = threadIdx.x & 15;
+    const int64_t wv = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (wv >= (int64_t)F * C * T) return;
+    const int t = (int)(wv % T);
+    const int fc = (int)(wv / T);
+    const int f = fc / C, c = fc - f * C;
+    const int64_t e = ((int64_t)c * T + t) * F + f;
+    const float *row = tracks + e * 5;
+    const float r0 = row[0], r1 = row[1], r2 = row[2], r3 = row[3];
+    if (t >= ntracks[c] || r0 != r0) {
+        if (l == 0) out_score[e] = __longlong_as_double(0x7FF8000000000000ll);
+        if (l < 4) out_box[e * 4 + l] = __uint_as_float(0x7FC00000u);
+        return;
+    }
+    const double p[4] = {(double)r0, (double)r1, (double)r2, (double)r3};
+    bool ok = false;
+    int j = -1;
+    if (group_flags[f] & kFlagRegular) {
+        j = nodes[e];
+        if (j >= 0 && j < B) {
+            const float4 bj = boxes[(int64_t)f * B + j];
+            const float4 tj = trunc4(bj);
+            if (tj.x == r0 && tj.y == r1 && tj.z == r2 && tj.w == r3) {
+                const double q[4] = {(double)bj.x, (double)bj.y, (double)bj.z, (double)bj.w};
+                ok = iou_f64_pair(p, q) > min_self_iou;
+            }
+        }
+    }
+    if (!ok) {     // (uniform over the 16 lanes of the box)
+        if (l == 0) todo[atomicAdd(todo_cnt, 1u)] = (int32_t)wv;
+        return;
+    }
+    const uint2 meta = row_meta[(int64_t)f * B + j];
+    const int n = (int)meta.y + 1;                // the neighbours + j itself
+    double bs = 0.0;
+    int64_t bi = -1;
+    const float pa = ((r2 - r0) + 1.0f) * ((r3 - r1) + 1.0f);
+    const float thr_lo = (float)thres - 1.0e-3f;  // f32 screen before the f64 IoU, as in the window scan
+    for (int i = l; i < n; i += 16) {
+        const int64_t k = i == 0 ? j : (int64_t)(adj[meta.x + (i - 1)] & 0x7FFF);
+        const float4 bb = boxes[(int64_t)f * B + k];
+        const float sw = (fminf(r2, bb.z) - fmaxf(r0, bb.x)) + 1.0f;
+        const float sh = (fminf(r3, bb.w) - fmaxf(r1, bb.y)) + 1.0f;
+        if (!(sw > 0.0f && sh > 0.0f)) continue;
+        const float sinter = sw * sh;
+        const float suni = (pa + box_area(bb)) - sinter;
+        if (!(sinter > thr_lo * suni)) continue;
+        const double qq[4] = {(double)bb.x, (double)bb.y, (double)bb.z, (double)bb.w};
+        if (iou_f64_pair(p, qq) > thres) {
+            const double s = (double)scores[((int64_t)f * B + k) * C + c];
+            if (argmax_better(s, k, bs, bi)) { bs = s; bi = k; }
+        }
+    }
+#pragma unroll
+    for (int d = 8; d > 0; d >>= 1) {             // arg-max over the box's 16 lanes
+        const double s2 = __shfl_xor(bs, d, 16);
+        const long long i2 = __shfl_xor((long long)bi, d, 16);
+        if (i2 >= 0 && argmax_better(s2, (int64_t)i2, bs, bi)) { bs = s2; bi = (int64_t)i2; }
+    }
+    if (l == 0) {
+        if (bi >= 0) {
+            const float4 bb = boxes[(int64_t)f * B + bi];
+            out_score[e] = bs;
+            out_box[e * 4 + 0] = bb.x; out_box[e * 4 + 1] = bb.y; out_box[e * 4 + 2] = bb.z; out_box[e * 4 + 3] = bb.w;
+        } else {   // no overlapping detection: sentinel score, box unchanged (:526-530)
+            out_score[e] = -1e5;
+            out_box[e * 4 + 0] = r0; out_box[e * 4 + 1] = r1; out_box[e * 4 + 2] = r2; out_box[e * 4 + 3] = r3;
         }
     }
 }

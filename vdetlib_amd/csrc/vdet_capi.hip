@@ -140,7 +140,7 @@ struct vdet_ctx {
                                   // 19.2 vs 19.7 ms one video at a time, 17.9 vs 16.9 with 3 in flight -- more streams than hardware queues)
     int link_maxb = 8;            // VDET_LINK_MAXB=8|16: boxes per thread and batch in the warm-up's window scans (A-B knob)
     int link_warm = -1;           // VDET_LINK_WARM=m: chains warmed per class (-1: max_tracks + 2; 0: none)
-    DevBuf linkmemo, linkstats, linkwarm, tracknode;
+    DevBuf linkmemo, linkstats, linkwarm, tracknode, rtodo;
     // which proposal every row of the last tracking call's tracks is (written by the link kernels; vdet_rescore_tracks
     // then finds a tubelet box's overlapping detections among that proposal's graph neighbours)
     struct NodeKey { const void *tracks = nullptr, *boxes = nullptr; int64_t F = 0, B = 0, C = 0; int T = 0; double nms_thres = 0; } nodekey;
@@ -829,7 +829,7 @@ int vdet_destroy(vdet_ctx *c)
     DevBuf *bufs[] = {&c->boxes, &c->scores, &c->keys, &c->excl, &c->frames, &c->groups, &c->tiles, &c->bits,
                       &c->rowz, &c->rowmeta, &c->groupz, &c->adj, &c->comp, &c->origidx, &c->out64,
                       &c->trk_frames, &c->trk_boxes, &c->b1, &c->b2, &c->iou_out, &c->order, &c->ncand, &c->keepidx,
-                      &c->keepcnt, &c->gflags, &c->pairs, &c->tkeys, &c->tstate, &c->visited, &c->heads, &c->xkeys, &c->xord, &c->xncand, &c->linkmemo, &c->linkstats, &c->linkwarm, &c->tracknode,
+                      &c->keepcnt, &c->gflags, &c->pairs, &c->tkeys, &c->tstate, &c->visited, &c->heads, &c->xkeys, &c->xord, &c->xncand, &c->linkmemo, &c->linkstats, &c->linkwarm, &c->tracknode, &c->rtodo,
                       &c->xbox, &c->xcum, &c->xinfo};
     for (DevBuf *b : bufs) b->release();
     for (DevBuf &b : c->tmp) b.release();
@@ -1408,11 +1408,29 @@ int vdet_rescore_tracks(vdet_ctx *c, const float *d_tracks, const int32_t *d_ntr
                              c->prep.F == F && c->prep.B == B && overlap_thres - c->nodekey.nms_thres > 0.05 &&
                              c->nodekey.nms_thres > 0.0 && overlap_thres < 1.0;
         const double min_self = use_adj ? 1.0 - (overlap_thres - c->nodekey.nms_thres) + 0.02 : 2.0;
-        hipLaunchKernelGGL(rescore_spatial_kernel, dim3((unsigned)((nb + 3) / 4)), dim3(256), 0, c->stream, d_tracks, d_ntracks,
-                           reinterpret_cast<const float4 *>(d_boxes), d_scores, (int)F, (int)B, (int)C, max_tracks,
-                           overlap_thres, d_det_score, d_boxes_out, ix, flags,
-                           use_adj ? c->tracknode.as<int32_t>() : (const int32_t *)nullptr, c->rowmeta.as<uint2>(),
-                           c->adj.as<uint16_t>(), min_self);
+        const int32_t *todo = nullptr;
+        const unsigned int *todo_cnt = nullptr;
+        unsigned scan_grid = (unsigned)((nb + 3) / 4);
+        if (use_adj) {
+            HIPCHK(c, c->rtodo.reserve((size_t)nb * 4 + 16));
+            unsigned int *cnt = reinterpret_cast<unsigned int *>(c->rtodo.as<char>() + (size_t)nb * 4);
+            HIPCHK(c, hipMemsetAsync(cnt, 0, 4, c->stream));
+            hipLaunchKernelGGL(rescore_adj_kernel, dim3((unsigned)((nb + 15) / 16)), dim3(256), 0, c->stream, d_tracks, d_ntracks,
+                               reinterpret_cast<const float4 *>(d_boxes), d_scores, (int)F, (int)B, (int)C, max_tracks,
+                               overlap_thres, d_det_score, d_boxes_out, flags, c->tracknode.as<int32_t>(), c->rowmeta.as<uint2>(),
+                               c->adj.as<uint16_t>(), min_self, c->rtodo.as<int32_t>(), cnt);
+            todo = c->rtodo.as<int32_t>();
+            todo_cnt = cnt;
+            scan_grid = (unsigned)std::min<int64_t>((nb + 3) / 4, 8 * c->n_cu);
+        }
+        if (todo)
+            hipLaunchKernelGGL(rescore_spatial_kernel<true>, dim3(scan_grid), dim3(256), 0, c->stream, d_tracks, d_ntracks,
+                               reinterpret_cast<const float4 *>(d_boxes), d_scores, (int)F, (int)B, (int)C, max_tracks,
+                               overlap_thres, d_det_score, d_boxes_out, ix, flags, todo, todo_cnt);
+        else
+            hipLaunchKernelGGL(rescore_spatial_kernel<false>, dim3(scan_grid), dim3(256), 0, c->stream, d_tracks, d_ntracks,
+                               reinterpret_cast<const float4 *>(d_boxes), d_scores, (int)F, (int)B, (int)C, max_tracks,
+                               overlap_thres, d_det_score, d_boxes_out, ix, flags, todo, todo_cnt);
     }
     {
         StageTimer tm(c, ST_RSERIES);
