@@ -50,8 +50,8 @@ def synth_video_cuda(torch, seed, F, B, C, device, kind="rand"):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=12)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--frames", type=int, default=300)
     ap.add_argument("--boxes", type=int, default=10000)
     ap.add_argument("--classes", type=int, default=200)
@@ -184,21 +184,24 @@ def main():
         torch.cuda.synchronize()
 
     def warm():
+        """Untimed steps.  Returns True when an asynchronous graph build outgrew the scratch sized by the first video
+        (vdet_sync: VDET_EAGAIN, the scratch has been enlarged) -- on ANY rank, so that all ranks repeat together."""
         for _ in range(max(args.warmup, nstreams)):
             step()
-        fence()
-        for cx in ctxs:
-            cx.sync()
-        fence()
-
-    try:
-        warm()
-    except _lib.RetryError:      # an asynchronous graph build outgrew the scratch sized by the first video: enlarged, again
+        again = 0
         for cx in ctxs:
             try:
                 cx.sync()
             except _lib.RetryError:
-                pass
+                again = 1
+        if world > 1:
+            flag = torch.tensor([again], dtype=torch.int32, device="cpu" if one_gpu else dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            again = int(flag.item())
+        fence()
+        return bool(again)
+
+    if warm():
         warm()
     t0 = time.perf_counter()
     for _ in range(args.steps):
