@@ -570,6 +570,10 @@ __global__ __launch_bounds__(256) void iou_bits_sym_kernel(const float4 *__restr
 // one coalesced copy; a slab that does not fit takes the slow direct path (a dependent index load per edge), so the
 // stage is sized for ~2x the graph degree of 10 000 random boxes (92) while leaving room for 4 blocks per CU.
 constexpr int kAdjRows = 128;
+#ifndef VDET_ADJ_BATCH
+#define VDET_ADJ_BATCH 16
+#endif
+constexpr int kAdjBatch = VDET_ADJ_BATCH;   // bit-matrix words loaded per memory round trip (a row's window is ~42 words)
 constexpr int kAdjStage = 16384;     // u16 entries staged in LDS per block (32 KB)
 
 __global__ __launch_bounds__(kAdjRows) void adj_build_kernel(const float4 *__restrict__ boxes,
@@ -664,12 +668,12 @@ __global__ __launch_bounds__(kAdjRows) void adj_build_kernel(const float4 *__res
         uint32_t q = lofs;
         // words in batches of 8, all loads issued before the serial bit loops (inside the loop each
         // load would be waited for on its own)
-        for (int wb = w0; wb < w1; wb += 8) {
-            uint64_t mm[8];
+        for (int wb = w0; wb < w1; wb += kAdjBatch) {
+            uint64_t mm[kAdjBatch];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) mm[j] = (wb + j < w1) ? col[(int64_t)(wb + j) * B] : 0ull;
+            for (int j = 0; j < kAdjBatch; ++j) mm[j] = (wb + j < w1) ? col[(int64_t)(wb + j) * B] : 0ull;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < kAdjBatch; ++j) {
                 uint64_t m = mm[j];
                 const int w = wb + j;
                 while (m) {
