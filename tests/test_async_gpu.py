@@ -77,6 +77,15 @@ def test_async_pool_overflow_is_reported_not_silent():
     widx, wcnt = ops.nms_volume(t_dense, ts, 0.3)   # default context, synchronous
     assert torch.equal(cnt, wcnt) and torch.equal(idx, widx)
     cx.close()
+    # ... and an op called with sync=True repeats the enqueue by itself
+    c2 = _ctx()
+    c2.set_cache(True)
+    c2.set_async(True)
+    ops.nms_volume(t_sparse, ts, 0.3, ctx=c2)
+    c2.invalidate()
+    idx2, cnt2 = ops.nms_volume(t_dense, ts, 0.3, ctx=c2)
+    assert torch.equal(cnt2, wcnt) and torch.equal(idx2, widx)
+    c2.close()
 
 
 def test_track_volume_beyond_the_index_limit_after_a_smaller_video(oracle):

@@ -25,6 +25,22 @@ def _ctx_for(t, ctx=None):
     return ctx
 
 
+def _finish(ctx, launch, sync, reset=None):
+    """Enqueue ``launch()``; with ``sync`` wait for it -- and when an asynchronous context (``ctx.set_async``) reports
+    that a graph build outgrew its scratch (``_lib.RetryError``: the scratch has been enlarged), restore the output
+    buffers' initial state (``reset``) and enqueue once more."""
+    launch()
+    if sync:
+        try:
+            ctx.sync()
+        except _lib.RetryError:
+            ctx.invalidate()
+            if reset is not None:
+                reset()
+            launch()
+            ctx.sync()
+
+
 def _keep_buffer(shape, device, pad):
     if pad:
         return torch.full(shape, -1, dtype=torch.int32, device=device)
@@ -65,12 +81,10 @@ def nms_volume(boxes, scores, thresh=0.3, score_thresh=None, cap=None, layout="F
     ctx = _ctx_for(boxes, ctx)
     keep_idx = _keep_buffer((F, C, cap), boxes.device, pad)
     keep_cnt = torch.zeros((F, C), dtype=torch.int32, device=boxes.device)
-    ctx.check(ctx.lib.vdet_nms_volume_topk(ctx.h, boxes.data_ptr(), scores.data_ptr(), lay, F, B, C, float(thresh),
-                                           0 if score_thresh is None else 1,
-                                           0.0 if score_thresh is None else float(score_thresh), int(topk),
-                                           keep_idx.data_ptr(), keep_cnt.data_ptr(), cap))
-    if sync:
-        ctx.sync()
+    _finish(ctx, lambda: ctx.check(ctx.lib.vdet_nms_volume_topk(
+        ctx.h, boxes.data_ptr(), scores.data_ptr(), lay, F, B, C, float(thresh), 0 if score_thresh is None else 1,
+        0.0 if score_thresh is None else float(score_thresh), int(topk), keep_idx.data_ptr(), keep_cnt.data_ptr(), cap)), sync,
+        reset=(lambda: keep_idx.fill_(-1)) if pad else None)
     return keep_idx, keep_cnt
 
 
@@ -195,11 +209,10 @@ def track_volume(boxes, scores, nms_thres=0.3, thres=0.0, max_tracks=10, link_th
     tracks = torch.full((C, max_tracks, F, 5), float('nan'), dtype=torch.float32, device=boxes.device)
     anchors = torch.zeros((C, max_tracks, 3), dtype=torch.float32, device=boxes.device)
     ntracks = torch.zeros((C,), dtype=torch.int32, device=boxes.device)
-    ctx.check(ctx.lib.vdet_track_volume(ctx.h, boxes.data_ptr(), scores.data_ptr(), F, B, C, float(nms_thres),
-                                        float(thres), int(max_tracks), float(link_thres), int(max_frames),
-                                        tracks.data_ptr(), anchors.data_ptr(), ntracks.data_ptr()))
-    if sync:
-        ctx.sync()
+    _finish(ctx, lambda: ctx.check(ctx.lib.vdet_track_volume(
+        ctx.h, boxes.data_ptr(), scores.data_ptr(), F, B, C, float(nms_thres), float(thres), int(max_tracks),
+        float(link_thres), int(max_frames), tracks.data_ptr(), anchors.data_ptr(), ntracks.data_ptr())), sync,
+        reset=lambda: (tracks.fill_(float('nan')), anchors.zero_()))
     return tracks, anchors, ntracks
 
 
@@ -224,12 +237,11 @@ def nms_track_volume(boxes, scores, nms_thres=0.3, thres=0.0, max_tracks=10, lin
     tracks = torch.full((C, max_tracks, F, 5), float('nan'), dtype=torch.float32, device=boxes.device)
     anchors = torch.zeros((C, max_tracks, 3), dtype=torch.float32, device=boxes.device)
     ntracks = torch.zeros((C,), dtype=torch.int32, device=boxes.device)
-    ctx.check(ctx.lib.vdet_nms_track_volume(ctx.h, boxes.data_ptr(), scores.data_ptr(), F, B, C, float(nms_thres),
-                                            float(thres), int(max_tracks), float(link_thres), int(max_frames),
-                                            tracks.data_ptr(), anchors.data_ptr(), ntracks.data_ptr(), cap,
-                                            keep_idx.data_ptr(), keep_cnt.data_ptr()))
-    if sync:
-        ctx.sync()
+    _finish(ctx, lambda: ctx.check(ctx.lib.vdet_nms_track_volume(
+        ctx.h, boxes.data_ptr(), scores.data_ptr(), F, B, C, float(nms_thres), float(thres), int(max_tracks),
+        float(link_thres), int(max_frames), tracks.data_ptr(), anchors.data_ptr(), ntracks.data_ptr(), cap,
+        keep_idx.data_ptr(), keep_cnt.data_ptr())), sync,
+        reset=lambda: (keep_idx.fill_(-1) if pad else None, tracks.fill_(float('nan')), anchors.zero_()))
     return keep_idx, keep_cnt, tracks, anchors, ntracks
 
 
