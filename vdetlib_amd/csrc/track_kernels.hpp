@@ -537,6 +537,9 @@ __global__ __launch_bounds__(LT) void track_link_memo_kernel(const float4 *__res
                 m = __builtin_amdgcn_readfirstlane((uint32_t)m) | ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(m >> 32)) << 32);
                 have = false;
                 if (!(m & kMemoValid)) break;                              // unknown: the block scans this step
+                // warm-up with unlimited reach: a known step has an owner -- the chain that scanned it went on from
+                // there and runs (or hands over, like this one) to the end of the video -- so there is nothing left to do
+                if (WARM && reach >= F) { done = 1; break; }
                 const int bidx = (int)((m >> 32) & 0x7FFFFFFFull) - 1;
                 if (bidx < 0) { done = 1; break; }                         // known: the chain ends here
                 float4 nb = make_float4(0.f, 0.f, 0.f, 0.f);
