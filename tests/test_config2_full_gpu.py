@@ -117,3 +117,25 @@ def test_full_volume_size_independent_properties(full_run):
         if bool(has[c, t, f]):
             row = tr[c, t, f, :4]
             assert bool((torch.trunc(r['boxes'][f]) == row[None]).all(dim=1).any())
+
+
+def test_full_volume_fast_paths_equal_the_plain_ones(full_run, monkeypatch):
+    """All 200 classes x 10 tracks of the full video: the link memo + warm-up and the graph-neighbour re-scoring (the
+    benchmarked paths) against the round-1 kernels they replace (every link step scans its window, every tubelet box
+    scans its window), which the oracle tests above and the golden tests pin."""
+    import torch
+    from vdetlib_amd import ops, _lib
+    r = full_run
+    monkeypatch.setenv("VDET_LINK_MEMO", "0")
+    monkeypatch.setenv("VDET_RESCORE_ADJ", "0")
+    monkeypatch.setenv("VDET_WALK_CAREFUL", "1")
+    cx = _lib.Context(torch.cuda.current_device())
+    cx.set_cache(True)
+    keep_idx, keep_cnt, tracks, anchors, ntracks = ops.nms_track_volume(
+        r['boxes'], r['scores'], nms_thres=0.3, thres=0.9, max_tracks=10, link_thres=0.5, cap=2048, ctx=cx)
+    det, tpool, tboxes = ops.rescore_tracks(tracks, ntracks, r['boxes'], r['scores'], overlap_thres=0.7, window=3, ctx=cx)
+    for name, a, b in (("keep_cnt", keep_cnt, r['keep_cnt']), ("keep_idx", keep_idx, r['keep_idx']), ("ntracks", ntracks, r['ntracks']),
+                       ("anchors", anchors, r['anchors']), ("tracks", tracks, r['tracks']), ("det", det, r['det']),
+                       ("tpool", tpool, r['tpool']), ("tboxes", tboxes, r['tboxes'])):
+        assert torch.equal(a.nan_to_num(-7.0), b.nan_to_num(-7.0)), name
+    cx.close()
