@@ -326,10 +326,13 @@ struct TilePair {
 __device__ __forceinline__ float amax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float amin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
+// XSORTED: the caller knows bc.x >= br.x (K1s off-diagonal blocks: columns come later in the x1 order), so
+// max(br.x, bc.x) is bc.x -- one half-rate v_max_f32 less per pair
+template <bool XSORTED = false>
 __device__ __forceinline__ bool pred_regular(float4 br, float rarea, float4 bc, float carea, float t32, float t32e,
                                              bool &border)
 {
-    const float xx1 = amax(br.x, bc.x);
+    const float xx1 = XSORTED ? bc.x : amax(br.x, bc.x);
     const float yy1 = amax(br.y, bc.y);
     const float xx2 = amin(br.z, bc.z);
     const float yy2 = amin(br.w, bc.w);
@@ -500,6 +503,24 @@ __global__ __launch_bounds__(256) void iou_bits_sym_kernel(const float4 *__restr
         // (same reach test per 64 x 64 block: the columns of block q start at sbox[q*64].x, sorted)
         if (!tile_empty && rows_left > 0 && !(c > r && sbox[q * 64].x > sreach[w])) {
             bool anyb = false;
+            if (WT && c > r) {      // off-diagonal block: every column starts at or to the right of every row (x1 order)
+#pragma unroll
+                for (int kk = 0; kk < 32; ++kk) {
+                    const int k = 31 - kk;
+                    bool border;
+                    const bool p = pred_regular<true>(br, rarea, sbox[q * 64 + k], sarea[q * 64 + k], t32, t32e, border);
+                    anyb |= border;
+                    shl1_or_pred(lo, p);
+                }
+#pragma unroll
+                for (int kk = 0; kk < 32; ++kk) {
+                    const int k = 31 - kk;
+                    bool border;
+                    const bool p = pred_regular<true>(br, rarea, sbox[q * 64 + 32 + k], sarea[q * 64 + 32 + k], t32, t32e, border);
+                    anyb |= border;
+                    shl1_or_pred(hi, p);
+                }
+            } else {
 #pragma unroll
             for (int kk = 0; kk < 32; ++kk) {
                 const int k = 31 - kk;      // descending: acc = 2*acc + p (one v_addc) leaves column k in bit k
@@ -525,6 +546,7 @@ __global__ __launch_bounds__(256) void iou_bits_sym_kernel(const float4 *__restr
                     tlo = (lane == 32 + k) ? (uint32_t)b : tlo;
                     thi = (lane == 32 + k) ? (uint32_t)(b >> 32) : thi;
                 }
+            }
             }
             if (__builtin_expect(__ballot(anyb) != 0ull, 0)) {
                 // rare (~1e-6 of the pairs sit in the half-ulp band, e.g. IoU exactly 3/10):
