@@ -27,6 +27,17 @@ def nms_golden():
 
 
 @pytest.fixture(scope="session")
+def exotic_golden():
+    """{case name: keep list, or the exception class the reference raised} (make_golden.py --exotic-only)."""
+    z = np.load(os.path.join(GOLDEN, 'exotic_golden.npz'))
+    out = {}
+    for c in __import__('synth').EXOTIC_CASES:
+        raised = str(z['exotic_%s_raised' % c['name']])
+        out[c['name']] = ZeroDivisionError if raised == 'ZeroDivisionError' else z['exotic_' + c['name']].tolist()
+    return out
+
+
+@pytest.fixture(scope="session")
 def proto_golden():
     with gzip.open(os.path.join(GOLDEN, 'proto_golden.json.gz'), 'rt') as f:
         return json.load(f)

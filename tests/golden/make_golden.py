@@ -424,10 +424,34 @@ def g14_link(R):
     np.savez_compressed(os.path.join(HERE, 'link_golden.npz'), **npz)
 
 
+def g15_exotic(R):
+    """What the reference's cython_nms does with NaN / inf / zero-area inputs and odd thresholds (synth.EXOTIC_CASES):
+    the keep list, or the exception it raises."""
+    npz = {}
+    for case in synth.EXOTIC_CASES:
+        args = synth.exotic_inputs(case)
+        fn = getattr(R['nms'], case['fn'])
+        try:
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                k = np.asarray(fn(*args, case['thresh']), dtype=np.int32)
+            raised = ''
+        except ZeroDivisionError:
+            k, raised = np.zeros(0, np.int32), 'ZeroDivisionError'
+        npz['exotic_' + case['name']] = k
+        npz['exotic_' + case['name'] + '_raised'] = np.asarray(raised)
+        print('  %-22s %s' % (case['name'], raised or ('%d kept' % len(k))))
+    np.savez_compressed(os.path.join(HERE, 'exotic_golden.npz'), **npz)
+
+
 def main():
     R = load_reference()
     if '--link-only' in sys.argv:
         g14_link(R)
+        return
+    if '--exotic-only' in sys.argv:
+        g15_exotic(R)
         return
     npz, index = {}, {}
     g1_nms(R, npz, index)
@@ -442,6 +466,7 @@ def main():
     with gzip.open(os.path.join(HERE, 'proto_golden.json.gz'), 'wt') as f:
         json.dump(out, f, separators=(',', ':'), sort_keys=True)
     g14_link(R)
+    g15_exotic(R)
     for fn in sorted(os.listdir(HERE)):
         print('%8d  %s' % (os.path.getsize(os.path.join(HERE, fn)), fn))
 

@@ -293,3 +293,58 @@ def link_case_video(case):
         ranks = np.argsort(np.argsort(scores, axis=1), axis=1)
         scores = ((ranks + 0.5) / scores.shape[1]).astype(np.float32)
     return boxes, scores
+
+
+# Exotic inputs (NaN / inf coordinates and scores, zero-area boxes, odd thresholds): what the REFERENCE does with them is
+# recorded by tests/golden/make_golden.py --exotic-only into tests/golden/exotic_golden.npz.  Scores stay tie-free
+# (one NaN score at most: several would tie in the reference's unstable argsort).
+EXOTIC_CASES = [
+    dict(name='nan_x1', fn='nms', seed=1501, n=300, thresh=0.3, nan_cols=[0], nan_rows=7),
+    dict(name='nan_y2_and_score', fn='nms', seed=1502, n=257, thresh=0.5, nan_cols=[3], nan_rows=5, nan_score=True),
+    dict(name='inf_coords', fn='nms', seed=1503, n=200, thresh=0.3, inf_rows=3),
+    dict(name='randn_scores_one_nan', fn='nms', seed=1504, n=400, thresh=0.3, nan_score=True, kind='randn'),
+    dict(name='zero_area', fn='nms', seed=1505, n=120, thresh=0.3, zero_area=6),
+    dict(name='thresh_nan', fn='nms', seed=1506, n=150, thresh=float('nan')),
+    dict(name='thresh_negative', fn='nms', seed=1507, n=150, thresh=-1.0),
+    dict(name='identical_boxes', fn='nms', seed=1508, n=64, thresh=0.3, identical=True),
+    dict(name='vid_nan_frames', fn='vid_nms', seed=1509, n=500, n_frames=4, thresh=0.3, nan_frames=5),
+    dict(name='vid_nan_box', fn='vid_nms', seed=1510, n=300, n_frames=2, thresh=0.3, nan_cols=[1], nan_rows=4),
+    dict(name='tdn_nan_track', fn='track_det_nms', seed=1511, m=300, t=3, n_frames=2, thresh=0.3, nan_track=True),
+    dict(name='tdn_nan_det', fn='track_det_nms', seed=1512, m=300, t=2, n_frames=2, thresh=0.3, nan_cols=[2], nan_rows=6),
+]
+
+
+def exotic_inputs(case):
+    """(dets [, tracks]) float32 arrays of an EXOTIC_CASES entry."""
+    rng = np.random.RandomState(case['seed'])
+    if case['fn'] == 'nms':
+        d = dets5(case['seed'], case['n'], kind=case.get('kind', 'perm'))
+        off = 0
+    else:
+        n = case.get('n', case.get('m'))
+        d = dets6(case['seed'], n, case['n_frames'])
+        off = 1
+    pick = rng.permutation(len(d))
+    for c in case.get('nan_cols', []):
+        d[pick[:case['nan_rows']], c] = np.nan            # column index as given (vid / track rows: 0 = frame, 1..4 = box)
+    if case.get('nan_score'):
+        d[pick[-1], off + 4] = np.nan
+    if case.get('inf_rows'):
+        k = case['inf_rows']
+        d[pick[:k], off + 2] = np.inf
+        d[pick[k:k + 2], off + 0] = -np.inf
+    if case.get('zero_area'):
+        k = case['zero_area']
+        d[pick[:k], off + 2] = d[pick[:k], off + 0] - 1.0          # width 0 (+1 convention)
+    if case.get('identical'):
+        d[:, off:off + 4] = d[0, off:off + 4]
+    if case.get('nan_frames'):
+        d[pick[:case['nan_frames']], 0] = np.nan
+    if case['fn'] != 'track_det_nms':
+        return (d,)
+    tb = boxes_1(rng, case['t'])
+    tf = rng.randint(1, case['n_frames'] + 1, case['t']).astype(np.float32)
+    tr = np.hstack([tf[:, None], tb]).astype(np.float32).reshape(-1, 5)
+    if case.get('nan_track'):
+        tr[0, 2] = np.nan
+    return (tr, d)

@@ -76,6 +76,12 @@ def test_nms_random_vs_oracle(cnms, oracle, seed):
         assert cnms.nms(d, thresh) == oracle.nms(d, thresh), (seed, n, thresh)
 
 
+def test_exotic_inputs_golden(cnms, exotic_golden):
+    """The device path on NaN / inf / zero-area inputs and odd thresholds, against what the REFERENCE returned."""
+    from test_oracle_golden import check_exotic
+    check_exotic(cnms, exotic_golden)
+
+
 def test_nms_nan_and_inf_coordinates(cnms, oracle):
     d = synth.dets5(31337, 300, degenerate=200)
     d[5, 0] = np.nan

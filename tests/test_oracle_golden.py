@@ -56,6 +56,27 @@ def test_track_det_nms_golden(oracle, nms_golden):
         assert oracle.track_det_nms(tr, d, c['thresh']) == z['tdn_%d' % i].tolist(), c
 
 
+def check_exotic(mod, want_by_name):
+    import warnings
+    for c in synth.EXOTIC_CASES:
+        args = synth.exotic_inputs(c)
+        want = want_by_name[c['name']]
+        fn = getattr(mod, c['fn'])
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            if want is ZeroDivisionError:
+                with pytest.raises(ZeroDivisionError):
+                    fn(*args, c['thresh'])
+            else:
+                assert fn(*args, c['thresh']) == want, c['name']
+
+
+def test_exotic_inputs_golden(oracle, exotic_golden):
+    """NaN / inf coordinates, a NaN score, zero-area boxes (ZeroDivisionError), NaN and negative thresholds,
+    NaN frame ids, NaN track boxes: the oracle does what the reference did."""
+    check_exotic(oracle, exotic_golden)
+
+
 def test_iou_golden(oracle, nms_golden):
     z, index = nms_golden
     for i, c in enumerate(index['iou']):
