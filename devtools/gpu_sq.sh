@@ -1,0 +1,12 @@
+# SQ counters of the NMS + TEMP kernels only (two PMC passes); output gpurun_out/sq1.csv, sq2.csv
+R=$GRAFT_REPO_ROOT
+cd $R
+O=gpurun_out
+CMD2="python $R/bench.py --steps 1 --warmup 1 --no-cpu --streams 1 --no-link"
+cd /tmp && export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_LDS -d $R/$O/p_s -o s -- $CMD2 > $R/$O/p_s.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_WAVES -d $R/$O/p_s2 -o s -- $CMD2 > $R/$O/p_s2.log 2>&1
+cd $R
+python profiles/sq_summarize.py $O/p_s/s_results.db $O/sq1.csv > /dev/null 2>> $O/p_sum.err
+python profiles/sq_summarize.py $O/p_s2/s_results.db $O/sq2.csv > /dev/null 2>> $O/p_sum.err
+rm -rf $O/p_s $O/p_s2

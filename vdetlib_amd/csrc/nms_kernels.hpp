@@ -591,6 +591,14 @@ __global__ __launch_bounds__(256) void iou_bits_sym_kernel(const float4 *__restr
 // One block = kAdjRows rows = HALF a 256-row tile (grid = 2 * n_tiles): the rows' lists are staged in LDS and leave in
 // one coalesced copy; a slab that does not fit takes the slow direct path (a dependent index load per edge), so the
 // stage is sized for ~2x the graph degree of 10 000 random boxes (92) while leaving room for 4 blocks per CU.
+// what the packed walk needs to queue one alive candidate, in ONE 32-byte record per box (its coordinates, its list's
+// offset and length) instead of a gather per table: that walk is bound by the cache lines it requests (the L1's
+// outstanding misses and the address unit: profiles/r02_pmc_tcp.csv), not by bytes
+struct WalkMeta {
+    float4 box;
+    uint4 row;           // x: list offset in the pool (u16 units, a multiple of 8), y: its length
+};
+
 constexpr int kAdjRows = 128;
 #ifndef VDET_ADJ_BATCH
 #define VDET_ADJ_BATCH 16
@@ -608,7 +616,8 @@ __global__ __launch_bounds__(kAdjRows) void adj_build_kernel(const float4 *__res
                                                         unsigned long long *__restrict__ pool_used,
                                                         unsigned long long pool_cap, int *__restrict__ status,
                                                         const uint32_t *__restrict__ group_flags,
-                                                        const FrameIndex ix, float one_minus_t, int pool_bits)
+                                                        const FrameIndex ix, float one_minus_t, int pool_bits,
+                                                        WalkMeta *__restrict__ wmeta)
 {
     __shared__ uint32_t sscan[8];
     __shared__ unsigned long long sbase;
@@ -656,7 +665,8 @@ __global__ __launch_bounds__(kAdjRows) void adj_build_kernel(const float4 *__res
     const uint32_t tot = deg + zc;
     // every list starts at an even pool offset (slabs are sums of even sizes): the walks read two
     // u16 entries with one 4-byte load
-    const uint32_t tot_al = (tot + 1u) & ~1u;
+    // ... and is padded to a multiple of 8 entries (16 bytes): the packed walk reads it with aligned 16-byte loads
+    const uint32_t tot_al = (tot + 7u) & ~7u;
     // block inclusive scan of the 256 list sizes: a DPP scan inside each wave (row_shr 1/2/4/8, then the
     // row_bcast 15/31 carries), the four wave totals combined through LDS -- two barriers instead of the
     // sixteen of a Hillis-Steele scan over LDS
@@ -680,6 +690,7 @@ __global__ __launch_bounds__(kAdjRows) void adj_build_kernel(const float4 *__res
     if (base + tile_total > pool_cap || base + tile_total > 0xFFFFFFFFull) {
         if (tid == 0) atomicOr(status, pool_bits);
         if (v < B) row_meta[gd.box_off + vo] = make_uint2(0u, 0u);
+        if (v < B && tr && wmeta) { wmeta[gd.box_off + vo].box = make_float4(0.f, 0.f, 0.f, 0.f); wmeta[gd.box_off + vo].row = make_uint4(0u, 0u, 0u, 0u); }
         return;
     }
     const bool staged = tile_total <= (uint32_t)kAdjStage;     // block-uniform
@@ -687,6 +698,10 @@ __global__ __launch_bounds__(kAdjRows) void adj_build_kernel(const float4 *__res
     if (v < B) {
         uint32_t p = (uint32_t)base + lofs;
         row_meta[gd.box_off + vo] = make_uint2(p, tot);
+        if (tr && wmeta) {        // regular group: the packed walk's record of this box
+            wmeta[gd.box_off + vo].box = ix.xbox[gd.box_off + v];
+            wmeta[gd.box_off + vo].row = make_uint4(p, tot, 0u, 0u);
+        }
         uint32_t q = lofs;
         // words in batches of 8, all loads issued before the serial bit loops (inside the loop each
         // load would be waited for on its own)
@@ -723,7 +738,8 @@ __global__ __launch_bounds__(kAdjRows) void adj_build_kernel(const float4 *__res
         }
         // odd lists are padded to even length with a DUPLICATE of their last entry: the walks apply
         // entries in pairs (a second OR of the same bit is harmless)
-        if (tot & 1u) { if (staged) sstage[q] = sstage[q - 1]; else adj[p] = adj[p - 1]; }
+        // (the rest of the padding repeats it too: the staged copy-out below translates every entry of the slab)
+        for (uint32_t e = tot; e < tot_al && tot > 0u; ++e) { if (staged) { sstage[q] = sstage[q - 1]; ++q; } else { adj[p] = adj[p - 1]; ++p; } }
     }
     if (staged) {   // one coalesced copy of the tile's slab instead of 256 interleaved 2-byte streams
         __syncthreads();
@@ -1109,8 +1125,12 @@ struct WalkParams {
     int32_t *keep_cnt;        // [P]
     int64_t cap;
     int *status;
-    int mask_words;           // u32 words per wave
+    int mask_words;           // u32 words of one wave's dead mask
     const uint32_t *group_flags;   // kFlagRegular per group (the K1s path ran), or null
+    int wave_words;           // u32 words of LDS per wave (mask + the packed walk's ring)
+    int packed;               // regular frames take walk_list_packed
+    const WalkMeta *wmeta;    // per box: coordinates + list (adj_build_kernel), and the graph's threshold: the packed walk
+    float t32;                // tests the members of a group against each other geometrically
 };
 
 // LDS words through which the lanes of one wave talk to each other (the walks' dead masks): every
@@ -1226,11 +1246,146 @@ __device__ __forceinline__ void walk_group_regular(lds_mask_t mask, const uint16
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The PACKED walk of a regular frame's list (round 2).  The walk above spends ~50 instructions per survivor, half of
+// them scalar (one survivor at a time: broadcast its id, look at its bit, select its length, mask the lanes), and
+// the scalar unit is its bottleneck.  Here EIGHT alive candidates are handled by one pass of vector code, 8 lanes
+// each: a lane loads 16 entries (32 B) of its member's adjacency list -- once the member is known to survive -- and ORs
+// them into the dead mask.  What makes
+// that legal is that the order inside a group only matters for members that suppress EACH OTHER, and that is a
+// property of their two boxes: lane (i, j) of the 8 x 8 lane grid evaluates the exact pair predicate of members
+// i < j (the graph's own edge rule), one ballot yields the group's conflict matrix, and only if it is non-zero
+// (rare: a few % of the groups) a short scalar loop decides who survives.  Everything else is the same greedy
+// rule: a member is alive iff its bit is clear when its group starts (all earlier groups are in the mask) and no
+// earlier SURVIVING member of its group suppresses it.
+// Alive candidates are queued in a small LDS ring (with their boxes and lists: one 32-byte record per candidate, fetched
+// one chunk ahead) as the chunks of 64 candidates are filtered, so every group but the last is full; a candidate filtered "alive" while earlier ones were still queued is simply found dead when its
+// group starts.  Lists longer than 128 entries finish in a (rare) per-member loop.
+// ------------------------------------------------------------------------------------------------
+constexpr int kPackRing = 72;                  // ring slots of 32 B: {box index, list offset, length, -, x1 y1 x2 y2}
+struct __attribute__((aligned(16))) AdjVec { uint32_t v[4]; };    // 8 entries (lists are 16-byte aligned)
+typedef float lds_f4v __attribute__((ext_vector_type(4)));
+typedef volatile __attribute__((address_space(3))) lds_f4v *lds_f4_t;
+
+__device__ __forceinline__ int ring_wrap(int s) { return s >= kPackRing ? s - kPackRing : s; }
+
+__device__ __forceinline__ void walk_list_packed(const WalkParams &prm, lds_mask_t mask, const int lane, const int rb,
+                                                 const uint16_t *__restrict__ order, const int ncand,
+                                                 int32_t *__restrict__ out, const int64_t cap, int &nk_out)
+{
+    lds_mask_t ring = mask + prm.mask_words;
+    lds_f4_t ringb = (lds_f4_t)ring;                              // slot s: words 8s .. 8s+3 = meta, float4 2s+1 = box
+    const WalkMeta *__restrict__ wmeta = prm.wmeta + rb;
+    const float t32 = prm.t32;
+    const int k = lane >> 3, sub = lane & 7;
+    int qh = 0, qn = 0, nk = 0;                                   // ring head, queued candidates, survivors (wave-uniform)
+    const int last = max(ncand - 1, 0);
+    int c_cur = (int)order[(uint32_t)min(lane, last)];
+    int c_nxt = (int)order[(uint32_t)min(64 + lane, last)];
+    uint2 m_cur = make_uint2(0u, 0u);
+    float4 b_cur = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane < ncand) {                                           // chunk 0: everything is alive
+        const WalkMeta *wm = wmeta + (uint32_t)c_cur;
+        b_cur = wm->box; const uint4 rw = wm->row; m_cur = make_uint2(rw.x, rw.y);
+    }
+    for (int q0 = 0; q0 < ncand; q0 += 64) {
+        const int c = c_cur;
+        const int c_nn = (int)order[(uint32_t)min(q0 + 128 + lane, last)];
+        uint2 m_nxt = make_uint2(0u, 0u);
+        float4 b_nxt = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((q0 + 64 + lane) < ncand && !((mask[c_nxt >> 5] >> (c_nxt & 31)) & 1u)) {
+            const WalkMeta *wm = wmeta + (uint32_t)c_nxt;
+            b_nxt = wm->box; const uint4 rw = wm->row; m_nxt = make_uint2(rw.x, rw.y);
+        }
+        const bool alive = (q0 + lane) < ncand && !((mask[c >> 5] >> (c & 31)) & 1u);
+        const unsigned long long am = __ballot(alive);
+        if (alive) {
+            const int s = ring_wrap(qh + qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u)));
+            ring[8 * s] = (uint32_t)c;
+            ring[8 * s + 1] = m_cur.x;
+            ring[8 * s + 2] = m_cur.y;
+            lds_f4v bv; bv.x = b_cur.x; bv.y = b_cur.y; bv.z = b_cur.z; bv.w = b_cur.w;
+            ringb[2 * s + 1] = bv;
+        }
+        qn += __popcll(am);
+        const bool flush = q0 + 64 >= ncand;
+        while (qn >= 8 || (flush && qn > 0)) {
+            const int ng = min(8, qn);
+            const int s = ring_wrap(qh + k);
+            const bool vk = k < ng;
+            const int cm = vk ? (int)ring[8 * s] : 0;
+            // who survives: alive when the group starts, and not suppressed by an earlier surviving member (boxes from the ring)
+            const lds_f4v vi = ringb[2 * s + 1], vj = ringb[2 * ring_wrap(qh + sub) + 1];
+            const float4 bi = make_float4(vi.x, vi.y, vi.z, vi.w), bj = make_float4(vj.x, vj.y, vj.z, vj.w);
+            const bool live = vk && !((mask[cm >> 5] >> (cm & 31)) & 1u);
+            const unsigned long long lm = __ballot(live);
+            const bool hit = (pair_pred(bi, box_area(bi), bj, box_area(bj), t32) & 1u) != 0u;
+            const unsigned long long cmask = __ballot(hit && k < sub && sub < ng && live && ((lm >> (8 * sub)) & 1ull));
+            unsigned long long surv_s = lm & 0x0101010101010101ull;      // bit 8k <=> member k survives
+            if (cmask) {
+                unsigned long long sv = 0ull;
+                for (int j = 0; j < 8; ++j) {
+                    const unsigned long long col = (cmask >> j) & 0x0101010101010101ull;   // bit 8i <=> i suppresses j
+                    if (((lm >> (8 * j)) & 1ull) && !(col & sv)) sv |= 1ull << (8 * j);
+                }
+                surv_s = sv;
+            }
+            const bool surv = (surv_s >> (lane & 56)) & 1ull;
+            if (surv_s) {
+                const int pos = nk + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(surv_s >> 32),
+                                                                   __builtin_amdgcn_mbcnt_lo((uint32_t)surv_s, 0u));
+                if (surv && sub == 0 && (int64_t)pos < cap) out[(uint32_t)pos] = cm;
+                nk += __popcll(surv_s);
+                // the survivors' lists: lane `sub` owns entries [8 sub, 8 sub + 8) and [64 + 8 sub, 64 + 8 sub + 8) -- 8 lanes
+                // read 128 contiguous, aligned bytes per load; a lane whose share lies past the list's end re-reads the
+                // list's first 16 bytes (no extra cache line, no divergent load); only entries that exist go to the LDS
+                const uint32_t off = surv ? ring[8 * s + 1] : 0u;
+                const int deg = surv ? (int)ring[8 * s + 2] : 0;
+                const AdjVec *pa = reinterpret_cast<const AdjVec *>(prm.adj + off);
+                const AdjVec a0 = pa[8 * sub < deg ? sub : 0];
+                const AdjVec a1 = pa[64 + 8 * sub < deg ? 8 + sub : 0];
+                const int n0 = min(max(deg - 8 * sub, 0), 8), n1 = min(max(deg - 64 - 8 * sub, 0), 8);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const uint32_t d = a0.v[t];
+                    if (2 * t < n0) lds_or(mask, (int)((d & 0xFFFFu) >> 5), 1u << (d & 31u));
+                    if (2 * t + 1 < n0) lds_or(mask, (int)(d >> 21), 1u << ((d >> 16) & 31u));
+                }
+                if (__ballot(n1 > 0) != 0ull) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const uint32_t d = a1.v[t];
+                        if (2 * t < n1) lds_or(mask, (int)((d & 0xFFFFu) >> 5), 1u << (d & 31u));
+                        if (2 * t + 1 < n1) lds_or(mask, (int)(d >> 21), 1u << ((d >> 16) & 31u));
+                    }
+                    unsigned long long lg = __ballot(sub == 0 && deg > 128);
+                    while (lg) {                                             // rare: long lists
+                        const int l = __ffsll((unsigned long long)lg) - 1;
+                        lg &= lg - 1;
+                        const uint32_t o = __builtin_amdgcn_readlane(off, l);
+                        const int dl = __builtin_amdgcn_readlane(deg, l);
+                        for (int e0 = 128; e0 < dl; e0 += 64) {
+                            const uint32_t e = prm.adj[o + min(e0 + lane, dl - 1)];
+                            if (e0 + lane < dl) lds_or(mask, (int)(e >> 5), 1u << (e & 31u));
+                        }
+                    }
+                }
+            }
+            qh = ring_wrap(qh + ng);
+            qn -= ng;
+        }
+        c_cur = c_nxt; c_nxt = c_nn; m_cur = m_nxt; b_cur = b_nxt;
+    }
+    nk_out = nk;
+}
+
 __global__ __launch_bounds__(256) void walk_kernel(const WalkParams prm)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    lds_mask_t mask = lds_mask_ptr(smem, w * prm.mask_words);
+    // (the wave index through readfirstlane: hipcc then knows that the problem, its list / frame pointers and every
+    //  address base below are wave-uniform -- scalar registers and saddr loads instead of 64-bit vector address math)
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    lds_mask_t mask = lds_mask_ptr(smem, w * prm.wave_words);
     const int nwaves_total = gridDim.x * 4;
     // wave-granular XCD mapping: block b -> XCD b % 8; consecutive problems share a frame
     const int per = nwaves_total >> 3;
@@ -1257,6 +1412,12 @@ __global__ __launch_bounds__(256) void walk_kernel(const WalkParams prm)
 
     int nk = 0;
     int bad = 0;
+    if (regular && prm.packed && N >= 2) {     // (singleton groups have no graph: adj_build_kernel never saw them)
+        walk_list_packed(prm, mask, lane, rb, order, ncand, out, cap, nk);
+        if (lane == 0) prm.keep_cnt[p] = nk;
+        if ((int64_t)nk > cap && lane == 0) atomicOr(prm.status, kStCap);
+        return;
+    }
     const uint32_t *adjw = reinterpret_cast<const uint32_t *>(prm.adj);   // adjacency lists start at even offsets
     // Two-deep software pipeline over the chunks of 64 candidates: the ids of chunk i+2 (one
     // coalesced load) and the row meta of chunk i+1 (an 8-B gather, issued only for the lanes that

@@ -90,7 +90,7 @@ struct vdet_ctx {
     int n_cu = 256;
     // scratch
     DevBuf boxes, scores, keys, excl, frames, groups, tiles, bits, rowz, rowmeta, groupz, adj, comp, origidx,
-        out64, trk_frames, trk_boxes, b1, b2, iou_out, order, ncand, keepidx, keepcnt, gflags, pairs, tkeys, tstate, visited, heads, xkeys, xord, xncand, xbox, xcum, xinfo, tmp[8];
+        out64, trk_frames, trk_boxes, b1, b2, iou_out, order, ncand, keepidx, keepcnt, gflags, pairs, tkeys, tstate, visited, heads, xkeys, xord, wmeta, xncand, xbox, xcum, xinfo, tmp[8];
     // timing
     bool timing = false;
     bool timing_accumulate = false;   // vdet_set_timing(ctx, 2): keep events across calls until read
@@ -131,6 +131,9 @@ struct vdet_ctx {
     bool force_general = false;   // VDET_FORCE_GENERAL=1: disable the symmetric fast kernel (tests)
     bool topk_attr_set = false;
     int link_threads = 256;       // VDET_LINK_THREADS=64|128|256: threads per link chain (A-B knob)
+    bool walk_packed = true;      // VDET_WALK_PACKED=0: regular frames walk one survivor at a time (A-B knob / tests)
+    float gt32 = 0.f;             // threshold of the last graph build (the packed walk's in-group test)
+    bool wmeta_built = false;     // ... which also wrote the packed walk's records (WalkMeta) of the regular frames
     bool walk_careful = false;    // VDET_WALK_CAREFUL=1: per-survivor bookkeeping also on regular frames (A-B knob / tests)
     bool link_memo = true;        // VDET_LINK_MEMO=0: every link step scans (A-B knob / tests)
     // second stream of the context: the memo warm-up runs on it, next to the NMS walk of the same video
@@ -333,6 +336,8 @@ int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32, doub
     const size_t G = pl.groups.size();
     c->host_groups = &pl.groups;
     c->sym_built = false;
+    c->gt32 = t32;
+    c->wmeta_built = false;
     HIPCHK(c, c->groups.reserve(G * sizeof(GroupDesc)));
     HIPCHK(c, c->tiles.reserve(std::max<size_t>(pl.tiles.size(), 1) * sizeof(TileDesc)));
     HIPCHK(c, c->bits.reserve(std::max<size_t>(pl.bits_words_max, 1) * 8));
@@ -373,12 +378,14 @@ int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32, doub
         HIPCHK(c, hipMemsetAsync(c->groupz.p, 0, G * 4, c->stream));
         if (async) HIPCHK(c, hipMemsetAsync((char *)c->d_cnt + kPerBuildOff, 0, sizeof(Counters) - kPerBuildOff, c->stream));
         else HIPCHK(c, hipMemsetAsync(c->d_cnt, 0, sizeof(Counters), c->stream));
-        const unsigned long long pool_cap = c->adj.cap / 2;
+        const unsigned long long pool_cap = (c->adj.cap - 2048) / 2;     // (the packed walk reads up to 256 B past a list)
         // fast symmetric kernel for regular frames needs 0 < t32 < inf (exact divide-free test)
         // ... and the x1 index, whose sort must fit the LDS (8 B per box + tables)
         const bool use_sym = t32 > 1e-30f && t32 < INFINITY && !c->force_general &&
                              (size_t)8 * pl.nmax + 24 * 1024 <= c->max_lds;
         c->sym_built = use_sym;
+        c->wmeta_built = use_sym && c->walk_packed;
+        if (c->wmeta_built) HIPCHK(c, c->wmeta.reserve((size_t)pl.ntot * sizeof(WalkMeta)));
         if (use_sym) {
             {
                 StageTimer tm(c, ST_OTHER);
@@ -432,7 +439,8 @@ int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32, doub
                                    c->adj.as<uint16_t>(), &c->d_cnt->pool_used, pool_cap,
                                    &c->d_cnt->status, use_sym ? c->gflags.as<uint32_t>() : (const uint32_t *)nullptr,
                                    use_sym ? frame_index_of(c) : FrameIndex{nullptr, nullptr, nullptr, nullptr}, one_minus_t,
-                                   async ? (kStPool | kStPoolAsync) : kStPool);
+                                   async ? (kStPool | kStPoolAsync) : kStPool,
+                                   c->wmeta_built ? c->wmeta.as<WalkMeta>() : (WalkMeta *)nullptr);
             }
         }
         HIPCHK(c, hipGetLastError());
@@ -592,10 +600,14 @@ int launch_sort_walk(vdet_ctx *c, const SortWalkArgs &a, int nmax, int64_t order
     wp.status = &c->d_cnt->status;
     wp.mask_words = (int)(r16((size_t)4 * ((std::max(nmax, 1) + 31) / 32)) / 4);
     wp.group_flags = (c->sym_built && !c->walk_careful) ? c->gflags.as<uint32_t>() : nullptr;   // frames whose graph is symmetric
+    wp.packed = (wp.group_flags && c->walk_packed && c->wmeta_built) ? 1 : 0;    // eight candidates per pass (walk_list_packed)
+    wp.wave_words = wp.mask_words + (wp.packed ? 8 * kPackRing : 0);             // + the ring of alive candidates
+    wp.wmeta = c->wmeta.as<WalkMeta>();
+    wp.t32 = c->gt32;
     {
         const int nblk = (((a.P + 3) / 4) + 7) & ~7;
         StageTimer tm(c, ST_WALK);
-        hipLaunchKernelGGL(walk_kernel, dim3(nblk), dim3(256), (size_t)wp.mask_words * 4 * 4, c->stream, wp);
+        hipLaunchKernelGGL(walk_kernel, dim3(nblk), dim3(256), (size_t)wp.wave_words * 4 * 4, c->stream, wp);
     }
     HIPCHK(c, hipGetLastError());
     return VDET_OK;
@@ -753,6 +765,7 @@ int vdet_create(vdet_ctx **out, int device)
     if (const char *e = getenv("VDET_NO_INDEX")) c->no_index = atoi(e) != 0;
     if (const char *e = getenv("VDET_NO_LAZY")) c->no_lazy = atoi(e) != 0;
     if (const char *e = getenv("VDET_WALK_CAREFUL")) c->walk_careful = atoi(e) != 0;
+    if (const char *e = getenv("VDET_WALK_PACKED")) c->walk_packed = atoi(e) != 0;
     if (const char *e = getenv("VDET_RESCORE_ADJ")) c->rescore_adj = atoi(e) != 0;
     if (const char *e = getenv("VDET_LINK_MEMO")) c->link_memo = atoi(e) != 0;
     if (const char *e = getenv("VDET_LINK_WARM")) c->link_warm = atoi(e);
@@ -830,7 +843,7 @@ int vdet_destroy(vdet_ctx *c)
                       &c->rowz, &c->rowmeta, &c->groupz, &c->adj, &c->comp, &c->origidx, &c->out64,
                       &c->trk_frames, &c->trk_boxes, &c->b1, &c->b2, &c->iou_out, &c->order, &c->ncand, &c->keepidx,
                       &c->keepcnt, &c->gflags, &c->pairs, &c->tkeys, &c->tstate, &c->visited, &c->heads, &c->xkeys, &c->xord, &c->xncand, &c->linkmemo, &c->linkstats, &c->linkwarm, &c->tracknode, &c->rtodo,
-                      &c->xbox, &c->xcum, &c->xinfo};
+                      &c->xbox, &c->xcum, &c->xinfo, &c->wmeta};
     for (DevBuf *b : bufs) b->release();
     for (DevBuf &b : c->tmp) b.release();
     for (auto &e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
