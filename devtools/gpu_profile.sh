@@ -12,13 +12,15 @@ timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/$O/p_f -o f -- $CMD2
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/$O/p_w -o w -- $CMD2 > $R/$O/p_w.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_LDS -d $R/$O/p_s -o s -- $CMD2 > $R/$O/p_s.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_WAVES -d $R/$O/p_s2 -o s -- $CMD2 > $R/$O/p_s2.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum TA_BUSY_avr TCP_TCC_READ_REQ_LATENCY_sum TA_FLAT_READ_WAVEFRONTS_sum -d $R/$O/p_t -o s -- $CMD2 > $R/$O/p_t.log 2>&1
 timeout 600 rocprofv3 --hip-runtime-trace --stats -d $R/$O/p_h -o h -- python $R/bench.py --steps 8 --warmup 4 --no-cpu > $R/$O/p_h.log 2>&1
 cd $R
 python profiles/summarize.py $O/p_k/k_results.db $O/r02_kernel_stats.csv "python bench.py --steps 3 --warmup 2 --no-cpu --streams 1 (one video at a time; 5 videos + 3 timing repetitions)" > /dev/null 2>> $O/p_sum.err
 python profiles/pmc_summarize.py $O/p_f/f_results.db $O/p_w/w_results.db $O/r02_pmc_hbm_traffic.csv $O/r02_pmc_traffic.json > /dev/null 2>> $O/p_sum.err
 python profiles/sq_summarize.py $O/p_s/s_results.db $O/r02_pmc_sq.csv > /dev/null 2>> $O/p_sum.err
 python profiles/sq_summarize.py $O/p_s2/s_results.db $O/r02_pmc_sq2.csv > /dev/null 2>> $O/p_sum.err
+python profiles/sq_summarize.py $O/p_t/s_results.db $O/r02_pmc_tcp.csv > /dev/null 2>> $O/p_sum.err
 python profiles/dispatch_times.py $O/p_k/k_results.db track_link 24 > $O/r02_link_dispatch_us.txt 2>> $O/p_sum.err
 python profiles/hip_api_summarize.py $O/p_h/h_results.db $O/r02_hip_api_stats.csv >> $O/p_sum.err 2>&1
 ls -la $O/p_h >> $O/p_sum.err 2>&1
-rm -rf $O/p_k $O/p_f $O/p_w $O/p_s $O/p_s2 $O/p_h
+rm -rf $O/p_k $O/p_f $O/p_w $O/p_s $O/p_s2 $O/p_h $O/p_t

@@ -20,12 +20,15 @@
 //                        boxes (the "j" boxes) broadcast from LDS; 64 predicates packed per u64, written
 //                        transposed ([word][row]) so the stores and the later loads are coalesced.
 //   K2 adj_build_kernel  bit rows -> compact u16 adjacency lists = OUT-lists "whom do I suppress"
-//                        (CSR slabs allocated with one atomicAdd per 256-row tile).
+//                        (CSR slabs allocated with one atomicAdd per 128-row block; lists 16-byte aligned)
+//                        + one 32-byte record {box, list} per box of a regular frame for the packed walk.
 //   K3 sort_kernel       one workgroup per (frame, class): stable LSD radix argsort of the scores,
 //                        entirely in LDS (keys stay put, a u16 index list is permuted).
 //   K4 walk_kernel       one WAVE per (frame, class): visits the candidates in descending order;
 //                        a survivor ORs its adjacency list into a "dead" bitmask held in LDS.
 //                        32 independent walks per CU hide the L2 latency of the list reads.
+//                        Regular frames: eight candidates per pass (walk_list_packed), their mutual
+//                        suppression decided geometrically by an 8 x 8 lane grid.
 //
 //   The O(B^2) float work is shared by all C classes; per class only integer work remains.
 //   (A first version resolved each class as a parallel greedy MIS without sorting -- correct, but
