@@ -154,6 +154,32 @@ __global__ __launch_bounds__(256) void temporal_both_vec4_kernel(const float4 *_
 // go through a double-buffered LDS tile [C][TB] (one barrier per frame; columns XOR-swizzled against bank
 // conflicts) and leave as 16-byte stores, TB*4 contiguous bytes per class row.
 // ------------------------------------------------------------------------------------------------
+// the outputs are written once and read by other kernels much later: streaming (non-temporal) stores
+// (measured: pass 1.9-2.0 -> 1.7-1.9 ms one video at a time; 0 = plain stores, 1 = pooled / convolved outputs only)
+#ifndef VDET_VPASS_NT
+#define VDET_VPASS_NT 2
+#endif
+typedef float vp_f4 __attribute__((ext_vector_type(4)));
+typedef uint32_t vp_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void vp_store(float4 *p, const float4 v)
+{
+#if VDET_VPASS_NT
+    vp_f4 t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+    __builtin_nontemporal_store(t, reinterpret_cast<vp_f4 *>(p));
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ void vp_store_u4(uint4 *p, const uint4 v)
+{
+#if VDET_VPASS_NT == 2
+    vp_u4 t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+    __builtin_nontemporal_store(t, reinterpret_cast<vp_u4 *>(p));
+#else
+    *p = v;
+#endif
+}
+
 template <int W, int ITEMS, bool CONV, int NT>
 __global__ __launch_bounds__(NT) void volume_pass_kernel(const float4 *__restrict__ in, float4 *__restrict__ out_max,
                                                          float4 *__restrict__ out_conv, uint32_t *__restrict__ keys,
@@ -237,7 +263,7 @@ __global__ __launch_bounds__(NT) void volume_pass_kernel(const float4 *__restric
             a.init(ok[0] ? win[i][0] : pm);
 #pragma unroll
             for (int k = 1; k < W; ++k) a.add(ok[k] ? win[i][k] : pm);
-            om[goff[i]] = a.get();
+            vp_store(om + goff[i], a.get());
             if (CONV) {
                 float4 r = splat4(bias);
 #pragma unroll
@@ -247,7 +273,7 @@ __global__ __launch_bounds__(NT) void volume_pass_kernel(const float4 *__restric
                     r.x = r.x + t * v.x; r.y = r.y + t * v.y;
                     r.z = r.z + t * v.z; r.w = r.w + t * v.w;
                 }
-                oc[goff[i]] = r;
+                vp_store(oc + goff[i], r);
             }
             const float4 s = win[i][H];
             uint4 k4 = make_uint4(score_key(s.x), score_key(s.y), score_key(s.z), score_key(s.w));
@@ -271,7 +297,11 @@ __global__ __launch_bounds__(NT) void volume_pass_kernel(const float4 *__restric
                 const uint4 k4 = *reinterpret_cast<const uint4 *>(tb + cc * TB + ((4 * q) ^ (((cc >> 2) & qmask) << 2)));
                 const int o = cc * B + 4 * q;
                 if (vec_ok && 4 * q + 3 < rows) {
-                    *reinterpret_cast<uint4 *>(kf + o) = k4;
+#if VDET_VPASS_NT == 2
+                    vp_store_u4(reinterpret_cast<uint4 *>(kf + o), k4);
+#else
+                    *reinterpret_cast<uint4 *>(kf + o) = k4;       // (the sort reads the keys next: keep them cached)
+#endif
                 } else {
                     kf[o] = k4.x;
                     if (4 * q + 1 < rows) kf[o + 1] = k4.y;
