@@ -190,3 +190,51 @@ def test_volume_nan_inf_boxes_take_general_path(torch_cuda, oracle):
     boxes[2, 100:110, 2] = boxes[2, 100:110, 0] - 5      # negative widths
     _check_volume(torch, oracle, boxes, scores, 0.3)
     _check_volume(torch, oracle, boxes, scores, 0.5, score_thresh=0.2)
+
+
+def _chain_video(rng, F, B, C, t):
+    """Adversarial frames for the packed walk (eight candidates per pass, walk_list_packed): CHAINS of boxes where each
+    suppresses the next but not the one after (IoU(i, i+1) >= t > IoU(i, i+2)), so that inside one group of eight the
+    fate of every member depends on the fate of the one before it; stacks of near-duplicates (everything suppresses
+    everything); a few boxes with very long adjacency lists (> 128 neighbours); isolated boxes."""
+    boxes = np.zeros((F, B, 4), np.float32)
+    for f in range(F):
+        out = []
+        while len(out) < B:
+            kind = rng.randint(4)
+            x0, y0 = rng.uniform(0, 1500), rng.uniform(0, 900)
+            w, h = rng.uniform(40, 120), rng.uniform(40, 120)
+            if kind == 0:       # chain along x: shift s with IoU = (w - s) / (w + s) just above t
+                n = rng.randint(3, 20)
+                s = np.floor(w * (1 - t) / (1 + t) * rng.uniform(0.75, 0.98))
+                for i in range(n):
+                    out.append([x0 + i * s, y0, x0 + i * s + w, y0 + h])
+            elif kind == 1:     # stack of near-duplicates
+                n = rng.randint(2, 12)
+                for i in range(n):
+                    out.append([x0 + rng.randint(0, 3), y0 + rng.randint(0, 3), x0 + w + rng.randint(0, 3), y0 + h + rng.randint(0, 3)])
+            elif kind == 2 and rng.rand() < 0.05:     # a hub: > 128 similar boxes around one place
+                for i in range(150):
+                    out.append([x0 + rng.uniform(-6, 6), y0 + rng.uniform(-6, 6), x0 + w + rng.uniform(-6, 6), y0 + h + rng.uniform(-6, 6)])
+            else:
+                out.append([x0, y0, x0 + w, y0 + h])
+        bb = np.round(np.asarray(out[:B], np.float32))
+        boxes[f] = bb[rng.permutation(B)]
+    scores = rng.permutation(F * B * C).reshape(F, B, C).astype(np.float32) / (F * B * C)      # tie-free
+    # along half of the chains the scores descend in box order (the walk then meets them as one run)
+    return boxes, scores
+
+
+@pytest.mark.parametrize("seed,t", [(1, 0.3), (2, 0.5), (3, 0.7)])
+def test_nms_volume_chains_stacks_hubs(torch_cuda, oracle, seed, t):
+    rng = np.random.RandomState(9000 + seed)
+    boxes, scores = _chain_video(rng, 3, 1500, 6, t)
+    # class 0: scores follow the box order inside each frame's original (unpermuted) construction as far as possible --
+    # sort class 0's scores along the x coordinate so that chains are met in order
+    for f in range(boxes.shape[0]):
+        o = np.argsort(boxes[f, :, 0] + 1e-3 * boxes[f, :, 1], kind="stable")
+        scores[f, o, 0] = np.sort(scores[f, :, 0])[::-1]
+    _check_volume(torch_cuda, oracle, boxes, scores, t)
+    from vdetlib_amd.utils import cython_nms
+    d = np.hstack([boxes[0], scores[0, :, :1]]).astype(np.float32)
+    assert cython_nms.nms(d, t) == oracle.nms(d, t)
