@@ -454,23 +454,62 @@ __device__ __forceinline__ void shl1_or_pred(uint32_t &acc, bool p)
 // translates back to box indices.  A tile pair whose columns all start to the right of every row's
 // IoU >= t reach (x1 + (1-t) * w, the same necessary condition as xwindow) is all-zero and is
 // written as such without evaluating a single pair: ~2.8x fewer pair tests at B = 10k.
+// Per word-row (64 consecutive ranks) of every regular frame: how far to the right a partner of ANY of its rows can
+// start (reach) and where its first box starts (first).  Block (r, c), c > r, of the predicate matrix can hold a set bit
+// only if first[c] <= reach[r]; K1s evaluates -- and WRITES -- only such blocks, and K2 reads a word (c, row of r) only
+// if the same test, on the same table, says it was written (for c < r it came from block (c, r)'s transposed store).
+// The all-zero blocks used to be written out as zeros: 64 % of the 4.5 GB bit matrix of a config-2 video.
+// Table slot of word-row r of group g: (box_off >> 6) + g + r   (disjoint: every group adds at most one partial row).
+__device__ __forceinline__ int reach_slot(const GroupDesc &gd, int g) { return (gd.box_off >> 6) + g; }
+
+__global__ __launch_bounds__(256) void reach_table_kernel(const float4 *__restrict__ xbox, const GroupDesc *__restrict__ groups,
+                                                          const uint32_t *__restrict__ group_flags, float one_minus_t,
+                                                          float2 *__restrict__ table)
+{
+    const int g = blockIdx.x;
+    if (!(group_flags[g] & kFlagRegular)) return;
+    const GroupDesc gd = groups[g];
+    const int B = gd.nbox, W = (B + 63) >> 6;
+    const int lane = threadIdx.x & 63;
+    for (int r = threadIdx.x >> 6; r < W; r += 4) {
+        const int v = r * 64 + lane;
+        float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (v < B) b = xbox[gd.box_off + v];
+        // (1 px + 0.1 % margin, cf. xwindow)
+        float reach = v < B ? b.x + one_minus_t * ((b.z - b.x) + 1.0f) * 1.001f + 1.0f : -3.0e38f;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) reach = fmaxf(reach, __shfl_xor(reach, d, 64));
+        const float first = __shfl(b.x, 0, 64);
+        if (lane == 0) table[reach_slot(gd, g) + r] = make_float2(reach, first);
+    }
+}
+
 template <bool WT>
 __global__ __launch_bounds__(256) void iou_bits_sym_kernel(const float4 *__restrict__ xbox,
                                                            const GroupDesc *__restrict__ groups,
                                                            const uint32_t *__restrict__ group_flags,
                                                            const TilePair *__restrict__ pairs, float t32, float one_minus_t,
-                                                           uint64_t *__restrict__ bits, uint32_t *__restrict__ row_deg)
+                                                           uint64_t *__restrict__ bits, uint32_t *__restrict__ row_deg,
+                                                           const float2 *__restrict__ reach_table)
 {
     __shared__ float4 sbox[256];
     __shared__ float sarea[256];
-    __shared__ float sreach[4];
     const TilePair tp = pairs[blockIdx.x];
     if (!(group_flags[tp.group] & kFlagRegular)) return;
     const GroupDesc gd = groups[tp.group];
     const int B = gd.nbox;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = tp.rt * 4 + w;                 // word-row of this wave
     const int v = r * 64 + lane;                 // my row (rank)
+    // which of this tile pair's blocks can hold a set bit at all (reach_table_kernel); a tile pair without any is done
+    const float2 *rtab = reach_table + reach_slot(gd, tp.group);
+    const int W = (B + 63) >> 6;
+    const float my_reach = r < W ? rtab[r].x : -3.0e38f;
+    if (tp.ct > tp.rt) {
+        float tr = -3.0e38f;
+        for (int k = 0; k < 4; ++k) if (tp.rt * 4 + k < W) tr = fmaxf(tr, rtab[tp.rt * 4 + k].x);
+        if (tp.ct * 4 >= W || rtab[tp.ct * 4].y > tr) return;       // (block-uniform)
+    }
     const float t32e = t32 * 4.76837158203125e-7f;   // 2^-21
     const TransposeConsts tcs = transpose_consts(lane);
 
@@ -483,17 +522,10 @@ __global__ __launch_bounds__(256) void iou_bits_sym_kernel(const float4 *__restr
         if (u < B) bc = xbox[gd.box_off + u];
         sbox[tid] = bc;
         sarea[tid] = box_area(bc);
-        // how far to the right can a partner of my row start?  (1 px + 0.1 % margin, cf. xwindow)
-        float reach = v < B ? br.x + one_minus_t * ((br.z - br.x) + 1.0f) * 1.001f + 1.0f : -3.0e38f;
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) reach = fmaxf(reach, __shfl_xor(reach, d, 64));
-        if (lane == 0) sreach[w] = reach;
     }
     __syncthreads();
     const int rows_left = B - r * 64;
     const unsigned long long rowvalid = rows_left >= 64 ? ~0ull : (rows_left > 0 ? ((1ull << rows_left) - 1ull) : 0ull);
-    const bool tile_empty = tp.ct > tp.rt &&
-                            sbox[0].x > fmaxf(fmaxf(sreach[0], sreach[1]), fmaxf(sreach[2], sreach[3]));
 
     uint32_t dsum = 0;
     for (int q = 0; q < 4; ++q) {
@@ -503,8 +535,10 @@ __global__ __launch_bounds__(256) void iou_bits_sym_kernel(const float4 *__restr
         if (cols_left <= 0) break;
         const unsigned long long colvalid = cols_left >= 64 ? ~0ull : ((1ull << cols_left) - 1ull);
         uint32_t lo = 0, hi = 0, tlo = 0, thi = 0;
-        // (same reach test per 64 x 64 block: the columns of block q start at sbox[q*64].x, sorted)
-        if (!tile_empty && rows_left > 0 && !(c > r && sbox[q * 64].x > sreach[w])) {
+        // the reach test per 64 x 64 block (the columns of block c start at first[c]): a block out of reach is neither
+        // evaluated nor written -- K2 applies the same test before it reads
+        if (rows_left <= 0 || (c > r && rtab[c].y > my_reach)) continue;
+        {
             bool anyb = false;
             if (WT && c > r) {      // off-diagonal block: every column starts at or to the right of every row (x1 order)
 #pragma unroll
@@ -602,6 +636,7 @@ struct WalkMeta {
     uint4 row;           // x: list offset in the pool (u16 units, a multiple of 8), y: its length
 };
 
+constexpr int kMaxWordRows = 320;       // 64-box word-rows of a regular frame (B <= 17 408: 272)
 constexpr int kAdjRows = 128;
 #ifndef VDET_ADJ_BATCH
 #define VDET_ADJ_BATCH 16
@@ -620,8 +655,9 @@ __global__ __launch_bounds__(kAdjRows) void adj_build_kernel(const float4 *__res
                                                         unsigned long long pool_cap, int *__restrict__ status,
                                                         const uint32_t *__restrict__ group_flags,
                                                         const FrameIndex ix, float one_minus_t, int pool_bits,
-                                                        WalkMeta *__restrict__ wmeta)
+                                                        WalkMeta *__restrict__ wmeta, const float2 *__restrict__ reach_table)
 {
+    __shared__ float2 srt[kMaxWordRows];       // regular group: its reach table (which words of a row were written at all)
     __shared__ uint32_t sscan[8];
     __shared__ unsigned long long sbase;
     __shared__ uint16_t sstage[kAdjStage];
@@ -638,6 +674,16 @@ __global__ __launch_bounds__(kAdjRows) void adj_build_kernel(const float4 *__res
     // ... and only the words inside the row's IoU >= t window can be non-zero (the rest was
     // zero-filled by the tile skipping or is zero anyway): read just those
     int w0 = 0, w1 = W;
+    if (tr) {
+        const float2 *rt = reach_table + reach_slot(gd, td.group);
+        for (int i = tid; i < W; i += kAdjRows) srt[i] = rt[i];
+        __syncthreads();
+    }
+    const int wr = __builtin_amdgcn_readfirstlane(v >> 6);     // my word-row (one per wave: 64 aligned rows)
+    // word c of my row exists iff block (min, max) of the upper triangle was in reach (iou_bits_sym_kernel's own test)
+    auto live = [&](int c) -> bool {
+        return !tr || c == wr || (c > wr ? srt[c].y <= srt[wr].x : srt[wr].y <= srt[c].x);
+    };
     if (tr && v < B) {
         const float4 bx = ix.xbox[gd.box_off + v];
         const float xmin = ix.info[td.group * 4 + 0], scale = ix.info[td.group * 4 + 1], wmax = ix.info[td.group * 4 + 2];
@@ -711,7 +757,7 @@ __global__ __launch_bounds__(kAdjRows) void adj_build_kernel(const float4 *__res
         for (int wb = w0; wb < w1; wb += kAdjBatch) {
             uint64_t mm[kAdjBatch];
 #pragma unroll
-            for (int j = 0; j < kAdjBatch; ++j) mm[j] = (wb + j < w1) ? col[(int64_t)(wb + j) * B] : 0ull;
+            for (int j = 0; j < kAdjBatch; ++j) mm[j] = (wb + j < w1 && live(wb + j)) ? col[(int64_t)(wb + j) * B] : 0ull;
 #pragma unroll
             for (int j = 0; j < kAdjBatch; ++j) {
                 uint64_t m = mm[j];

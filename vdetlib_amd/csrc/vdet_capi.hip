@@ -90,7 +90,7 @@ struct vdet_ctx {
     int n_cu = 256;
     // scratch
     DevBuf boxes, scores, keys, excl, frames, groups, tiles, bits, rowz, rowmeta, groupz, adj, comp, origidx,
-        out64, trk_frames, trk_boxes, b1, b2, iou_out, order, ncand, keepidx, keepcnt, gflags, pairs, tkeys, tstate, visited, heads, xkeys, xord, wmeta, xncand, xbox, xcum, xinfo, tmp[8];
+        out64, trk_frames, trk_boxes, b1, b2, iou_out, order, ncand, keepidx, keepcnt, gflags, pairs, tkeys, tstate, visited, heads, xkeys, xord, wmeta, reachtab, xncand, xbox, xcum, xinfo, tmp[8];
     // timing
     bool timing = false;
     bool timing_accumulate = false;   // vdet_set_timing(ctx, 2): keep events across calls until read
@@ -396,6 +396,13 @@ int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32, doub
             if (!volume) c->index_valid = false;
             const int rci = build_frame_index(c, d_boxes, pl.ntot, (int64_t)G, pl.nmax);
             if (rci) return rci;
+            // which 64 x 64 blocks of the predicate matrix can hold a set bit (K1s writes, K2 reads only those)
+            HIPCHK(c, c->reachtab.reserve((size_t)(pl.ntot / 64 + (int64_t)G + 2) * sizeof(float2)));
+            {
+                StageTimer tm(c, ST_OTHER);
+                hipLaunchKernelGGL(reach_table_kernel, dim3((unsigned)G), dim3(256), 0, c->stream, c->xbox.as<float4>(),
+                                   c->groups.as<GroupDesc>(), c->gflags.as<uint32_t>(), one_minus_t, c->reachtab.as<float2>());
+            }
         } else {
             c->index_valid = false;      // gflags / the x-index describe some earlier boxes
         }
@@ -409,11 +416,13 @@ int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32, doub
                 if (c->wave_transpose)
                     hipLaunchKernelGGL(iou_bits_sym_kernel<true>, dim3(bp.second - bp.first), dim3(256), 0, c->stream,
                                        c->xbox.as<float4>(), c->groups.as<GroupDesc>(), c->gflags.as<uint32_t>(),
-                                       c->pairs.as<TilePair>() + bp.first, t32, one_minus_t, c->bits.as<uint64_t>(), c->rowz.as<uint32_t>());
+                                       c->pairs.as<TilePair>() + bp.first, t32, one_minus_t, c->bits.as<uint64_t>(), c->rowz.as<uint32_t>(),
+                                       c->reachtab.as<float2>());
                 else
                     hipLaunchKernelGGL(iou_bits_sym_kernel<false>, dim3(bp.second - bp.first), dim3(256), 0, c->stream,
                                        c->xbox.as<float4>(), c->groups.as<GroupDesc>(), c->gflags.as<uint32_t>(),
-                                       c->pairs.as<TilePair>() + bp.first, t32, one_minus_t, c->bits.as<uint64_t>(), c->rowz.as<uint32_t>());
+                                       c->pairs.as<TilePair>() + bp.first, t32, one_minus_t, c->bits.as<uint64_t>(), c->rowz.as<uint32_t>(),
+                                       c->reachtab.as<float2>());
             }
             // enough column splits to fill the chip when there are few row tiles
             int splits = 1;
@@ -440,7 +449,8 @@ int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32, doub
                                    &c->d_cnt->status, use_sym ? c->gflags.as<uint32_t>() : (const uint32_t *)nullptr,
                                    use_sym ? frame_index_of(c) : FrameIndex{nullptr, nullptr, nullptr, nullptr}, one_minus_t,
                                    async ? (kStPool | kStPoolAsync) : kStPool,
-                                   c->wmeta_built ? c->wmeta.as<WalkMeta>() : (WalkMeta *)nullptr);
+                                   c->wmeta_built ? c->wmeta.as<WalkMeta>() : (WalkMeta *)nullptr,
+                                   use_sym ? c->reachtab.as<float2>() : (const float2 *)nullptr);
             }
         }
         HIPCHK(c, hipGetLastError());
@@ -843,7 +853,7 @@ int vdet_destroy(vdet_ctx *c)
                       &c->rowz, &c->rowmeta, &c->groupz, &c->adj, &c->comp, &c->origidx, &c->out64,
                       &c->trk_frames, &c->trk_boxes, &c->b1, &c->b2, &c->iou_out, &c->order, &c->ncand, &c->keepidx,
                       &c->keepcnt, &c->gflags, &c->pairs, &c->tkeys, &c->tstate, &c->visited, &c->heads, &c->xkeys, &c->xord, &c->xncand, &c->linkmemo, &c->linkstats, &c->linkwarm, &c->tracknode, &c->rtodo,
-                      &c->xbox, &c->xcum, &c->xinfo, &c->wmeta};
+                      &c->xbox, &c->xcum, &c->xinfo, &c->wmeta, &c->reachtab};
     for (DevBuf *b : bufs) b->release();
     for (DevBuf &b : c->tmp) b.release();
     for (auto &e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
