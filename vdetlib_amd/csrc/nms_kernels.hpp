@@ -1393,19 +1393,25 @@ __device__ __forceinline__ void walk_list_packed(const WalkParams &prm, lds_mask
                 const AdjVec *pa = reinterpret_cast<const AdjVec *>(prm.adj + off);
                 const AdjVec a0 = pa[8 * sub < deg ? sub : 0];
                 const AdjVec a1 = pa[64 + 8 * sub < deg ? 8 + sub : 0];
-                const int n0 = min(max(deg - 8 * sub, 0), 8), n1 = min(max(deg - 64 - 8 * sub, 0), 8);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const uint32_t d = a0.v[t];
-                    if (2 * t < n0) lds_or(mask, (int)((d & 0xFFFFu) >> 5), 1u << (d & 31u));
-                    if (2 * t + 1 < n0) lds_or(mask, (int)(d >> 21), 1u << ((d >> 16) & 31u));
-                }
-                if (__ballot(n1 > 0) != 0ull) {
+                // (a piece that starts inside the list is applied whole: K2 pads every list to a multiple of 8 entries with
+                //  copies of its last entry -- one guard per piece instead of one per entry)
+                const bool has0 = 8 * sub < deg, has1 = 64 + 8 * sub < deg;
+                if (has0) {
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
-                        const uint32_t d = a1.v[t];
-                        if (2 * t < n1) lds_or(mask, (int)((d & 0xFFFFu) >> 5), 1u << (d & 31u));
-                        if (2 * t + 1 < n1) lds_or(mask, (int)(d >> 21), 1u << ((d >> 16) & 31u));
+                        const uint32_t d = a0.v[t];
+                        lds_or(mask, (int)((d & 0xFFFFu) >> 5), 1u << (d & 31u));
+                        lds_or(mask, (int)(d >> 21), 1u << ((d >> 16) & 31u));
+                    }
+                }
+                if (__ballot(has1) != 0ull) {
+                    if (has1) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const uint32_t d = a1.v[t];
+                            lds_or(mask, (int)((d & 0xFFFFu) >> 5), 1u << (d & 31u));
+                            lds_or(mask, (int)(d >> 21), 1u << ((d >> 16) & 31u));
+                        }
                     }
                     unsigned long long lg = __ballot(sub == 0 && deg > 128);
                     while (lg) {                                             // rare: long lists
