@@ -100,6 +100,57 @@ def test_rescore_tracks_vs_oracle(oracle):
         assert failed == want_fail
 
 
+@pytest.mark.parametrize("window", [1, 3, 5])
+def test_rescore_series_gaps(oracle, window):
+    """Hand-made tubelets whose boxes either sit on a proposal (a score) or far from every proposal (the -1e5 sentinel):
+    leading / trailing / inner gaps of many lengths over 150 frames (several frames per lane of the one-wave-per-series
+    kernel), a tubelet with a single scored frame, tubelets that start and end inside the video."""
+    import torch
+    from vdetlib_amd import ops
+    F, B, C, T = 150, 60, 2, 6
+    rng = np.random.RandomState(700 + window)
+    boxes = np.zeros((F, B, 4), np.float32)
+    for f in range(F):
+        x = rng.uniform(0, 2000, B); y = rng.uniform(0, 1000, B)
+        boxes[f] = np.round(np.stack([x, y, x + rng.uniform(30, 90, B), y + rng.uniform(30, 90, B)], 1))
+    scores = rng.permutation(F * B * C).reshape(F, B, C).astype(np.float32) / (F * B * C)
+    tracks = np.full((C, T, F, 5), np.nan, np.float32)
+    ntr = np.array([T, T - 1], np.int32)
+    far = np.array([90000, 90000, 90050, 90050], np.float32)
+    for c in range(C):
+        for t in range(ntr[c]):
+            a, b = (0, F) if t % 2 == 0 else (rng.randint(0, 40), rng.randint(100, F))
+            present = rng.rand(F) < (0.5 if t < 4 else 0.05)
+            if t == 1: present[a:a + 7] = False                     # leading gap
+            if t == 2: present[b - 9:b] = False                     # trailing gap
+            if t == 3: present[:] = False; present[(a + b) // 2] = True     # one scored frame only
+            if not present[a:b].any(): present[a] = True
+            for f in range(a, b):
+                tracks[c, t, f, :4] = boxes[f, rng.randint(B)] if present[f] else far
+                tracks[c, t, f, 4] = 1.0
+    tb, ts = torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda()
+    det, pooled, ob = ops.rescore_tracks(torch.from_numpy(tracks).cuda(), torch.from_numpy(ntr).cuda(), tb, ts,
+                                         overlap_thres=0.7, window=window)
+    det, pooled = det.cpu().numpy(), pooled.cpu().numpy()
+    h = window // 2
+    for c in range(C):
+        for t in range(ntr[c]):
+            frames = [f for f in range(F) if not np.isnan(tracks[c, t, f, 0])]
+            s = [oracle.spatial_maxpool([tracks[c, t, f, :4]], boxes[f], scores[f, :, c], 0.7)[0][0] for f in frames]
+            assert min(s) < -10 and max(s) > -10
+            comp = oracle.score_completion(s)
+            pool = np.array([max([comp[g] if 0 <= g < len(comp) else -1e5 for g in range(i - h, i + h + 1)]) for i in range(len(comp))])
+            assert np.array_equal(det[c, t][frames], comp), (c, t)
+            assert np.array_equal(pooled[c, t][frames], pool), (c, t)
+            rest = [f for f in range(F) if f not in frames]
+            assert np.isnan(det[c, t][rest]).all() and np.isnan(pooled[c, t][rest]).all()
+    assert np.isnan(pooled[1, T - 1]).all()                         # beyond ntracks
+    # no scored frame at all -> the reference's IndexError
+    tracks[0, 0, :, :4] = far
+    with pytest.raises(IndexError):
+        ops.rescore_tracks(torch.from_numpy(tracks).cuda(), torch.from_numpy(ntr).cuda(), tb, ts, overlap_thres=0.7, window=window)
+
+
 def _fused_case(seed, F, B, C, irregular=False):
     boxes, scores = _coherent_video(seed, F, B, C, jitter=4)
     if irregular:
@@ -291,7 +342,7 @@ def test_track_volume_random_sweep(oracle, seed):
 
 @pytest.mark.parametrize("knob", ["VDET_FORCE_GENERAL", "VDET_NO_INDEX", "VDET_NO_TRANSPOSE", "VDET_NO_LAZY",
                                   "VDET_WAVE_TRANSPOSE=0", "VDET_ATOMIC_RANK=0", "VDET_LINK_MEMO=0", "VDET_LINK_THREADS=64",
-                                  "VDET_LINK_THREADS=128", "VDET_LINK_WARM=0", "VDET_LINK_MAXB=16", "VDET_AUX_STREAM=1", "VDET_WALK_CAREFUL=1", "VDET_WALK_PACKED=0", "VDET_RESCORE_ADJ=0"])
+                                  "VDET_LINK_THREADS=128", "VDET_LINK_WARM=0", "VDET_LINK_MAXB=16", "VDET_AUX_STREAM=1", "VDET_WALK_CAREFUL=1", "VDET_WALK_PACKED=0", "VDET_SERIES_SERIAL=1", "VDET_RESCORE_ADJ=0"])
 def test_alternative_kernel_paths_agree(monkeypatch, knob):
     """Every A/B knob selects a different kernel path for the same result (general predicate kernel,
     no x-index, strided key reads, eager track_det_nms, ballot transposition in K1s, ballot ranks in

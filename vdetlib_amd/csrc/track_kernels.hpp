@@ -1168,4 +1168,74 @@ __global__ void rescore_series_kernel(double *__restrict__ sc, double *__restric
     }
 }
 
+// The same, one WAVE per series (F <= kSeriesWaveMaxF): the series sits in LDS, a lane owns every 64th frame.  A missing
+// score (<= -10) is filled from the nearest present scores on either side -- found by walking a flag array that is
+// complete before anything is written, so the in-place fill of the serial kernel becomes order-free: a fill only reads
+// present entries, and those never change.  Same arithmetic per element, same NaN behaviour (a NaN inside the run is
+// neither missing nor filled and bounds the gaps next to it), same error rule (no present score at all).
+constexpr int kSeriesWaveMaxF = 1536;
+
+__global__ __launch_bounds__(256) void rescore_series_wave_kernel(double *__restrict__ sc, double *__restrict__ out2,
+                                                                  const int32_t *__restrict__ ntracks, int F, int C, int T,
+                                                                  int window, int *__restrict__ err, int stride_bytes)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char series_smem[];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ct = blockIdx.x * 4 + w;
+    if (ct >= C * T) return;
+    volatile double *v = reinterpret_cast<volatile double *>(series_smem + (size_t)w * stride_bytes);
+    volatile unsigned char *miss = series_smem + (size_t)w * stride_bytes + (size_t)F * 8;
+    const int c = ct / T, t = ct - c * T;
+    double *s = sc + (int64_t)ct * F;
+    double *o = out2 + (int64_t)ct * F;
+    const double qnan = __longlong_as_double(0x7FF8000000000000ll);
+    int amin = F, bmax = -1;
+    for (int f = lane; f < F; f += 64) {
+        const double x = s[f];
+        v[f] = x;
+        miss[f] = (x <= -10.0) ? 1 : 0;
+        o[f] = qnan;
+        if (x == x) { amin = min(amin, f); bmax = max(bmax, f); }
+    }
+    if (t >= ntracks[c]) return;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { amin = min(amin, __shfl_xor(amin, d, 64)); bmax = max(bmax, __shfl_xor(bmax, d, 64)); }
+    const int a = amin, n = bmax + 1 - amin;       // the tubelet = the run from the first to the last frame with a box
+    if (n <= 0) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    bool bad = false;
+    for (int i = lane; i < n; i += 64) {           // do_score_completion
+        if (!miss[a + i]) continue;
+        int i0 = i, j = i + 1;
+        while (i0 > 0 && miss[a + i0 - 1]) --i0;
+        while (j < n && miss[a + j]) ++j;
+        double x;
+        if (i0 == 0) {
+            if (j == n) { bad = true; continue; }
+            x = v[a + j];
+        } else if (j == n) {
+            x = v[a + i0 - 1];
+        } else {
+            const double l = v[a + i0 - 1], r = v[a + j];
+            x = l + (r - l) * (double)(i - i0 + 1) / (double)(j - i0 + 1);
+        }
+        v[a + i] = x;
+        s[a + i] = x;
+    }
+    if (__ballot(bad)) { if (lane == 0) atomicOr(err, 1); return; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int h = window / 2;
+    for (int i = lane; i < n; i += 64) {           // score_proto_temporal_maxpool
+        double m = v[a + i];
+        for (int d = -h; d <= h; ++d) {
+            const int g = i + d;
+            const double x = (g < 0 || g >= n) ? -1e5 : v[a + g];
+            m = (x > m) ? x : m;
+        }
+        o[a + i] = m;
+    }
+}
+
 }  // namespace vdet

@@ -131,6 +131,7 @@ struct vdet_ctx {
     bool force_general = false;   // VDET_FORCE_GENERAL=1: disable the symmetric fast kernel (tests)
     bool topk_attr_set = false;
     int link_threads = 256;       // VDET_LINK_THREADS=64|128|256: threads per link chain (A-B knob)
+    bool series_serial = false;   // VDET_SERIES_SERIAL=1: one thread per tubelet series (A-B knob / tests)
     bool walk_packed = true;      // VDET_WALK_PACKED=0: regular frames walk one survivor at a time (A-B knob / tests)
     float gt32 = 0.f;             // threshold of the last graph build (the packed walk's in-group test)
     bool wmeta_built = false;     // ... which also wrote the packed walk's records (WalkMeta) of the regular frames
@@ -776,6 +777,7 @@ int vdet_create(vdet_ctx **out, int device)
     if (const char *e = getenv("VDET_NO_LAZY")) c->no_lazy = atoi(e) != 0;
     if (const char *e = getenv("VDET_WALK_CAREFUL")) c->walk_careful = atoi(e) != 0;
     if (const char *e = getenv("VDET_WALK_PACKED")) c->walk_packed = atoi(e) != 0;
+    if (const char *e = getenv("VDET_SERIES_SERIAL")) c->series_serial = atoi(e) != 0;
     if (const char *e = getenv("VDET_RESCORE_ADJ")) c->rescore_adj = atoi(e) != 0;
     if (const char *e = getenv("VDET_LINK_MEMO")) c->link_memo = atoi(e) != 0;
     if (const char *e = getenv("VDET_LINK_WARM")) c->link_warm = atoi(e);
@@ -1458,8 +1460,14 @@ int vdet_rescore_tracks(vdet_ctx *c, const float *d_tracks, const int32_t *d_ntr
     {
         StageTimer tm(c, ST_RSERIES);
         const int n = (int)(C * max_tracks);
-        hipLaunchKernelGGL(rescore_series_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, d_det_score,
-                           d_pooled, d_ntracks, (int)F, (int)C, max_tracks, window, &c->d_cnt->eindex);
+        if (F <= kSeriesWaveMaxF && !c->series_serial) {      // one wave per series
+            const int stride = (int)(((size_t)F * 9 + 15) & ~(size_t)15);
+            hipLaunchKernelGGL(rescore_series_wave_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), (size_t)stride * 4, c->stream,
+                               d_det_score, d_pooled, d_ntracks, (int)F, (int)C, max_tracks, window, &c->d_cnt->eindex, stride);
+        } else {
+            hipLaunchKernelGGL(rescore_series_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, d_det_score,
+                               d_pooled, d_ntracks, (int)F, (int)C, max_tracks, window, &c->d_cnt->eindex);
+        }
     }
     HIPCHK(c, hipGetLastError());
     return VDET_OK;
