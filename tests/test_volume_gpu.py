@@ -238,3 +238,36 @@ def test_nms_volume_chains_stacks_hubs(torch_cuda, oracle, seed, t):
     from vdetlib_amd.utils import cython_nms
     d = np.hstack([boxes[0], scores[0, :, :1]]).astype(np.float32)
     assert cython_nms.nms(d, t) == oracle.nms(d, t)
+
+
+def test_packed_walk_random_sweep(torch_cuda, monkeypatch):
+    """Eight candidates per pass (walk_list_packed) against one survivor at a time (VDET_WALK_PACKED=0) on 150 random
+    volumes: frame sizes around the 64 / 128 / 256 boundaries, dense clusters (long lists, many in-group suppressions),
+    integral / fractional boxes, tied scores, thresholds 0.05 .. 0.99, with and without a score threshold."""
+    from vdetlib_amd import ops, _lib
+    torch = torch_cuda
+    monkeypatch.setenv("VDET_WALK_PACKED", "0")
+    cx0 = _lib.Context(torch.cuda.current_device())
+    monkeypatch.delenv("VDET_WALK_PACKED")
+    cx1 = _lib.Context(torch.cuda.current_device())
+    rng = np.random.RandomState(4242)
+    for it in range(150):
+        B = int(rng.choice([2, 3, 7, 63, 64, 65, 127, 128, 129, 255, 256, 257, 500, 1000, 2049]))
+        F, C = int(rng.randint(1, 5)), int(rng.randint(1, 5))
+        t = float(rng.choice([0.05, 0.1, 0.3, 0.5, 0.7, 0.9, 0.99]))
+        kind = rng.randint(4)
+        if kind == 0:
+            boxes, scores = synth.video(int(rng.randint(1 << 30)), F, B, C, frac=bool(rng.randint(2)))
+        else:
+            x, y = rng.uniform(0, 300, (F, B)), rng.uniform(0, 200 if kind == 1 else 40, (F, B))
+            boxes = np.stack([x, y, x + rng.uniform(20, 200, (F, B)), y + rng.uniform(20, 200, (F, B))], 2).astype(np.float32)
+            if kind == 2:
+                boxes = np.round(boxes)
+            scores = rng.rand(F, B, C).astype(np.float32)
+            if kind == 3:
+                scores = np.round(scores * 8) / 8
+        tb, ts = torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda()
+        st = None if rng.randint(2) else float(rng.uniform(0, 0.5))
+        i0, c0 = ops.nms_volume(tb, ts, t, score_thresh=st, ctx=cx0)
+        i1, c1 = ops.nms_volume(tb, ts, t, score_thresh=st, ctx=cx1)
+        assert torch.equal(c0, c1) and torch.equal(i0, i1), (it, B, F, C, t, kind)
