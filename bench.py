@@ -75,6 +75,8 @@ def main():
                     help="heavy: the throughput-bound phase (volume pass, graph, sort, walk) of step n+1 starts when that of step n is done "
                          "(HIP events between the streams), so exactly one video is in it while the latency-bound link chains of the "
                          "previous ones run underneath; none: streams run free")
+    ap.add_argument("--max-frames", type=int, default=0, help="(ablation) tubelet length limit of the tracker (0 = the whole video)")
+    ap.add_argument("--no-rescore", action="store_true", help="(ablation) tubelets without the spatial / temporal re-scoring")
     ap.add_argument("--no-upload", action="store_true", help="skip the PCIe-fed pipeline leg (reported next to value, never part of it)")
     args = ap.parse_args()
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
@@ -154,7 +156,7 @@ def main():
             else:   # NMS survivors + tubelets from one call (same graph, same sorted lists)
                 keep_idx, keep_cnt, tracks, anchors, ntracks = ops.nms_track_volume(
                     vb, vs, nms_thres=args.thresh, thres=args.track_thres, max_tracks=args.max_tracks,
-                    link_thres=args.link_thres, cap=args.cap, sync=False, ctx=cx, pad=False)
+                    link_thres=args.link_thres, max_frames=args.max_frames, cap=args.cap, sync=False, ctx=cx, pad=False)
             if args.separate_pass:
                 if taps is None:
                     pooled = ops.temporal_maxpool(vs, args.window, ctx=cx)
@@ -163,7 +165,7 @@ def main():
                     pooled, conv = ops.temporal_maxpool_conv(vs, args.window, TAPS, ctx=cx)
             elif conv is None and not args.no_conv:
                 conv = ops.temporal_conv(vs, TAPS, bias=0.0, pad=0.0, ctx=cx)
-            if not args.no_link:
+            if not args.no_link and not args.no_rescore:
                 det, tpool, tboxes = ops.rescore_tracks(tracks, ntracks, vb, vs, overlap_thres=args.pool_thres,
                                                         window=args.window, sync=False, ctx=cx)
                 tub = (tracks, ntracks, tpool, tboxes)
