@@ -342,7 +342,7 @@ def test_track_volume_random_sweep(oracle, seed):
 
 @pytest.mark.parametrize("knob", ["VDET_FORCE_GENERAL", "VDET_NO_INDEX", "VDET_NO_TRANSPOSE", "VDET_NO_LAZY",
                                   "VDET_WAVE_TRANSPOSE=0", "VDET_ATOMIC_RANK=0", "VDET_LINK_MEMO=0", "VDET_LINK_THREADS=64",
-                                  "VDET_LINK_THREADS=128", "VDET_LINK_WARM=0", "VDET_LINK_MAXB=16", "VDET_AUX_STREAM=1", "VDET_WALK_CAREFUL=1", "VDET_WALK_PACKED=0", "VDET_SERIES_SERIAL=1", "VDET_RESCORE_ADJ=0"])
+                                  "VDET_LINK_THREADS=128", "VDET_LINK_WARM=0", "VDET_LINK_MAXB=16", "VDET_AUX_STREAM=1", "VDET_WALK_CAREFUL=1", "VDET_WALK_PACKED=0", "VDET_SERIES_SERIAL=1", "VDET_LINK_MATERIALIZE=0", "VDET_RESCORE_ADJ=0"])
 def test_alternative_kernel_paths_agree(monkeypatch, knob):
     """Every A/B knob selects a different kernel path for the same result (general predicate kernel,
     no x-index, strided key reads, eager track_det_nms, ballot transposition in K1s, ballot ranks in
@@ -374,8 +374,10 @@ def test_link_memo_shares_steps_across_chains(oracle):
     boxes, scores = synth.coherent_video(77, 40, 300, 6)
     cx = _lib.Context(torch.cuda.current_device())
     tr, an, nt = ops.track_volume(torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda(), thres=0.0, max_tracks=8, ctx=cx)
-    hits, misses = cx.query(4), cx.query(5)
-    assert hits + misses > 0 and misses > 0
+    # steps found in the memo / scanned, by the tracking loop (4, 5) and by the warm-up of the predicted anchors (6, 7);
+    # tubelets of predicted anchors are copied from the materialised warm chains, so the loop may have nothing left to do
+    hits, misses = cx.query(4) + cx.query(6), cx.query(5) + cx.query(7)
+    assert misses > 0
     assert hits > 0          # 48 chains on 300 coherent proposals do meet
     for c in (0, 5):
         wt, wa, wn = oracle.greedy_track_volume(boxes, scores[:, :, c], 0.3, 0.0, 8, 0.5, 0)

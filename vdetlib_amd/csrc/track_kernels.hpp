@@ -34,6 +34,7 @@ struct TrackState {          // per class
     int32_t anchor_frame;    // 0-based frame of the current anchor
     int32_t anchor_box;
     float anchor_score;
+    int32_t resolved;        // the current anchor's tubelet was copied from the materialised warm chains: no link launch needed
 };
 
 // entry e = (key, flat) is at or before the cursor (ka, fa) in the global order
@@ -200,6 +201,7 @@ __global__ __launch_bounds__(256) void track_pick_kernel(const uint32_t *__restr
         st[c].anchor_frame = f;
         st[c].anchor_box = b;
         st[c].anchor_score = sc;
+        st[c].resolved = 0;
         float *a = anchors + ((int64_t)c * max_tracks + s.ntracks) * 3;
         a[0] = (float)(f + 1);      // 1-based frame id
         a[1] = (float)b;
@@ -468,7 +470,12 @@ __device__ __forceinline__ unsigned long long memo_load(const unsigned long long
 // Structure: KNOWN steps are walked by wave 0 alone, one 8-byte load per step and no barrier (the row of the
 // previous step is written while the next memo word is in flight); an UNKNOWN step is scanned by the whole
 // block like track_link_kernel and its result published.
-template <int LT, bool WARM, int MAXB>
+// MODE 0: the tracking loop's link of one class (anchor from its TrackState, rows into its next track slot)
+// MODE 1: warm-up (anchor = warm[blockIdx.x], nothing written but the memo, a chain stops at its first known step)
+// MODE 2: materialise (anchor = warm[blockIdx.x], rows into chain slot blockIdx.x of `tracks` / `nodes`): run once after
+//         the warm-up, when every step of these chains is known -- the tracking loop then COPIES a predicted anchor's
+//         tubelet (track_resolve_kernel) instead of walking its ~300 dependent steps again, track after track
+template <int LT, int MODE, int MAXB>
 __global__ __launch_bounds__(LT) void track_link_memo_kernel(const float4 *__restrict__ boxes, int F, int B, int max_tracks,
                                                              float link_t32, int reach, const TrackState *__restrict__ st,
                                                              float *__restrict__ tracks,
@@ -489,7 +496,8 @@ __global__ __launch_bounds__(LT) void track_link_memo_kernel(const float4 *__res
     const int dir = blockIdx.y == 0 ? 1 : -1;
     int anchor_frame, anchor_box;
     float *trk = nullptr;
-    if (WARM) {
+    constexpr bool WARM = MODE == 1;
+    if (MODE != 0) {
         const int flat = warm[blockIdx.x];
         if (flat < 0) return;
         anchor_frame = flat / B;
@@ -497,11 +505,19 @@ __global__ __launch_bounds__(LT) void track_link_memo_kernel(const float4 *__res
     } else {
         const int c = blockIdx.x;
         const TrackState s = st[c];
-        if (!s.active) return;
+        if (!s.active || s.resolved) return;
         anchor_frame = s.anchor_frame;
         anchor_box = s.anchor_box;
-        trk = tracks + ((int64_t)c * max_tracks + s.ntracks) * F * 5;
-        if (nodes) nodes += ((int64_t)c * max_tracks + s.ntracks) * F;      // which proposal each row of the track is
+    }
+    if (MODE != 1) {
+        if (MODE == 0) {
+            const TrackState s = st[blockIdx.x];
+            trk = tracks + ((int64_t)blockIdx.x * max_tracks + s.ntracks) * F * 5;
+            if (nodes) nodes += ((int64_t)blockIdx.x * max_tracks + s.ntracks) * F;      // which proposal each row of the track is
+        } else {
+            trk = tracks + (int64_t)blockIdx.x * F * 5;
+            if (nodes) nodes += (int64_t)blockIdx.x * F;
+        }
         const float qnan = __uint_as_float(0x7FC00000u);
         if (dir > 0) { for (int i = anchor_frame * 5 + tid; i < F * 5; i += LT) trk[i] = qnan; }
         else { for (int i = tid; i < anchor_frame * 5; i += LT) trk[i] = qnan; }
@@ -539,7 +555,7 @@ __global__ __launch_bounds__(LT) void track_link_memo_kernel(const float4 *__res
                 if (!(m & kMemoValid)) break;                              // unknown: the block scans this step
                 // warm-up with unlimited reach: a known step has an owner -- the chain that scanned it went on from
                 // there and runs (or hands over, like this one) to the end of the video -- so there is nothing left to do
-                if (WARM && reach >= F) { done = 1; break; }
+                if (WARM && reach >= F) { ++nhit; done = 1; break; }
                 const int bidx = (int)((m >> 32) & 0x7FFFFFFFull) - 1;
                 if (bidx < 0) { done = 1; break; }                         // known: the chain ends here
                 float4 nb = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -718,6 +734,41 @@ __global__ __launch_bounds__(256) void track_warm_anchors_kernel(const uint32_t 
             return;
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The tracking loop's anchor of class c is (almost always) one of its warm anchors, whose tubelet the materialise launch
+// (track_link_memo_kernel MODE 2) has already written: copy it into the class's next track slot.  A tubelet depends on
+// its anchor only -- next(f, j, dir) knows neither class nor track -- so the copy IS what the link would write.
+// One block per class; an anchor that was not predicted leaves resolved = 0 and the link kernel runs for that class.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void track_resolve_kernel(TrackState *__restrict__ st, const int32_t *__restrict__ warm, int m,
+                                                            const float *__restrict__ chains, const int32_t *__restrict__ chain_nodes,
+                                                            float *__restrict__ tracks, int32_t *__restrict__ nodes,
+                                                            int F, int B, int max_tracks)
+{
+    __shared__ int sslot;
+    const int c = blockIdx.x, tid = threadIdx.x;
+    const TrackState s = st[c];
+    if (!s.active) return;
+    if (tid == 0) {
+        const int flat = s.anchor_frame * B + s.anchor_box;
+        int slot = -1;
+        for (int k = 0; k < m; ++k) if (warm[c * m + k] == flat) { slot = k; break; }
+        sslot = slot;
+    }
+    __syncthreads();
+    const int slot = sslot;
+    if (slot < 0) return;
+    const float *src = chains + ((int64_t)c * m + slot) * F * 5;
+    float *dst = tracks + ((int64_t)c * max_tracks + s.ntracks) * F * 5;
+    for (int i = tid; i < F * 5; i += 256) dst[i] = src[i];
+    if (nodes) {
+        const int32_t *ns = chain_nodes + ((int64_t)c * m + slot) * F;
+        int32_t *nd = nodes + ((int64_t)c * max_tracks + s.ntracks) * F;
+        for (int i = tid; i < F; i += 256) nd[i] = ns[i];
+    }
+    if (tid == 0) st[c].resolved = 1;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -923,7 +974,7 @@ __global__ void track_init_kernel(TrackState *__restrict__ st, int C)
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     TrackState s;
-    s.active = 1; s.ntracks = 0; s.last_key = 0; s.last_flat = -1; s.anchor_frame = 0; s.anchor_box = 0; s.anchor_score = 0.f;
+    s.active = 1; s.ntracks = 0; s.last_key = 0; s.last_flat = -1; s.anchor_frame = 0; s.anchor_box = 0; s.anchor_score = 0.f; s.resolved = 0;
     st[c] = s;
 }
 

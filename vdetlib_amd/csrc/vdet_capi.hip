@@ -132,6 +132,7 @@ struct vdet_ctx {
     bool topk_attr_set = false;
     int link_threads = 256;       // VDET_LINK_THREADS=64|128|256: threads per link chain (A-B knob)
     bool series_serial = false;   // VDET_SERIES_SERIAL=1: one thread per tubelet series (A-B knob / tests)
+    bool link_materialize = true; // VDET_LINK_MATERIALIZE=0: the tracking loop walks every tubelet itself (A-B knob / tests)
     bool walk_packed = true;      // VDET_WALK_PACKED=0: regular frames walk one survivor at a time (A-B knob / tests)
     float gt32 = 0.f;             // threshold of the last graph build (the packed walk's in-group test)
     bool wmeta_built = false;     // ... which also wrote the packed walk's records (WalkMeta) of the regular frames
@@ -144,7 +145,7 @@ struct vdet_ctx {
                                   // 19.2 vs 19.7 ms one video at a time, 17.9 vs 16.9 with 3 in flight -- more streams than hardware queues)
     int link_maxb = 8;            // VDET_LINK_MAXB=8|16: boxes per thread and batch in the warm-up's window scans (A-B knob)
     int link_warm = -1;           // VDET_LINK_WARM=m: chains warmed per class (-1: max_tracks + 2; 0: none)
-    DevBuf linkmemo, linkstats, linkwarm, tracknode, rtodo;
+    DevBuf linkmemo, linkstats, linkwarm, linkchains, linknodes, tracknode, rtodo;
     // which proposal every row of the last tracking call's tracks is (written by the link kernels; vdet_rescore_tracks
     // then finds a tubelet box's overlapping detections among that proposal's graph neighbours)
     struct NodeKey { const void *tracks = nullptr, *boxes = nullptr; int64_t F = 0, B = 0, C = 0; int T = 0; double nms_thres = 0; } nodekey;
@@ -777,6 +778,7 @@ int vdet_create(vdet_ctx **out, int device)
     if (const char *e = getenv("VDET_NO_LAZY")) c->no_lazy = atoi(e) != 0;
     if (const char *e = getenv("VDET_WALK_CAREFUL")) c->walk_careful = atoi(e) != 0;
     if (const char *e = getenv("VDET_WALK_PACKED")) c->walk_packed = atoi(e) != 0;
+    if (const char *e = getenv("VDET_LINK_MATERIALIZE")) c->link_materialize = atoi(e) != 0;
     if (const char *e = getenv("VDET_SERIES_SERIAL")) c->series_serial = atoi(e) != 0;
     if (const char *e = getenv("VDET_RESCORE_ADJ")) c->rescore_adj = atoi(e) != 0;
     if (const char *e = getenv("VDET_LINK_MEMO")) c->link_memo = atoi(e) != 0;
@@ -854,7 +856,7 @@ int vdet_destroy(vdet_ctx *c)
     DevBuf *bufs[] = {&c->boxes, &c->scores, &c->keys, &c->excl, &c->frames, &c->groups, &c->tiles, &c->bits,
                       &c->rowz, &c->rowmeta, &c->groupz, &c->adj, &c->comp, &c->origidx, &c->out64,
                       &c->trk_frames, &c->trk_boxes, &c->b1, &c->b2, &c->iou_out, &c->order, &c->ncand, &c->keepidx,
-                      &c->keepcnt, &c->gflags, &c->pairs, &c->tkeys, &c->tstate, &c->visited, &c->heads, &c->xkeys, &c->xord, &c->xncand, &c->linkmemo, &c->linkstats, &c->linkwarm, &c->tracknode, &c->rtodo,
+                      &c->keepcnt, &c->gflags, &c->pairs, &c->tkeys, &c->tstate, &c->visited, &c->heads, &c->xkeys, &c->xord, &c->xncand, &c->linkmemo, &c->linkstats, &c->linkwarm, &c->linkchains, &c->linknodes, &c->tracknode, &c->rtodo,
                       &c->xbox, &c->xcum, &c->xinfo, &c->wmeta, &c->reachtab};
     for (DevBuf *b : bufs) b->release();
     for (DevBuf &b : c->tmp) b.release();
@@ -1251,6 +1253,7 @@ int vdet_nms_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scor
     HIPCHK(c, c->tracknode.reserve((size_t)std::max<int64_t>(C * max_tracks * F, 1) * 4));
     HIPCHK(c, hipMemsetAsync(c->tracknode.p, 0xFF, (size_t)std::max<int64_t>(C * max_tracks * F, 1) * 4, c->stream));
     bool forked = false;
+    int materialized = 0;            // warm chains per class whose tubelets are written out (0: none)
     if (c->link_memo) {      // one memo per call: a link step depends on the video's boxes and link_thres only
         HIPCHK(c, c->linkmemo.reserve((size_t)2 * F * B * 8));
         HIPCHK(c, c->linkstats.reserve(16));
@@ -1279,13 +1282,26 @@ int vdet_nms_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scor
             hipLaunchKernelGGL(track_warm_anchors_kernel, dim3((unsigned)C), dim3(256), 0, ws, c->tkeys.as<uint32_t>(),
                                c->order.as<uint16_t>(), c->ncand.as<int32_t>(), (int)F, (int)B, (int)C, d_scores, thres, wm,
                                c->linkwarm.as<int32_t>());
-#define VDET_WARM(MB) hipLaunchKernelGGL((track_link_memo_kernel<256, true, MB>), dim3((unsigned)(C * wm), 2), dim3(256), 0, ws, \
+#define VDET_WARM(MB) hipLaunchKernelGGL((track_link_memo_kernel<256, 1, MB>), dim3((unsigned)(C * wm), 2), dim3(256), 0, ws, \
                                reinterpret_cast<const float4 *>(d_boxes), (int)F, (int)B, max_tracks, link_t32, reach, \
                                (const TrackState *)nullptr, (float *)nullptr, w_flags, w_ix, link_thres, \
                                c->linkmemo.as<unsigned long long>(), c->linkstats.as<unsigned int>(), c->linkwarm.as<int32_t>(), \
                                (int32_t *)nullptr)
             if (c->link_maxb == 16) VDET_WARM(16); else VDET_WARM(8);
 #undef VDET_WARM
+            if (c->link_materialize) {
+                // every step of the warm chains is known now: write each predicted anchor's tubelet ONCE (one wave walks
+                // a chain; all of them side by side), for the tracking loop to copy (track_resolve_kernel)
+                HIPCHK(c, c->linkchains.reserve((size_t)C * wm * F * 5 * 4));
+                HIPCHK(c, c->linknodes.reserve((size_t)C * wm * F * 4));
+                HIPCHK(c, hipMemsetAsync(c->linknodes.p, 0xFF, (size_t)C * wm * F * 4, ws));
+                hipLaunchKernelGGL((track_link_memo_kernel<64, 2, 8>), dim3((unsigned)(C * wm), 2), dim3(64), 0, ws,
+                                   reinterpret_cast<const float4 *>(d_boxes), (int)F, (int)B, max_tracks, link_t32, reach,
+                                   (const TrackState *)nullptr, c->linkchains.as<float>(), w_flags, w_ix, link_thres,
+                                   c->linkmemo.as<unsigned long long>(), (unsigned int *)nullptr, c->linkwarm.as<int32_t>(),
+                                   c->linknodes.as<int32_t>());
+                materialized = wm;
+            }
         }
         if (forked) HIPCHK(c, hipEventRecord(c->ev_join, c->aux_stream));
     }
@@ -1351,10 +1367,14 @@ int vdet_nms_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scor
 #define VDET_LINK(LTV) hipLaunchKernelGGL(track_link_kernel<LTV>, dim3((unsigned)C, 2), dim3(LTV), 0, c->stream, \
                                reinterpret_cast<const float4 *>(d_boxes), (int)F, (int)B, max_tracks, link_t32, reach, st, \
                                d_tracks, sp.group_flags, sp.ix, link_thres)
-#define VDET_LINKM(LTV) hipLaunchKernelGGL((track_link_memo_kernel<LTV, false, 8>), dim3((unsigned)C, 2), dim3(LTV), 0, c->stream, \
+#define VDET_LINKM(LTV) hipLaunchKernelGGL((track_link_memo_kernel<LTV, 0, 8>), dim3((unsigned)C, 2), dim3(LTV), 0, c->stream, \
                                reinterpret_cast<const float4 *>(d_boxes), (int)F, (int)B, max_tracks, link_t32, reach, st, \
                                d_tracks, sp.group_flags, sp.ix, link_thres, c->linkmemo.as<unsigned long long>(), c->linkstats.as<unsigned int>(), \
                                (const int32_t *)nullptr, c->tracknode.as<int32_t>())
+            if (materialized)      // predicted anchors: their tubelets exist already
+                hipLaunchKernelGGL(track_resolve_kernel, dim3((unsigned)C), dim3(256), 0, c->stream, st, c->linkwarm.as<int32_t>(),
+                                   materialized, c->linkchains.as<float>(), c->linknodes.as<int32_t>(), d_tracks,
+                                   c->tracknode.as<int32_t>(), (int)F, (int)B, max_tracks);
             if (c->link_memo) {
                 if (c->link_threads == 64) VDET_LINKM(64); else if (c->link_threads == 128) VDET_LINKM(128); else VDET_LINKM(256);
             } else {
