@@ -476,7 +476,7 @@ __device__ __forceinline__ unsigned long long memo_load(const unsigned long long
 //         the warm-up, when every step of these chains is known -- the tracking loop then COPIES a predicted anchor's
 //         tubelet (track_resolve_kernel) instead of walking its ~300 dependent steps again, track after track
 template <int LT, int MODE, int MAXB>
-__global__ __launch_bounds__(LT) void track_link_memo_kernel(const float4 *__restrict__ boxes, int F, int B, int max_tracks,
+__global__ __launch_bounds__(LT, (MODE == 1 && LT == 256 && MAXB == 8) ? 5 : 1) void track_link_memo_kernel(const float4 *__restrict__ boxes, int F, int B, int max_tracks,
                                                              float link_t32, int reach, const TrackState *__restrict__ st,
                                                              float *__restrict__ tracks,
                                                              const uint32_t *__restrict__ group_flags,
