@@ -100,14 +100,24 @@ __device__ __forceinline__ bool lazy_examine(const LazyLists &lz, uint16_t *l, i
     return true;
 }
 
+struct ResolveArgs {           // the materialised warm chains (null chains: none)
+    const int32_t *warm;      // [C, m] flat anchor or -1
+    int m;
+    const float *chains;      // [C, m, F, 5]
+    const int32_t *chain_nodes;
+    float *tracks;
+    int32_t *nodes;
+};
+
 __global__ __launch_bounds__(256) void track_pick_kernel(const uint32_t *__restrict__ keys, uint16_t *lists,
                                                          const int32_t *__restrict__ cnt, int F, int B, int C,
                                                          const float *__restrict__ scores, double thres, int max_tracks,
                                                          TrackState *__restrict__ st, float *__restrict__ anchors,
-                                                         const LazyLists lz)
+                                                         const LazyLists lz, const ResolveArgs rv)
 {
     __shared__ uint32_t sk[256];
     __shared__ int sf[256];
+    __shared__ int sslot;
     const int c = blockIdx.x, tid = threadIdx.x;
     TrackState s = st[c];
     if (!s.active) return;
@@ -191,22 +201,51 @@ __global__ __launch_bounds__(256) void track_pick_kernel(const uint32_t *__restr
         }
         __syncthreads();
     }
-    if (tid == 0) {
-        if (sf[0] < 0 || s.ntracks >= max_tracks) { st[c].active = 0; return; }     // "while np.any(keep) and len(tracks) < max_tracks"
-        const int f = sf[0] / B, b = sf[0] - f * B;
-        const float sc = scores[((int64_t)f * B + b) * C + c];
-        st[c].last_key = sk[0];
-        st[c].last_flat = sf[0];
-        if ((double)sc < thres) { st[c].active = 0; return; }                       // vdet/track.py:218 (f32 score vs python float)
-        st[c].anchor_frame = f;
-        st[c].anchor_box = b;
-        st[c].anchor_score = sc;
-        st[c].resolved = 0;
-        float *a = anchors + ((int64_t)c * max_tracks + s.ntracks) * 3;
-        a[0] = (float)(f + 1);      // 1-based frame id
-        a[1] = (float)b;
-        a[2] = sc;
+    if (tid == 0) {     // (no early return: every thread meets the barriers below)
+        if (sf[0] < 0 || s.ntracks >= max_tracks) {                                 // "while np.any(keep) and len(tracks) < max_tracks"
+            st[c].active = 0;
+        } else {
+            const int f = sf[0] / B, b = sf[0] - f * B;
+            const float sc = scores[((int64_t)f * B + b) * C + c];
+            st[c].last_key = sk[0];
+            st[c].last_flat = sf[0];
+            if ((double)sc < thres) {                                               // vdet/track.py:218 (f32 score vs python float)
+                st[c].active = 0;
+            } else {
+                st[c].anchor_frame = f;
+                st[c].anchor_box = b;
+                st[c].anchor_score = sc;
+                st[c].resolved = 0;
+                float *a = anchors + ((int64_t)c * max_tracks + s.ntracks) * 3;
+                a[0] = (float)(f + 1);      // 1-based frame id
+                a[1] = (float)b;
+                a[2] = sc;
+            }
+        }
     }
+    // The anchor is (almost always) one of the class's warm anchors, whose tubelet the materialise launch
+    // (track_link_memo_kernel MODE 2) has already written: copy it into the class's next track slot.  A tubelet depends on
+    // its anchor only -- next(f, j, dir) knows neither class nor track -- so the copy IS what the link would write.  An
+    // anchor that was not predicted leaves resolved = 0 and the link kernel runs for this class.
+    if (!rv.chains) return;
+    if (tid == 0) sslot = -1;
+    __threadfence_block();
+    __syncthreads();
+    const TrackState s2 = st[c];             // (written by thread 0 above: visible after the fence + barrier)
+    if (!s2.active) return;
+    if (tid < rv.m && rv.warm[c * rv.m + tid] == s2.anchor_frame * B + s2.anchor_box) sslot = tid;
+    __syncthreads();
+    const int slot = sslot;
+    if (slot < 0) return;
+    const float *src = rv.chains + ((int64_t)c * rv.m + slot) * F * 5;
+    float *dst = rv.tracks + ((int64_t)c * max_tracks + s2.ntracks) * F * 5;
+    for (int i = tid; i < F * 5; i += 256) dst[i] = src[i];
+    if (rv.nodes) {
+        const int32_t *ns = rv.chain_nodes + ((int64_t)c * rv.m + slot) * F;
+        int32_t *nd = rv.nodes + ((int64_t)c * max_tracks + s2.ntracks) * F;
+        for (int i = tid; i < F; i += 256) nd[i] = ns[i];
+    }
+    if (tid == 0) st[c].resolved = 1;
 }
 
 // IoU of the current track box (as the "i" box) with a proposal (as "j"), utils/nms.pyx arithmetic
@@ -474,7 +513,7 @@ __device__ __forceinline__ unsigned long long memo_load(const unsigned long long
 // MODE 1: warm-up (anchor = warm[blockIdx.x], nothing written but the memo, a chain stops at its first known step)
 // MODE 2: materialise (anchor = warm[blockIdx.x], rows into chain slot blockIdx.x of `tracks` / `nodes`): run once after
 //         the warm-up, when every step of these chains is known -- the tracking loop then COPIES a predicted anchor's
-//         tubelet (track_resolve_kernel) instead of walking its ~300 dependent steps again, track after track
+//         tubelet (the tail of track_pick_kernel) instead of walking its ~300 dependent steps again, track after track
 template <int LT, int MODE, int MAXB>
 __global__ __launch_bounds__(LT, (MODE == 1 && LT == 256 && MAXB == 8) ? 5 : 1) void track_link_memo_kernel(const float4 *__restrict__ boxes, int F, int B, int max_tracks,
                                                              float link_t32, int reach, const TrackState *__restrict__ st,
@@ -734,41 +773,6 @@ __global__ __launch_bounds__(256) void track_warm_anchors_kernel(const uint32_t 
             return;
         }
     }
-}
-
-// ------------------------------------------------------------------------------------------------
-// The tracking loop's anchor of class c is (almost always) one of its warm anchors, whose tubelet the materialise launch
-// (track_link_memo_kernel MODE 2) has already written: copy it into the class's next track slot.  A tubelet depends on
-// its anchor only -- next(f, j, dir) knows neither class nor track -- so the copy IS what the link would write.
-// One block per class; an anchor that was not predicted leaves resolved = 0 and the link kernel runs for that class.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void track_resolve_kernel(TrackState *__restrict__ st, const int32_t *__restrict__ warm, int m,
-                                                            const float *__restrict__ chains, const int32_t *__restrict__ chain_nodes,
-                                                            float *__restrict__ tracks, int32_t *__restrict__ nodes,
-                                                            int F, int B, int max_tracks)
-{
-    __shared__ int sslot;
-    const int c = blockIdx.x, tid = threadIdx.x;
-    const TrackState s = st[c];
-    if (!s.active) return;
-    if (tid == 0) {
-        const int flat = s.anchor_frame * B + s.anchor_box;
-        int slot = -1;
-        for (int k = 0; k < m; ++k) if (warm[c * m + k] == flat) { slot = k; break; }
-        sslot = slot;
-    }
-    __syncthreads();
-    const int slot = sslot;
-    if (slot < 0) return;
-    const float *src = chains + ((int64_t)c * m + slot) * F * 5;
-    float *dst = tracks + ((int64_t)c * max_tracks + s.ntracks) * F * 5;
-    for (int i = tid; i < F * 5; i += 256) dst[i] = src[i];
-    if (nodes) {
-        const int32_t *ns = chain_nodes + ((int64_t)c * m + slot) * F;
-        int32_t *nd = nodes + ((int64_t)c * max_tracks + s.ntracks) * F;
-        for (int i = tid; i < F; i += 256) nd[i] = ns[i];
-    }
-    if (tid == 0) st[c].resolved = 1;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1291,7 +1291,7 @@ int vdet_nms_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scor
 #undef VDET_WARM
             if (c->link_materialize) {
                 // every step of the warm chains is known now: write each predicted anchor's tubelet ONCE (one wave walks
-                // a chain; all of them side by side), for the tracking loop to copy (track_resolve_kernel)
+                // a chain; all of them side by side), for the tracking loop to copy (the tail of track_pick_kernel)
                 HIPCHK(c, c->linkchains.reserve((size_t)C * wm * F * 5 * 4));
                 HIPCHK(c, c->linknodes.reserve((size_t)C * wm * F * 4));
                 HIPCHK(c, hipMemsetAsync(c->linknodes.p, 0xFF, (size_t)C * wm * F * 4, ws));
@@ -1354,12 +1354,16 @@ int vdet_nms_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scor
     const bool need_suppress = !sp.lazy || !sp.group_flags || !c->all_regular;
     sp.n_irregular = &c->d_cnt->irregular;
     if (forked) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));      // the memo is warm
+    ResolveArgs rv{nullptr, 0, nullptr, nullptr, nullptr, nullptr};
+    if (materialized)      // predicted anchors: their tubelets exist already, the pick kernel copies them
+        rv = ResolveArgs{c->linkwarm.as<int32_t>(), materialized, c->linkchains.as<float>(), c->linknodes.as<int32_t>(), d_tracks,
+                         c->tracknode.as<int32_t>()};
     for (int t = 0; t < max_tracks; ++t) {
         {
             StageTimer tm(c, ST_TPICK);
             hipLaunchKernelGGL(track_pick_kernel, dim3((unsigned)C), dim3(256), 0, c->stream, c->tkeys.as<uint32_t>(),
                                c->order.as<uint16_t>(), c->ncand.as<int32_t>(), (int)F, (int)B, (int)C, d_scores, thres,
-                               max_tracks, st, d_anchors, lz);
+                               max_tracks, st, d_anchors, lz, rv);
         }
         if (c->debug_sync) { fprintf(stderr, "[vdet] iter %d pick...\n", t); HIPCHK(c, host_sync(c)); fprintf(stderr, "[vdet] iter %d pick ok\n", t); }
         {
@@ -1371,10 +1375,6 @@ int vdet_nms_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scor
                                reinterpret_cast<const float4 *>(d_boxes), (int)F, (int)B, max_tracks, link_t32, reach, st, \
                                d_tracks, sp.group_flags, sp.ix, link_thres, c->linkmemo.as<unsigned long long>(), c->linkstats.as<unsigned int>(), \
                                (const int32_t *)nullptr, c->tracknode.as<int32_t>())
-            if (materialized)      // predicted anchors: their tubelets exist already
-                hipLaunchKernelGGL(track_resolve_kernel, dim3((unsigned)C), dim3(256), 0, c->stream, st, c->linkwarm.as<int32_t>(),
-                                   materialized, c->linkchains.as<float>(), c->linknodes.as<int32_t>(), d_tracks,
-                                   c->tracknode.as<int32_t>(), (int)F, (int)B, max_tracks);
             if (c->link_memo) {
                 if (c->link_threads == 64) VDET_LINKM(64); else if (c->link_threads == 128) VDET_LINKM(128); else VDET_LINKM(256);
             } else {
