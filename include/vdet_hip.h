@@ -98,7 +98,9 @@ int vdet_set_async(vdet_ctx *ctx, int enable);
  * what = 4 / 5 -> link steps of the last tracking call that were served by the link memo / that scanned their
  * frame (synchronises the stream); 6 / 7 -> the same for the memo warm-up launch;
  * what = 8 -> number of host waits (hipStreamSynchronize) this context has made so far: the asynchronous video
- * step (vdet_set_async) adds none between the entry and the return of the volume entry points. */
+ * step (vdet_set_async) adds none between the entry and the return of the volume entry points;
+ * what = 9 -> (frame, class) columns of the last volume sort that the equalised counting sort handed to the LSD
+ * radix kernel (tied / quantised / thresholded columns; synchronises the stream), -1 if that sort did not use it. */
 int vdet_query(vdet_ctx *ctx, int what);
 /* Per-stage HIP-event timing: 0 off (default), 1 on (events of the most recent call), 2 on and
  * accumulating over calls until vdet_last_timing_ms reads them. */
@@ -233,6 +235,18 @@ int vdet_nms_volume_topk(vdet_ctx *ctx, const float *d_boxes, const float *d_sco
                          int64_t F, int64_t B, int64_t C, double thresh, int use_score_thresh,
                          float score_thresh, int topk, int32_t *d_keep_idx, int32_t *d_keep_cnt,
                          int64_t cap);
+
+/*
+ * Descending argsort of every (frame, class) score column of a volume: the order utils/nms.pyx:25
+ * (`scores.argsort()[::-1]`) and vdet/video_det.py:93 (`argsort(-cls_scores)`) walk, with the build's
+ * deterministic tie rule (equal scores by DESCENDING index, -0.0 == +0.0, NaN first).
+ *   d_scores [F,B,C] or [F,C,B] f32 (layout)   use_score_thresh != 0: boxes with score <= score_thresh are
+ *   no candidates and go to the tail.   d_order [F,C,B] uint16: box indices;   d_ncand [F,C] int32: candidates.
+ * The same lists vdet_nms_volume / vdet_track_volume build internally (equalised counting sort, LSD radix
+ * sort for tied / thresholded columns).  B <= ~18000.
+ */
+int vdet_argsort_volume(vdet_ctx *ctx, const float *d_scores, int layout, int64_t F, int64_t B, int64_t C,
+                        int use_score_thresh, float score_thresh, uint16_t *d_order, int32_t *d_ncand);
 
 /*
  * Centred sliding temporal max over series laid out [F,S] (series s = in[f*S+s]); the array form

@@ -145,3 +145,23 @@ def test_raw_video_files_are_memory_mapped(tmp_path):
     b, s, c = vio.open_video_raw(str(tmp_path / 'v'))
     assert isinstance(b, np.memmap) and isinstance(s, np.memmap) and not s.flags.writeable
     assert np.array_equal(b, boxes) and np.array_equal(s, scores) and np.array_equal(c, counts)
+
+
+def test_gen_vid_proto_file_cli(tmp_path, capsys):
+    """tools/gen_vid_proto_file.py:10-24: frames -> .vid file, parent directory created, and the idempotent early exit
+    (an existing out_file is left untouched, exit status 0)."""
+    from vdetlib_amd.tools import gen_vid_proto_file as gen
+    frames = tmp_path / "frames"
+    frames.mkdir()
+    for name in ("10.JPEG", "2.JPEG", "1.JPEG", "notes.txt"):
+        (frames / name).write_bytes(b"")
+    out = tmp_path / "protos" / "deep" / "v.vid"
+    assert gen.main(["myvid", str(frames), str(out)]) == 0
+    vid = P.proto_load(str(out))
+    assert vid["video"] == "myvid" and vid["root_path"] == str(frames)
+    assert [(f["frame"], f["path"]) for f in vid["frames"]] == [(1, "1.JPEG"), (2, "2.JPEG"), (3, "10.JPEG")]
+    before = out.read_bytes()
+    (frames / "3.JPEG").write_bytes(b"")
+    assert gen.main(["other", str(frames), str(out)]) == 0          # resume rule: nothing is redone
+    assert out.read_bytes() == before
+    assert "already exists" in capsys.readouterr().out

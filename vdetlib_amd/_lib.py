@@ -44,6 +44,7 @@ SYMBOLS = {
     "vdet_conv1d_f32": (_ci, [_vp, _vp, _ci, _ci, _vp, _vp, _ci, _ci, _ci, _vp]),
     "vdet_nms_volume": (_ci, [_vp, _vp, _vp, _ci, _i64, _i64, _i64, _f64, _ci, _f32, _vp, _vp, _i64]),
     "vdet_nms_volume_topk": (_ci, [_vp, _vp, _vp, _ci, _i64, _i64, _i64, _f64, _ci, _f32, _ci, _vp, _vp, _i64]),
+    "vdet_argsort_volume": (_ci, [_vp, _vp, _ci, _i64, _i64, _i64, _ci, _f32, _vp, _vp]),
     "vdet_volume_pass": (_ci, [_vp, _vp, _i64, _i64, _i64, _ci, _f32, _vp, _f32, _f32, _vp, _vp, _ci, _f32]),
     "vdet_track_volume": (_ci, [_vp, _vp, _vp, _i64, _i64, _i64, _f64, _f64, _ci, _f64, _ci, _vp, _vp, _vp]),
     "vdet_nms_track_volume": (_ci, [_vp, _vp, _vp, _i64, _i64, _i64, _f64, _f64, _ci, _f64, _ci, _vp, _vp, _vp,
@@ -179,7 +180,7 @@ class Context(object):
         self.check(self.lib.vdet_last_launches(self.h, n))
         names = ["iou_bits", "adj_build", "sort", "walk", "temporal", "merge_sort", "iou_bits_general", "other",
                  "transpose_keys", "track_pick", "track_link", "track_suppress", "rescore_spatial", "rescore_series",
-                 "_14", "_15"]
+                 "sort_fallback", "_15"]
         return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(names)}
 
 

@@ -1,0 +1,328 @@
+// binsort_kernels.hpp -- K3', the per-(frame, class) descending argsort as ONE equalised counting pass (round 3).
+//
+// sort_kernel (nms_kernels.hpp) is a stable LSD radix sort: 4 passes x (gather, returning atomic, table look-up,
+// scatter) over every key plus ~22 workgroup barriers per problem -- ~20 LDS operations per key, the LDS pipe and the
+// barriers are its bound (profiles/r02_pmc_sq2.csv).  The order it produces is fully determined by the keys
+// (descending key, ties by descending index), so ANY algorithm that ends in that order is a drop-in.  This one needs
+// ~6 LDS operations per key and 7 barriers:
+//
+//   1. level 1: histogram of the keys' top 9 bits (sign + exponent of the inverted sortable key), 8 copies per value
+//      spread over the lanes (scores concentrate on a handful of exponents; same-address LDS atomics serialise);
+//   2. every exponent value e that occurs gets m_e = ceil(count_e * S / N) sub-bins of EQUAL mantissa width,
+//      S = 32 256: a piecewise-linear, monotone map key -> bin in [0, 32 768) that follows the key distribution octave
+//      by octave (uniform, normal, exponential / softmax-like scores all end with ~0.3 keys per bin);
+//   3. one returning byte-wide LDS atomic per key counts the bin and hands the key its arrival rank r inside it;
+//   4. an exclusive scan over the 32 768 byte counters (8 192 words; 8 words per thread) gives every bin its start;
+//   5. the key's entry {sub-bin fraction (16 bits) | first-of-bin flag | index} goes to start + r;
+//   6. fix-up: bins are contiguous runs of 1-3 entries (never more than kBinMax) in ARRIVAL order; every entry looks
+//      at its run's other members (coalesced neighbour reads) and counts how many of them belong before it -- by
+//      fraction, and in the rare case of equal fractions (equal keys, or an exponent with < 128 sub-bins) by the full
+//      key from global memory and then by descending index.  It then stores its index at its exact final position.
+//
+// The result is bit-identical to sort_kernel's.  A problem the map cannot spread (a bin with more than kBinMax keys:
+// heavily tied / quantised scores; or any excluded key) is appended to a fail list and sorted by the LSD kernel
+// afterwards (sort_list_kernel) -- the decision is made per problem, on the device, from the counts alone.
+// Workgroups are persistent and claim problems from a global counter; the next problem's keys are in flight while
+// the current one is scanned, scattered and fixed up.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "nms_kernels.hpp"
+
+namespace vdet {
+
+constexpr int kBinWords = 8192;          // 32 768 byte counters
+constexpr int kBinTotal = 4 * kBinWords;
+constexpr int kBinSub = kBinTotal - 512; // sub-bins handed out proportionally (every exponent value adds < 1 by rounding up)
+constexpr int kBinMax = 10;              // keys per bin (three of them must fit a 5-bit field of the scanned counter word)
+
+struct BinSortCtl {
+    int next;            // next problem to claim
+    int nfail;           // problems handed to the LSD kernel
+};
+
+struct BinSortParams {
+    const uint32_t *raw; // [P, N] rows of sortable keys (0 = not a candidate), or of float32 scores (FLOATS)
+    int P, N;            // problems = (frame, class) pairs; boxes per frame (the same for every problem of a volume)
+    uint16_t *order;     // [P, N]
+    int32_t *ncand;      // [P]
+    BinSortCtl *ctl;
+    int32_t *fail_list;  // [P]
+};
+
+// dynamic LDS: [counter words: 32 KB][16 B][entries: N + kBinTail words]
+constexpr int kBinEntOff = 4 * kBinWords + 16;
+constexpr int kBinTail = 72;             // flagged sentinels behind the last entry + slack for the last chunk's window reads
+inline size_t binsort_lds_bytes(int n) { return (size_t)kBinEntOff + (size_t)4 * (size_t)(((n + 63) & ~63) + kBinTail); }
+
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t x)
+{
+#define VDET_BS_STEP(CTRL, ROWMASK) x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROWMASK, 0xf, false);
+    VDET_BS_STEP(0x111, 0xf) VDET_BS_STEP(0x112, 0xf) VDET_BS_STEP(0x114, 0xf) VDET_BS_STEP(0x118, 0xf)
+    VDET_BS_STEP(0x142, 0xa) VDET_BS_STEP(0x143, 0xc)
+#undef VDET_BS_STEP
+    return x;
+}
+
+// CPW = keys per thread (key v = tid + k * BLOCK) = chunks of 64 positions per wave in the fix-up (even).
+// 512 threads x 20 keys at B = 10 000: the LDS (72 KB) admits two workgroups per CU whatever their size, and 8 waves
+// each leave 128 VGPRs per lane -- with 1 024 threads x 10 keys the 64-register cap spilled the loop's invariants.
+// The kernel is bound by VALU issue (profiles/r03_pmc_sort.csv), so every phase is written for instruction count:
+// full-rate 24-bit multiplies, compile-time key format, immediate LDS offsets, flags tested as lane masks.
+template <int CPW, bool FLOATS>
+__global__ __launch_bounds__(512, CPW <= 20 ? 4 : 2) void binsort_kernel(const BinSortParams prm)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int BLOCK = 512, NW = BLOCK / 64;
+    constexpr int WPT = kBinWords / BLOCK;          // counter words per thread in the scan (16)
+    static_assert(CPW % 2 == 0, "the fix-up takes two chunks per round");
+    uint32_t *hist = reinterpret_cast<uint32_t *>(smem);                        // [kBinWords]; level-1 table in its first 4 096 words
+    uint32_t *ent = reinterpret_cast<uint32_t *>(smem + kBinEntOff);            // [N] fraction << 16 | first << 15 | index
+    __shared__ uint32_t tab[512];        // per exponent value: first bin << 16 | number of sub-bins
+    __shared__ uint32_t wsum[NW];
+    __shared__ int snext;
+
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int P = prm.P, N = prm.N;
+
+    // inverted sortable key of element idx of a row (ascending = descending score; 0xFFFFFFFF = not a candidate)
+    auto ikey = [&](const uint32_t *row, uint32_t idx) -> uint32_t {
+        const uint32_t x = row[idx];
+        return ~(FLOATS ? score_key(__uint_as_float(x)) : x);
+    };
+    auto load_keys = [&](int p, uint32_t (&ik)[CPW]) {
+        const uint32_t *row = prm.raw + (int64_t)p * N;          // (scalar base + 32-bit lane offsets)
+        uint32_t off = (uint32_t)tid;
+        asm volatile("" : "+v"(off));                            // not hoisted out of the problem loop as CPW 64-bit pointers
+#pragma unroll
+        for (int k = 0; k < CPW; ++k) {
+            const uint32_t v = off + (uint32_t)(k * BLOCK);
+            ik[k] = v < (uint32_t)N ? ikey(row, v) : 0xFFFFFFFFu;
+        }
+    };
+
+    if (tid == 0) snext = atomicAdd(&prm.ctl->next, 1);
+    for (int i = tid; i < kBinWords / 4; i += BLOCK) reinterpret_cast<uint4 *>(hist)[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (tid < kBinTail) ent[N + tid] = 0x8000u;                  // sentinels: "a new bin starts here" closes every walk to the right
+    __syncthreads();
+    int p = __builtin_amdgcn_readfirstlane(snext);      // (wave-uniform by construction: scalar addressing)
+    __syncthreads();                 // (thread 0 overwrites snext at the top of the loop)
+    uint32_t ik[CPW];
+    if (p < P) load_keys(p, ik);
+
+    // (every phase re-derives what it needs from an OPAQUE copy of the thread index: left alone, hipcc hoists each
+    //  phase's addresses and predicates out of the problem loop and then spills them -- seen in the ISA)
+    auto fresh_tid = [&]() -> int { int t = tid; asm volatile("" : "+v"(t)); return t; };
+    while (p < P) {
+        int bad = 0;
+        // ---- 1. level 1: exponent histogram, 8 copies per value (lane & 7)
+        {
+            const int t = fresh_tid();
+            const uint32_t copy = (uint32_t)(t & 7);
+#pragma unroll
+            for (int k = 0; k < CPW; ++k) {
+                const bool none = ik[k] == 0xFFFFFFFFu;                          // (slots past N hold 0xFFFFFFFF too)
+                bad |= (int)(none & (t + k * BLOCK < N));                        // excluded keys: the LSD kernel's business
+                if (!none) atomicAdd(&hist[((ik[k] >> 23) << 3) | copy], 1u);
+            }
+        }
+        if (tid == 0) snext = atomicAdd(&prm.ctl->next, 1);                     // (read after the barriers below)
+        __syncthreads();
+        // ---- 2. sub-bins per exponent value: thread e owns value e (BLOCK == 512 values); its level-1 words are zeroed again
+        {
+            static_assert(BLOCK == 512, "one thread per exponent value");
+            const int e = fresh_tid();
+            uint4 *src = reinterpret_cast<uint4 *>(hist) + e * 2;
+            const uint4 a = src[0], b = src[1];
+            src[0] = make_uint4(0u, 0u, 0u, 0u); src[1] = make_uint4(0u, 0u, 0u, 0u);
+            const uint32_t cnt = a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w;
+            const uint32_t m = cnt ? (cnt * (uint32_t)kBinSub + (uint32_t)N - 1u) / (uint32_t)N : 0u;      // (cnt <= N < 2^15, kBinSub < 2^15)
+            const uint32_t incl = wave_incl_scan_u32(m);
+            if ((e & 63) == 63) wsum[w] = incl;
+            __syncthreads();
+            uint32_t run = incl - m;
+            for (int k = 0; k < w; ++k) run += wsum[k];
+            tab[e] = (run << 16) | m;
+        }
+        __syncthreads();
+        const int pnext = __builtin_amdgcn_readfirstlane(snext);
+        // ---- 3. bin + arrival rank of every key.  Each stage of the phase runs over ALL the thread's keys before the next
+        //         one starts (table reads, then atomics, then their returns): 16 waves per CU hide no LDS latency, the
+        //         20 independent operations per thread do
+        uint32_t cs[CPW];            // bin << 16 | fraction
+        uint32_t rr[(CPW + 3) / 4];  // ranks, one byte each
+        {
+#pragma unroll
+            for (int k = 0; k < CPW; ++k) cs[k] = tab[ik[k] >> 23];
+#pragma unroll
+            for (int k = 0; k < CPW; ++k) {
+                // bin = first + (mant * m) >> 23, fraction = the next 16 bits: 23 x 16-bit product from the full-rate 24-bit
+                // multipliers (v_mul_lo / v_mul_hi_u32 are quarter rate)
+                const uint32_t t = cs[k], mant = ik[k] & 0x7FFFFFu, m = t & 0xFFFFu;
+                uint32_t lo, hi;
+                asm("v_mul_u32_u24 %0, %1, %2" : "=v"(lo) : "v"(mant), "v"(m));
+                asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(hi) : "v"(mant), "v"(m));
+                const uint32_t binv = (t >> 16) + __builtin_amdgcn_alignbit(hi, lo, 23);
+                cs[k] = ik[k] == 0xFFFFFFFFu ? 0u : ((binv << 16) | ((lo >> 7) & 0xFFFFu));
+            }
+            uint32_t old[CPW];
+#pragma unroll
+            for (int k = 0; k < CPW; ++k) {
+                old[k] = 0u;
+                if (ik[k] != 0xFFFFFFFFu) old[k] = atomicAdd(&hist[cs[k] >> 18], 1u << ((cs[k] >> 13) & 24u));
+            }
+#pragma unroll
+            for (int k = 0; k < (CPW + 3) / 4; ++k) rr[k] = 0u;
+#pragma unroll
+            for (int k = 0; k < CPW; ++k) {
+                const uint32_t r = (old[k] >> ((cs[k] >> 13) & 24u)) & 0xFFu;
+                if (r >= (uint32_t)kBinMax) bad = 1;
+                rr[k >> 2] |= r << ((k & 3) * 8);
+            }
+        }
+        // which of my slots hold keys: remembered as a bit per slot (ik is about to be reused)
+        unsigned long long have = 0ull;
+#pragma unroll
+        for (int k = 0; k < CPW; ++k) have |= (unsigned long long)(ik[k] != 0xFFFFFFFFu ? 1u : 0u) << k;
+        // the next problem's keys travel while this one is scanned, scattered and fixed up
+        if (pnext < P) load_keys(pnext, ik);
+        if (__syncthreads_or(bad)) {
+            // not spreadable (ties / quantised scores / exclusions): hand the problem to the LSD kernel
+            if (tid == 0) prm.fail_list[atomicAdd(&prm.ctl->nfail, 1)] = p;
+            for (int i = tid; i < kBinWords / 4; i += BLOCK) reinterpret_cast<uint4 *>(hist)[i] = make_uint4(0u, 0u, 0u, 0u);
+            __syncthreads();
+            p = pnext;
+            continue;
+        }
+        // ---- 4. exclusive scan of the byte counters; word <- start | s1 << 17 | s2 << 22 | s3 << 27, s_j = keys in the
+        //         word's first j bins (<= 3 * kBinMax = 30: five bits)
+        //         (two reads of the thread's 16 words instead of 16 live registers + their shifted copies across the barrier)
+        {
+            uint4 *hw = reinterpret_cast<uint4 *>(hist) + fresh_tid() * (WPT / 4);
+            auto bytesum = [](uint32_t x) -> uint32_t {
+                const uint32_t h2 = (x & 0x00FF00FFu) + ((x >> 8) & 0x00FF00FFu);
+                return (h2 & 0xFFFFu) + (h2 >> 16);
+            };
+            uint32_t tot = 0;
+#pragma unroll
+            for (int j = 0; j < WPT / 4; ++j) { const uint4 a = hw[j]; tot += bytesum(a.x) + bytesum(a.y) + bytesum(a.z) + bytesum(a.w); }
+            const uint32_t incl = wave_incl_scan_u32(tot);
+            if (lane == 63) wsum[w] = incl;
+            __syncthreads();
+            uint32_t run = incl - tot;
+            for (int k = 0; k < w; ++k) run += wsum[k];
+            auto enc = [&](uint32_t x) -> uint32_t {
+                const uint32_t s1 = x & 0xFFu, s2 = s1 + ((x >> 8) & 0xFFu), s3 = s2 + ((x >> 16) & 0xFFu);
+                const uint32_t r = run | (s1 << 17) | (s2 << 22) | (s3 << 27);
+                run += s3 + (x >> 24);
+                return r;
+            };
+            uint4 *hw2 = reinterpret_cast<uint4 *>(hist) + fresh_tid() * (WPT / 4);
+#pragma unroll 2
+            for (int j = 0; j < WPT / 4; ++j) {
+                const uint4 a = hw2[j];
+                uint4 o;
+                o.x = enc(a.x); o.y = enc(a.y); o.z = enc(a.z); o.w = enc(a.w);
+                hw2[j] = o;
+            }
+        }
+        __syncthreads();
+        // ---- 5. scatter: position = word start + keys in the word's earlier bins + arrival rank
+        {
+            const int t5 = fresh_tid();
+            uint32_t e[CPW];
+#pragma unroll
+            for (int k = 0; k < CPW; ++k) e[k] = hist[cs[k] >> 18];
+#pragma unroll
+            for (int k = 0; k < CPW; ++k) {
+                const uint32_t j = (cs[k] >> 16) & 3u;
+                const uint32_t r = (rr[k >> 2] >> ((k & 3) * 8)) & 0xFFu;
+                // (j = 0 reads 5 bits that lie inside the 17-bit start field: masked out by the select)
+                const uint32_t before = (e[k] >> (12u + 5u * j)) & 31u;
+                const uint32_t pos = (e[k] & 0x1FFFFu) + r + (j ? before : 0u);
+                if ((have >> k) & 1ull) ent[pos] = (cs[k] << 16) | (r == 0u ? 0x8000u : 0u) | (uint32_t)(t5 + k * BLOCK);
+            }
+        }
+        __syncthreads();
+        // ---- 6. fix-up + store; the counters are cleared for the next problem meanwhile
+        for (int i = fresh_tid(); i < kBinWords / 4; i += BLOCK) reinterpret_cast<uint4 *>(hist)[i] = make_uint4(0u, 0u, 0u, 0u);
+        {
+            const int lane6 = fresh_tid() & 63;
+            uint16_t *out = prm.order + (int64_t)p * N;
+            const uint32_t *row = prm.raw + (int64_t)p * N;
+            auto key_of = [&](uint32_t idx) -> uint32_t { return ~ikey(row, idx); };
+            // the general form: walk my bin to the left and to the right, one entry per step
+            auto fix_general = [&](int q, uint32_t me) -> int {
+                const uint32_t mfr = me >> 16, midx = me & 0x7FFFu;
+                int npos = q;
+                bool lopen = !(me & 0x8000u), ropen = true;          // (entry N is a flagged sentinel)
+                for (int k = 1; lopen || ropen; ++k) {
+                    uint32_t l = 0u, r = 0x8000u;
+                    if (lopen) l = ent[q - k];
+                    if (ropen) r = ent[q + k];
+                    ropen = ropen && !(r & 0x8000u);
+                    bool l_after = lopen && (l >> 16) > mfr, r_before = ropen && (r >> 16) < mfr;
+                    if ((lopen && (l >> 16) == mfr) || (ropen && (r >> 16) == mfr)) {     // equal fractions: the keys themselves
+                        const uint32_t km = key_of(midx);
+                        if (lopen && (l >> 16) == mfr) { const uint32_t kl = key_of(l & 0x7FFFu); l_after = kl < km || (kl == km && (l & 0x7FFFu) < midx); }
+                        if (ropen && (r >> 16) == mfr) { const uint32_t kr = key_of(r & 0x7FFFu); r_before = kr > km || (kr == km && (r & 0x7FFFu) > midx); }
+                    }
+                    npos += (r_before ? 1 : 0) - (l_after ? 1 : 0);
+                    lopen = lopen && !(l & 0x8000u);
+                }
+                return npos;
+            };
+            // An entry of my bin on my left that belongs after me moves me one place forward, one on my right that belongs
+            // before me one place back.  Fast form: three neighbours to the left, four to the right, all read at once with
+            // immediate offsets (bins hold 1-3 entries; the entries behind the last one are flagged sentinels); a lane
+            // whose bin reaches further, or that meets an equal fraction (equal keys; an exponent with < 128 sub-bins),
+            // takes the general form -- rare.  Two chunks per round: twice the reads in flight.
+#pragma unroll 1
+            for (int ch = 0; ch < CPW; ch += 2) {
+                const int q0 = (w * CPW + ch) * 64;
+                if (q0 >= N) break;
+                const uint32_t *pe = ent + q0 + lane6;
+                uint32_t me[2], l1[2], l2[2], l3[2], r1[2], r2[2], r3[2], r4[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    me[u] = pe[u * 64];
+                    l1[u] = pe[u * 64 - 1]; l2[u] = pe[u * 64 - 2]; l3[u] = pe[u * 64 - 3];      // (q = 0 .. 2: the 16 B in front of the
+                    r1[u] = pe[u * 64 + 1]; r2[u] = pe[u * 64 + 2]; r3[u] = pe[u * 64 + 3];      //  entries; never used -- entry 0 is flagged)
+                    r4[u] = pe[u * 64 + 4];
+                }
+                int npos[2];
+                bool slow[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    // (bitwise & / | on purpose: with && / || hipcc builds a forest of exec-masked branches -- seen in the ISA)
+                    const uint32_t hi = me[u] | 0xFFFFu, lo = me[u] & 0xFFFF0000u;     // x > hi: larger fraction; x < lo: smaller
+                    const bool o1 = (me[u] & 0x8000u) == 0u, o2 = o1 & ((l1[u] & 0x8000u) == 0u), o3 = o2 & ((l2[u] & 0x8000u) == 0u);
+                    const bool p1 = (r1[u] & 0x8000u) == 0u, p2 = p1 & ((r2[u] & 0x8000u) == 0u), p3 = p2 & ((r3[u] & 0x8000u) == 0u);
+                    const bool a1 = l1[u] > hi, a2 = l2[u] > hi, a3 = l3[u] > hi;          // left neighbour belongs after me
+                    const bool b1 = r1[u] < lo, b2 = r2[u] < lo, b3 = r3[u] < lo;          // right neighbour belongs before me
+                    const int d = (int)(p1 & b1) + (int)(p2 & b2) + (int)(p3 & b3) - (int)(o1 & a1) - (int)(o2 & a2) - (int)(o3 & a3);
+                    // an in-bin neighbour that is neither: equal fraction
+                    const bool tie = (o1 & !a1 & !(l1[u] < lo)) | (o2 & !a2 & !(l2[u] < lo)) | (o3 & !a3 & !(l3[u] < lo)) |
+                                     (p1 & !b1 & !(r1[u] > hi)) | (p2 & !b2 & !(r2[u] > hi)) | (p3 & !b3 & !(r3[u] > hi));
+                    const int q = q0 + u * 64 + lane6;
+                    npos[u] = q + d;
+                    slow[u] = (q < N) & (tie | (o3 & ((l3[u] & 0x8000u) == 0u)) | (p3 & ((r4[u] & 0x8000u) == 0u)));
+                }
+                if (__ballot(slow[0] | slow[1]) != 0ull) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+                        if (slow[u]) npos[u] = fix_general(q0 + u * 64 + lane6, me[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    if (q0 + u * 64 + lane6 < N) out[npos[u]] = (uint16_t)(me[u] & 0x7FFFu);
+            }
+            if (tid == 0) prm.ncand[p] = N;
+        }
+        __syncthreads();
+        p = pnext;
+    }
+}
+
+}  // namespace vdet

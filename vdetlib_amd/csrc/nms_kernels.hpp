@@ -878,9 +878,8 @@ __device__ __forceinline__ unsigned long long match8(uint32_t d, bool valid)
 // (1024-thread variants up to CPW = 10, i.e. N <= 10 240, are register-capped to 8 waves per SIMD
 // -- hipcc's second __launch_bounds__ argument -- so that two workgroups are resident per CU)
 template <int BLOCK, int CPW, bool ARANK>
-__global__ __launch_bounds__(BLOCK, (BLOCK == 1024 && CPW <= 10) ? 8 : 1) void sort_kernel(const SortParams prm)
+__device__ __forceinline__ void lsd_sort_problem(const SortParams &prm, const int p, unsigned char *smem)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NW = BLOCK / 64;
     // Only 16 key bits live in LDS at a time (passes 0-1 sort by the low half, passes 2-3 by the
     // high half, which waits in registers meanwhile): 6 B instead of 8 B per key, so TWO workgroups
@@ -892,8 +891,6 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 && CPW <= 10) ? 8 : 1) void s
     uint32_t *tot = bases + NW * 256;                                           // [256] + [1] excluded count
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int p = xcd_problem(blockIdx.x, gridDim.x);
-    if (p >= prm.P) return;
     const ProblemRef pr = decode_problem(prm.mode, p, prm.B, prm.C, prm.groups);
     const int N = pr.N;
 
@@ -1095,6 +1092,29 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 && CPW <= 10) ? 8 : 1) void s
         for (int v = tid; v < N; v += BLOCK) out[v] = src[v];
     }
     if (tid == 0) prm.ncand[p] = ncand_out;
+}
+
+template <int BLOCK, int CPW, bool ARANK>
+__global__ __launch_bounds__(BLOCK, (BLOCK == 1024 && CPW <= 10) ? 8 : 1) void sort_kernel(const SortParams prm)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int p = xcd_problem(blockIdx.x, gridDim.x);
+    if (p >= prm.P) return;
+    lsd_sort_problem<BLOCK, CPW, ARANK>(prm, p, smem);
+}
+
+// The same sort for a LIST of problems (the ones binsort_kernel could not spread, binsort_kernels.hpp): persistent
+// workgroups stride over list[0 .. *count).  An empty list costs one launch of workgroups that leave at once.
+template <int BLOCK, int CPW, bool ARANK>
+__global__ __launch_bounds__(BLOCK, (BLOCK == 1024 && CPW <= 10) ? 8 : 1) void sort_list_kernel(const SortParams prm, const int32_t *__restrict__ list,
+                                                                                                   const int *__restrict__ count)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int n = *count;
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        lsd_sort_problem<BLOCK, CPW, ARANK>(prm, list[i], smem);
+        __syncthreads();             // the next problem rewrites the LDS this one's final copy reads
+    }
 }
 
 // Self-test for ARANK (see sort_kernel): for each of the n patterns, every lane adds 1 to

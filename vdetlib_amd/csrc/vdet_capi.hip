@@ -15,6 +15,7 @@
 
 #include "../../include/vdet_hip.h"
 #include "nms_kernels.hpp"
+#include "binsort_kernels.hpp"
 #include "temporal_kernels.hpp"
 #include "tubelet_kernels.hpp"
 #include "track_kernels.hpp"
@@ -52,18 +53,25 @@ struct DevBuf {
 };
 
 enum Stage { ST_IOU_BITS = 0, ST_ADJ = 1, ST_SORTK = 2, ST_WALK = 3, ST_TEMPORAL = 4, ST_SORT = 5, ST_IOU_GEN = 6, ST_OTHER = 7,
-             ST_TRANSPOSE = 8, ST_TPICK = 9, ST_TLINK = 10, ST_TSUPP = 11, ST_RSPATIAL = 12, ST_RSERIES = 13, ST_COUNT = 16 };
+             ST_TRANSPOSE = 8, ST_TPICK = 9, ST_TLINK = 10, ST_TSUPP = 11, ST_RSPATIAL = 12, ST_RSERIES = 13, ST_SORTFB = 14, ST_COUNT = 16 };
 
 struct Counters {            // one small device block
     // sticky until vdet_sync (or a synchronous graph build) reads and clears them
     int status;
     int eindex;              // latched "IndexError" of the rescoring kernels
+    unsigned long long pool_max;   // largest pool_used of the asynchronous builds since the last vdet_sync
     // per graph build (kPerBuildOff .. end): cleared when a build starts
     unsigned int glob_cnt;
     int irregular;           // frames that are not "regular" (frame_flags_kernel), counted per graph build
     unsigned long long pool_used;
 };
-constexpr size_t kPerBuildOff = 8;
+constexpr size_t kPerBuildOff = 16;
+
+// an asynchronous build is about to clear the per-build counters: keep the largest pool demand of the window
+__global__ void fold_pool_kernel(Counters *cnt)
+{
+    if (cnt->pool_used > cnt->pool_max) cnt->pool_max = cnt->pool_used;
+}
 
 struct NmsPlan {
     std::vector<GroupDesc> groups;   // bits_off is batch-local
@@ -138,6 +146,10 @@ struct vdet_ctx {
     bool wmeta_built = false;     // ... which also wrote the packed walk's records (WalkMeta) of the regular frames
     bool walk_careful = false;    // VDET_WALK_CAREFUL=1: per-survivor bookkeeping also on regular frames (A-B knob / tests)
     bool link_memo = true;        // VDET_LINK_MEMO=0: every link step scans (A-B knob / tests)
+    bool binsort = false;         // VDET_BINSORT=1: untied volume columns by the equalised counting sort (binsort_kernels.hpp) instead of the
+                                  // LSD radix kernel.  Bit-identical; measured at the LSD kernel's speed (3.32 vs 3.37 ms per c2 video), so off
+    bool last_sort_binned = false;   // the last per-(frame, class) sort went through binsort_kernel (vdet_query 9)
+    DevBuf sortctl;               // binsort_kernel's work counter + the list of problems it handed to the LSD kernel
     // second stream of the context: the memo warm-up runs on it, next to the NMS walk of the same video
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -224,6 +236,7 @@ uint32_t pow2ceil(uint32_t x)
 
 int translate_status(vdet_ctx *c, int st)
 {
+    if (st & kStPoolAsync) return fail(c, VDET_EAGAIN, "adjacency pool overflow in an asynchronous graph build: run the calls again");
     if (st & kStDivZero) return fail(c, VDET_EDIVZERO, "float division (zero union)");
     if (st & kStCap) return fail(c, VDET_ECAP, "more survivors than the output capacity");
     if (st & kStPool) return fail(c, VDET_EHIP, "internal: adjacency pool overflow");
@@ -340,6 +353,7 @@ int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32, doub
     c->sym_built = false;
     c->gt32 = t32;
     c->wmeta_built = false;
+    c->nodes_valid = false;      // the adjacency lists the recorded track nodes point into are rewritten
     HIPCHK(c, c->groups.reserve(G * sizeof(GroupDesc)));
     HIPCHK(c, c->tiles.reserve(std::max<size_t>(pl.tiles.size(), 1) * sizeof(TileDesc)));
     HIPCHK(c, c->bits.reserve(std::max<size_t>(pl.bits_words_max, 1) * 8));
@@ -378,7 +392,10 @@ int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32, doub
         HIPCHK(c, hipMemsetAsync(c->rowz.p, 0, (size_t)pl.ntot * 4, c->stream));
         HIPCHK(c, hipMemsetAsync(c->rowmeta.p, 0, (size_t)pl.ntot * 8, c->stream));
         HIPCHK(c, hipMemsetAsync(c->groupz.p, 0, G * 4, c->stream));
-        if (async) HIPCHK(c, hipMemsetAsync((char *)c->d_cnt + kPerBuildOff, 0, sizeof(Counters) - kPerBuildOff, c->stream));
+        if (async) {
+            hipLaunchKernelGGL(fold_pool_kernel, dim3(1), dim3(1), 0, c->stream, c->d_cnt);
+            HIPCHK(c, hipMemsetAsync((char *)c->d_cnt + kPerBuildOff, 0, sizeof(Counters) - kPerBuildOff, c->stream));
+        }
         else HIPCHK(c, hipMemsetAsync(c->d_cnt, 0, sizeof(Counters), c->stream));
         const unsigned long long pool_cap = (c->adj.cap - 2048) / 2;     // (the packed walk reads up to 256 B past a list)
         // fast symmetric kernel for regular frames needs 0 < t32 < inf (exact divide-free test)
@@ -508,8 +525,9 @@ int launch_sort_walk(vdet_ctx *c, const SortWalkArgs &a, int nmax, int64_t order
     const int nchunks = (std::max(nmax, 1) + 63) / 64;
     const int need_cpw = (nchunks + nw - 1) / nw;
     // instantiated (BLOCK, CPW) pairs; CPW = chunks of 64 keys per wave
-    struct Variant { int block, cpw; const void *fn[2]; };   // fn[0]: ballot match, fn[1]: atomic rank
-#define VDET_SV(BL, CP) {BL, CP, {reinterpret_cast<const void *>(sort_kernel<BL, CP, false>), reinterpret_cast<const void *>(sort_kernel<BL, CP, true>)}}
+    struct Variant { int block, cpw; const void *fn[2]; const void *fn_list[2]; };   // [0]: ballot match, [1]: atomic rank
+#define VDET_SV(BL, CP) {BL, CP, {reinterpret_cast<const void *>(sort_kernel<BL, CP, false>), reinterpret_cast<const void *>(sort_kernel<BL, CP, true>)}, \
+                         {reinterpret_cast<const void *>(sort_list_kernel<BL, CP, false>), reinterpret_cast<const void *>(sort_list_kernel<BL, CP, true>)}}
     static const Variant variants[] = {VDET_SV(256, 1), VDET_SV(256, 2), VDET_SV(256, 4), VDET_SV(1024, 2), VDET_SV(1024, 4),
                                        VDET_SV(1024, 6), VDET_SV(1024, 8), VDET_SV(1024, 10), VDET_SV(1024, 12),
                                        VDET_SV(1024, 16), VDET_SV(1024, 18)};
@@ -517,8 +535,12 @@ int launch_sort_walk(vdet_ctx *c, const SortWalkArgs &a, int nmax, int64_t order
     if (!c->sort_attr_set) {
         size_t stat = 0;
         std::vector<const void *> fns;
-        for (const Variant &v : variants) { fns.push_back(v.fn[0]); fns.push_back(v.fn[1]); }
+        for (const Variant &v : variants) { fns.push_back(v.fn[0]); fns.push_back(v.fn[1]); fns.push_back(v.fn_list[0]); fns.push_back(v.fn_list[1]); }
         fns.push_back(reinterpret_cast<const void *>(walk_kernel));
+        for (const void *fn : {reinterpret_cast<const void *>(binsort_kernel<8, false>), reinterpret_cast<const void *>(binsort_kernel<8, true>),
+                               reinterpret_cast<const void *>(binsort_kernel<20, false>), reinterpret_cast<const void *>(binsort_kernel<20, true>),
+                               reinterpret_cast<const void *>(binsort_kernel<36, false>), reinterpret_cast<const void *>(binsort_kernel<36, true>)})
+            fns.push_back(fn);
         for (const void *fn : fns) {
             hipFuncAttributes fa;
             HIPCHK(c, hipFuncGetAttributes(&fa, fn));
@@ -591,10 +613,41 @@ int launch_sort_walk(vdet_ctx *c, const SortWalkArgs &a, int nmax, int64_t order
         }
         HIPCHK(c, hipGetLastError());
     } else if (!a.walk_only) {
-        const int grid = (a.P + 7) & ~7;
+        // volumes of untied scores: the equalised counting sort (binsort_kernels.hpp); what it can not spread -- decided per
+        // problem on the device -- lands on a list the LSD kernel works off afterwards (normally empty)
+        const size_t bin_lds = binsort_lds_bytes(std::max(nmax, 1));
+        const int bin_cpw = nmax <= 4096 ? 8 : nmax <= 10240 ? 20 : 36;      // keys per thread, 512 threads
+        const bool use_bin = c->binsort && (sp.mode == 1 || sp.mode == 3) && a.topk == 0 && !a.use_thr && !a.excl && block == 1024 &&
+                             nmax <= 512 * bin_cpw && bin_lds + 4096 <= c->dyn_lds_max && sp.npass == 4;
         StageTimer tm(c, ST_SORTK);
-        void *args[] = {&sp};
-        HIPCHK(c, hipLaunchKernel(var->fn[c->atomic_rank ? 1 : 0], dim3(grid), dim3(block), args, lds, c->stream));
+        if (a.mode != 2) c->last_sort_binned = use_bin;
+        if (use_bin) {
+            HIPCHK(c, c->sortctl.reserve(sizeof(BinSortCtl) + (size_t)a.P * 4));
+            HIPCHK(c, hipMemsetAsync(c->sortctl.p, 0, sizeof(BinSortCtl), c->stream));
+            BinSortParams bp{};
+            const bool floats = sp.keys == nullptr;
+            bp.raw = floats ? reinterpret_cast<const uint32_t *>(sp.scores) : sp.keys;
+            bp.P = a.P; bp.N = a.B;
+            bp.order = sp.order; bp.ncand = sp.ncand;
+            bp.ctl = c->sortctl.as<BinSortCtl>();
+            bp.fail_list = reinterpret_cast<int32_t *>(c->sortctl.as<char>() + sizeof(BinSortCtl));
+            const int per_cu = std::max<int>(1, (int)(c->max_lds / (bin_lds + 4096)));
+            const int grid = std::min(a.P, per_cu * c->n_cu);
+#define VDET_BSK(CP) (floats ? reinterpret_cast<const void *>(binsort_kernel<CP, true>) : reinterpret_cast<const void *>(binsort_kernel<CP, false>))
+            const void *bfn = bin_cpw == 8 ? VDET_BSK(8) : bin_cpw == 20 ? VDET_BSK(20) : VDET_BSK(36);
+#undef VDET_BSK
+            void *bargs[] = {&bp};
+            HIPCHK(c, hipLaunchKernel(bfn, dim3(grid), dim3(512), bargs, bin_lds, c->stream));
+            const int32_t *fl = bp.fail_list;
+            const int *fc = &bp.ctl->nfail;
+            void *largs[] = {&sp, (void *)&fl, (void *)&fc};
+            StageTimer tm2(c, ST_SORTFB);
+            HIPCHK(c, hipLaunchKernel(var->fn_list[c->atomic_rank ? 1 : 0], dim3(std::min(a.P, 2 * c->n_cu)), dim3(block), largs, lds, c->stream));
+        } else {
+            const int grid = (a.P + 7) & ~7;
+            void *args[] = {&sp};
+            HIPCHK(c, hipLaunchKernel(var->fn[c->atomic_rank ? 1 : 0], dim3(grid), dim3(block), args, lds, c->stream));
+        }
     }
     HIPCHK(c, hipGetLastError());
     if (a.sort_only) return VDET_OK;
@@ -782,6 +835,7 @@ int vdet_create(vdet_ctx **out, int device)
     if (const char *e = getenv("VDET_SERIES_SERIAL")) c->series_serial = atoi(e) != 0;
     if (const char *e = getenv("VDET_RESCORE_ADJ")) c->rescore_adj = atoi(e) != 0;
     if (const char *e = getenv("VDET_LINK_MEMO")) c->link_memo = atoi(e) != 0;
+    if (const char *e = getenv("VDET_BINSORT")) c->binsort = atoi(e) != 0;
     if (const char *e = getenv("VDET_LINK_WARM")) c->link_warm = atoi(e);
     if (const char *e = getenv("VDET_LINK_MAXB")) c->link_maxb = atoi(e) == 16 ? 16 : 8;
     if (const char *e = getenv("VDET_AUX_STREAM")) c->use_aux = atoi(e) != 0;
@@ -857,7 +911,7 @@ int vdet_destroy(vdet_ctx *c)
                       &c->rowz, &c->rowmeta, &c->groupz, &c->adj, &c->comp, &c->origidx, &c->out64,
                       &c->trk_frames, &c->trk_boxes, &c->b1, &c->b2, &c->iou_out, &c->order, &c->ncand, &c->keepidx,
                       &c->keepcnt, &c->gflags, &c->pairs, &c->tkeys, &c->tstate, &c->visited, &c->heads, &c->xkeys, &c->xord, &c->xncand, &c->linkmemo, &c->linkstats, &c->linkwarm, &c->linkchains, &c->linknodes, &c->tracknode, &c->rtodo,
-                      &c->xbox, &c->xcum, &c->xinfo, &c->wmeta, &c->reachtab};
+                      &c->xbox, &c->xcum, &c->xinfo, &c->wmeta, &c->reachtab, &c->sortctl};
     for (DevBuf *b : bufs) b->release();
     for (DevBuf &b : c->tmp) b.release();
     for (auto &e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -890,7 +944,7 @@ int vdet_set_cache(vdet_ctx *c, int enable)
 {
     if (!c) return VDET_EINVAL;
     c->cache_enabled = enable != 0;
-    c->graph_valid = c->lists_valid = c->index_valid = c->keys_valid = false;
+    c->graph_valid = c->lists_valid = c->index_valid = c->keys_valid = c->nodes_valid = false;
     return VDET_OK;
 }
 
@@ -909,6 +963,12 @@ int vdet_query(vdet_ctx *c, int what)
     if (what == 2) return c->all_regular ? 1 : 0;
     if (what == 3) return c->wave_transpose ? 1 : 0;
     if (what == 8) return (int)std::min<long long>(c->n_host_syncs, 0x7FFFFFFF);
+    if (what == 9) {   // problems the last volume sort's counting kernel handed to the LSD kernel (-1: it did not run)
+        if (!c->last_sort_binned || !c->sortctl.p) return -1;
+        BinSortCtl h{};
+        if (hipMemcpyAsync(&h, c->sortctl.p, sizeof h, hipMemcpyDeviceToHost, c->stream) != hipSuccess || host_sync(c) != hipSuccess) return VDET_EHIP;
+        return h.nfail;
+    }
     if (what >= 4 && what <= 7) {     // link steps of the last tracking call served by the memo (4) / scanned (5); 6 / 7: the warm-up's
         unsigned int h[4] = {0, 0, 0, 0};
         if (!c->linkstats.p) return 0;
@@ -959,21 +1019,23 @@ int vdet_sync(vdet_ctx *c)
     Counters h;
     HIPCHK(c, hipMemcpyAsync(&h, c->d_cnt, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, host_sync(c));
-    HIPCHK(c, hipMemsetAsync(&c->d_cnt->status, 0, sizeof(int), c->stream));
-    HIPCHK(c, hipMemsetAsync(&c->d_cnt->eindex, 0, sizeof(int), c->stream));
+    HIPCHK(c, hipMemsetAsync(&c->d_cnt->status, 0, kPerBuildOff, c->stream));     // status, eindex, pool_max
+    h.pool_used = std::max(h.pool_used, h.pool_max);
     const int l = c->latched;
     c->latched = 0;
-    if (l) return l;
-    if (h.status & kStPoolAsync) {
+    if ((h.status & kStPoolAsync) || l == VDET_EAGAIN) {
         // an asynchronous graph build (vdet_set_async) ran out of adjacency pool: everything enqueued
         // since is invalid.  The pool is enlarged here, so running the same calls again succeeds.
-        c->graph_valid = c->lists_valid = false;
+        // (handled before a latched error of the same window is reported: the truncated graph must not be reused)
+        c->graph_valid = c->lists_valid = c->nodes_valid = false;
         c->pool_hint = std::max(c->pool_hint, h.pool_used);
         if (h.pool_used <= 0xFFFFFFFFull) (void)c->adj.reserve((size_t)(h.pool_used + h.pool_used / 2) * 2 + 4096);
+        if (l && l != VDET_EAGAIN) return l;
         return fail(c, VDET_EAGAIN, "adjacency pool overflow in an asynchronous graph build (%llu entries needed): the "
                                     "results since the last vdet_sync are invalid; the pool has been enlarged, run the calls again",
                     (unsigned long long)h.pool_used);
     }
+    if (l) return l;
     c->pool_hint = std::max(c->pool_hint, h.pool_used);
     if (h.eindex) return fail(c, VDET_EINDEX, "list index out of range");
     return translate_status(c, h.status);
@@ -1189,6 +1251,38 @@ int vdet_nms_volume_topk(vdet_ctx *c, const float *d_boxes, const float *d_score
     c->prep.thr = score_thresh; c->prep.topk = topk;
     c->lists_valid = true;
     return VDET_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+int vdet_argsort_volume(vdet_ctx *c, const float *d_scores, int layout, int64_t F, int64_t B, int64_t C,
+                        int use_score_thresh, float score_thresh, uint16_t *d_order, int32_t *d_ncand)
+{
+    if (!c) return VDET_EINVAL;
+    if (F < 0 || B < 0 || C < 0 || (layout != VDET_LAYOUT_FBC && layout != VDET_LAYOUT_FCB)) return fail(c, VDET_EINVAL, "bad shape/layout");
+    if (F == 0 || C == 0) return VDET_OK;
+    if (!d_ncand || (B > 0 && (!d_scores || !d_order))) return fail(c, VDET_EINVAL, "null buffer");
+    if (B > 32767) return fail(c, VDET_EINVAL, "B = %lld boxes per frame; the limit is 32767", (long long)B);
+    if (F * C > 0x7FFFFFF0ll || F * B > 0x7FFFFFF0ll) return fail(c, VDET_EINVAL, "volume too large");
+    HIPCHK(c, hipSetDevice(c->device));
+    timing_reset(c);
+    if (B == 0) {
+        HIPCHK(c, hipMemsetAsync(d_ncand, 0, (size_t)(F * C) * 4, c->stream));
+        return VDET_OK;
+    }
+    // only the group table (one group of B boxes per frame) is needed; tiles / pairs follow with the next graph build
+    NmsPlan &pl = volume_plan(c, F, B);
+    c->host_groups = &pl.groups;
+    HIPCHK(c, c->groups.reserve((size_t)F * sizeof(GroupDesc)));
+    if (!c->vplan_valid)
+        HIPCHK(c, hipMemcpyAsync(c->groups.p, pl.groups.data(), (size_t)F * sizeof(GroupDesc), hipMemcpyHostToDevice, c->stream));
+    c->lists_valid = false;          // (c->tkeys, which the context's own lists are read with, is rewritten)
+    SortWalkArgs a{};
+    a.sort_only = true;
+    a.mode = layout; a.P = (int)(F * C); a.B = (int)B; a.C = (int)C;
+    a.scores = d_scores;
+    a.use_thr = use_score_thresh; a.thr = score_thresh;
+    a.order_out = d_order; a.ncand_out = d_ncand;
+    return launch_sort_walk(c, a, (int)B, F * C * B);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1451,7 +1545,9 @@ int vdet_rescore_tracks(vdet_ctx *c, const float *d_tracks, const int32_t *d_ntr
                              c->nodekey.tracks == d_tracks && c->nodekey.boxes == d_boxes && c->prep.boxes == d_boxes &&
                              c->nodekey.F == F && c->nodekey.B == B && c->nodekey.C == C && c->nodekey.T == max_tracks &&
                              c->prep.F == F && c->prep.B == B && overlap_thres - c->nodekey.nms_thres > 0.05 &&
-                             c->nodekey.nms_thres > 0.0 && overlap_thres < 1.0;
+                             c->nodekey.nms_thres > 0.0 && overlap_thres < 1.0 &&
+                             // ... and the resident graph is the one the tracks were made on (same threshold)
+                             [&] { const float nt = thresh_to_f32(c->nodekey.nms_thres); return memcmp(&c->prep.t32, &nt, 4) == 0; }();
         const double min_self = use_adj ? 1.0 - (overlap_thres - c->nodekey.nms_thres) + 0.02 : 2.0;
         const int32_t *todo = nullptr;
         const unsigned int *todo_cnt = nullptr;
@@ -1835,6 +1931,11 @@ int vdet_volume_pass(vdet_ctx *c, const float *d_scores, int64_t F, int64_t B, i
     }
     HIPCHK(c, hipSetDevice(c->device));
     timing_reset(c);
+    // c->tkeys is rewritten (and possibly reallocated) below: sorted lists stay valid only if they are the lists of
+    // exactly these keys (the tracking kernels read keys and lists together)
+    if (!(c->prep.scores == d_scores && c->prep.F == F && c->prep.B == B && c->prep.C == C && c->prep.layout == VDET_LAYOUT_FBC &&
+          c->prep.topk == 0 && c->prep.use_thr == (use_score_thresh ? 1 : 0) && (!use_score_thresh || c->prep.thr == score_thresh)))
+        c->lists_valid = false;
     HIPCHK(c, c->tkeys.reserve((size_t)(F * C * B) * 4));
     Taps taps{};
     if (conv) for (int k = 0; k < window; ++k) taps.w[k] = h_taps[k];

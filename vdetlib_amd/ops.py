@@ -88,6 +88,31 @@ def nms_volume(boxes, scores, thresh=0.3, score_thresh=None, cap=None, layout="F
     return keep_idx, keep_cnt
 
 
+def argsort_volume(scores, score_thresh=None, layout="FBC", ctx=None):
+    """Descending argsort of every (frame, class) column of a score volume -- ``scores.argsort()[::-1]`` of
+    utils/nms.pyx:25 / ``argsort(-cls_scores)`` of vdet/video_det.py:93 with the build's tie rule (equal scores by
+    descending index, -0.0 == +0.0, NaN first).  Returns (order int16-as-uint16 [F,C,B] box indices, ncand int32 [F,C]);
+    with score_thresh only boxes with score > score_thresh are candidates, the others form the tail."""
+    if scores.dtype != torch.float32:
+        raise ValueError("Buffer dtype mismatch, expected 'float32_t'")
+    scores = scores.contiguous()
+    if layout == "FBC":
+        F, B, C = scores.shape
+        lay = _lib.LAYOUT_FBC
+    elif layout == "FCB":
+        F, C, B = scores.shape
+        lay = _lib.LAYOUT_FCB
+    else:
+        raise ValueError("layout must be 'FBC' or 'FCB'")
+    ctx = _ctx_for(scores, ctx)
+    order = torch.empty((F, C, B), dtype=torch.int16, device=scores.device)     # uint16 payload (B <= 32767: never negative)
+    ncand = torch.zeros((F, C), dtype=torch.int32, device=scores.device)
+    _finish(ctx, lambda: ctx.check(ctx.lib.vdet_argsort_volume(
+        ctx.h, scores.data_ptr(), lay, F, B, C, 0 if score_thresh is None else 1,
+        0.0 if score_thresh is None else float(score_thresh), order.data_ptr(), ncand.data_ptr())), True)
+    return order, ncand
+
+
 def temporal_maxpool(vol, window, pad=-1e5, ctx=None):
     """Centred sliding max along axis 0 (array form of score_proto_temporal_maxpool,
     vdet/tubelet_cls.py:386-414; pad value :402).  vol: f32 [F, ...]."""

@@ -31,19 +31,30 @@ def svm_scores(features, svm_model):
     B = np.asarray(svm_model['B'])
     if features.ndim != 2 or W.ndim != 2 or features.shape[1] != W.shape[0]:
         raise ValueError("shapes %s and %s not aligned" % (features.shape, W.shape))
-    dt = np.result_type(features.dtype, W.dtype, B.dtype)
+    # the product is computed in the dtype numpy's dot would use (features, W); B joins afterwards exactly as
+    # ``+ B`` would (a float64 B on float32 operands promotes the SUM, not the contraction)
+    dt = np.result_type(features.dtype, W.dtype)
     dt = np.dtype(np.float32) if dt == np.float32 else np.dtype(np.float64)
     a = np.ascontiguousarray(features, dtype=dt)
     w = np.ascontiguousarray(W, dtype=dt)
     n, k = a.shape
     m = w.shape[1]
-    bias = None
-    if B.size == m:                     # the usual [m] / [1, m] row: added inside the kernel
-        bias = np.ascontiguousarray(B.reshape(m), dtype=dt)
+    # the bias is fused only when it is a per-COLUMN row ([m] / [1, m]) of the product's dtype; anything else -- a
+    # column-shaped [m, 1] B (numpy broadcasts it per row when n == m and raises otherwise), another dtype --
+    # is added by numpy with numpy's own broadcasting rules
+    fuse = (B.ndim <= 1 or B.shape == (1, m)) and B.size == m and np.result_type(dt, B.dtype) == dt
+    bias = np.ascontiguousarray(B.reshape(m), dtype=dt) if fuse else None
     out = np.empty((n, m), dtype=dt)
-    ctx = _lib.get_context()
-    ctx.reset_stream()
+    # a private context on its own stream: the shared per-device context (and whichever torch stream it follows)
+    # is left alone
+    global _svm_ctx
+    if _svm_ctx is None:
+        _svm_ctx = _lib.Context()
+    ctx = _svm_ctx
     fn = ctx.lib.vdet_svm_scores_f32 if dt == np.float32 else ctx.lib.vdet_svm_scores_f64
     ctx.check(fn(ctx.h, a.ctypes.data, n, k, w.ctypes.data, bias.ctypes.data if bias is not None else None, m,
                  out.ctypes.data))
     return out if bias is not None else out + B
+
+
+_svm_ctx = None
