@@ -78,6 +78,9 @@ def main():
     ap.add_argument("--max-frames", type=int, default=0, help="(ablation) tubelet length limit of the tracker (0 = the whole video)")
     ap.add_argument("--no-rescore", action="store_true", help="(ablation) tubelets without the spatial / temporal re-scoring")
     ap.add_argument("--no-upload", action="store_true", help="skip the PCIe-fed pipeline leg (reported next to value, never part of it)")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="run the N > 1 exchange step -- process group, RCCL communicator, all-gather of device tensors from "
+                         "every stream -- also in a world of ONE (what a single-GPU box can execute of configs[3])")
     args = ap.parse_args()
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
         args.no_cpu = True       # the CPU baseline / mAP-parity / PCIe legs are reported at N = 1 only
@@ -97,7 +100,9 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    vdist.init(backend=("gloo" if one_gpu else "nccl") if world > 1 else None, device=dev)
+    force_x = args.force_exchange and world == 1
+    vdist.init(backend=("gloo" if one_gpu else "nccl") if (world > 1 or force_x) else None, device=dev, force=force_x)
+    exch = {"events": [], "bytes": 0, "ok": True}      # per step: HIP events around the exchange on the step's stream
     F, B, C = args.frames, args.boxes, args.classes
     TOPK = 100
     TAPS = [0.25, 0.5, 0.25]     # the temporal convolution of the score volume (stand-in for the external TCN's first layer)
@@ -169,19 +174,25 @@ def main():
                 det, tpool, tboxes = ops.rescore_tracks(tracks, ntracks, vb, vs, overlap_thres=args.pool_thres,
                                                         window=args.window, sync=False, ctx=cx)
                 tub = (tracks, ntracks, tpool, tboxes)
-            if world > 1 and exchange:   # the one exchange step: RCCL all-gather of the per-video results over xGMI
+            if (world > 1 or force_x) and exchange:   # the one exchange step: RCCL all-gather of the per-video results over xGMI
                 # (same geometry on every rank: one fixed-shape collective per tensor, nothing the host
                 # has to wait for -- a count exchange would stall the multi-video pipeline)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
                 if tub is not None:
                     payload = torch.cat([tub[3].reshape(C, -1), tub[2].to(torch.float32).reshape(C, -1)], 1)
-                    gathered = (vdist.all_gather_fixed(payload), vdist.all_gather_fixed(keep_cnt))
+                    sent = (payload, keep_cnt)
                 else:
-                    top = keep_idx[:, :, :TOPK].contiguous()
-                    gathered = (vdist.all_gather_fixed(top), vdist.all_gather_fixed(torch.clamp(keep_cnt, max=TOPK)))
+                    sent = (keep_idx[:, :, :TOPK].contiguous(), torch.clamp(keep_cnt, max=TOPK))
+                gathered = (vdist.all_gather_fixed(sent[0], force=force_x), vdist.all_gather_fixed(sent[1], force=force_x))
+                e1.record()
+                exch["events"].append((e0, e1))
+                exch["bytes"] = sum(t.numel() * t.element_size() for t in sent)
+                exch["last"] = (sent, gathered)
         return keep_idx, keep_cnt, pooled, tub, conv
 
     def fence():
-        if world > 1:
+        if world > 1 or force_x:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -218,6 +229,18 @@ def main():
     dt = float(tmax.item())
     ms_per_step = dt / args.steps * 1e3
     boxes_per_s = world * F * B * args.steps / dt
+    exchange = None
+    if exch["events"]:
+        ev = exch["events"][-args.steps:]                     # the timed steps' exchanges (everything has completed: fence())
+        xms = [a.elapsed_time(b) for a, b in ev]
+        sent, got = exch["last"]
+        mine = all(torch.equal(g[rank].nan_to_num(-7.0), t_.nan_to_num(-7.0) if t_.dim() else t_[None].nan_to_num(-7.0))
+                   for t_, g in zip(sent, got))               # this rank's slot of the gathered result is what it sent
+        exchange = {"exchange_ms": sum(xms) / len(xms), "exchange_ms_max": max(xms),
+                    "payload_bytes_per_rank": exch["bytes"], "gathered_bytes_per_rank": exch["bytes"] * max(world, 1),
+                    "backend": dist.get_backend(), "world": dist.get_world_size(), "own_slot_matches": bool(mine),
+                    "note": "HIP events on the step's stream around the two all_gather_into_tensor calls (tubelet boxes + pooled "
+                            "scores, kept counts); the collectives run on RCCL's stream, ordered after the step's kernels"}
 
     # ---- per-kernel timing (HIP events on the kernels' stream), outside the timed region
     result = None
@@ -433,6 +456,51 @@ def main():
                 upload_src[0] = None
                 upload = {"error": str(e)[:200]}
 
+        # ---- caveats of `value`, measured here so that the line is self-contained (never part of `value`)
+        torch.cuda.synchronize()
+        n1 = max(6, nstreams * 2)
+        for _ in range(2):
+            step_no[0] = 0
+            step(exchange=False)
+        torch.cuda.synchronize()
+        t6 = time.perf_counter()
+        for _ in range(n1):
+            step_no[0] = 0          # always stream 0 / context 0: one video at a time, nothing overlaps
+            step(exchange=False)
+        torch.cuda.synchronize()
+        single_video_ms = (time.perf_counter() - t6) / n1 * 1e3
+        ctx.sync()
+        value_other = None
+        if not args.no_cpu:
+            # the other synthetic score distribution (another radix-digit / sub-bin pattern for the sort): same step
+            other = "randn" if args.scores == "rand" else "rand"
+            g = torch.Generator(device=dev).manual_seed(4242)
+            for vb_, vs_ in vids:
+                if other == "randn":
+                    vs_.normal_(generator=g)
+                else:
+                    vs_.uniform_(generator=g)
+            step_no[0] = 0
+            for _ in range(2 * nstreams):
+                step(exchange=False)
+            torch.cuda.synchronize()
+            no = max(args.steps // 2, 2 * nstreams)
+            t7 = time.perf_counter()
+            for _ in range(no):
+                step(exchange=False)
+            torch.cuda.synchronize()
+            odt = time.perf_counter() - t7
+            for cx in ctxs:
+                cx.sync()
+            value_other = {"scores": other, "value": F * B * no / odt, "ms_per_step": odt / no * 1e3, "steps": no}
+        hbm_total = None
+        pj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.isfile(pj):
+            try:
+                hbm_total = json.load(open(pj)).get("_per_video", None)
+            except Exception:
+                hbm_total = None
+
         result = {
             "metric": METRIC,
             "value": boxes_per_s, "unit": "boxes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -444,14 +512,19 @@ def main():
                                     "" if args.no_link else "; greedy tubelets: %d tracks/class (stop < %.2f), IoU-link "
                                     ">= %.2f, spatial max-pool IoU > %.2f + completion + temporal max-pool" %
                                     (args.max_tracks, args.track_thres, args.link_thres, args.pool_thres),
-                                    "; RCCL all-gather of the final tubelets + kept counts" if world > 1 else ""),
+                                    "; RCCL all-gather of the final tubelets + kept counts" if (world > 1 or force_x) else ""),
                        "frames": F, "boxes": B, "classes": C, "scores": args.scores,
                        "parallelism": "video-per-gpu x%d, %d distinct videos in flight per GPU%s" % (
                            world, nstreams, ", heavy phases gated one at a time" if args.gate == "heavy" and nstreams > 1 else "")},
+            "exchange": exchange,
+            "single_video_ms": single_video_ms,          # one video at a time (no videos in flight): the latency of one step
+            "value_other_scores": value_other,           # the same step on the other synthetic score distribution
+            "hbm_traffic_per_video": hbm_total,          # sum of the PMC table (profiles/pmc_traffic.json), all kernels of one step
+            "inputs": "HBM-resident (the PCIe-fed rate is upload_pipeline.boxes_per_s, never `value`)",
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_allcores": cpu_all, "map_parity": map_par, "pcie": pcie,
             "upload_pipeline": upload,
         }
-    if world > 1:
+    if world > 1 or force_x:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

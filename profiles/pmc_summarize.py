@@ -20,7 +20,10 @@ STAGES = [("iou_bits_sym_kernel", "iou_bits"), ("iou_bits_kernel", "iou_bits_gen
           ("sort_kernel", "sort"), ("walk_kernel", "walk"), ("volume_pass_kernel", "temporal"), ("temporal_both_vec4_kernel", "temporal"), ("temporal_vec4_kernel", "temporal"),
           ("transpose_keys_kernel", "transpose_keys"), ("track_pick_kernel", "track_pick"),
           ("track_link_kernel", "track_link"), ("track_suppress_kernel", "track_suppress"),
-          ("rescore_spatial_kernel", "rescore_spatial"), ("rescore_series_kernel", "rescore_series")]
+          ("rescore_spatial_kernel", "rescore_spatial"), ("rescore_series_kernel", "rescore_series"),
+          ("rescore_series_wave_kernel", "rescore_series"), ("rescore_adj_kernel", "rescore_adj"), ("track_loop_kernel", "track_loop"),
+          ("track_link_memo_kernel", "track_link"), ("track_warm_anchors_kernel", "track_warm"), ("binsort_kernel", "sort"),
+          ("sort_list_kernel", "sort_fallback")]
 
 
 def per_kernel(db, counter):
@@ -60,6 +63,16 @@ def main():
         fo.write("kernel,launches_sampled,fetch_KiB_per_launch_raw,write_KiB_per_launch,hbm_bytes_per_launch_corrected\n")
         for k, n, f, w, hbm in sorted(rows, key=lambda r: -r[4] * r[1]):
             fo.write('"%s",%d,%.1f,%.1f,%.0f\n' % (k, n, f, w, hbm))
+    # everything one video step moves: all launches of all vdet kernels / number of videos in the run (= launches of the
+    # volume pass, one per step)
+    nvid = max([n for k, n, f, w, hbm in rows if "volume_pass_kernel" in k] or [1])
+    total = sum(n * hbm for k, n, f, w, hbm in rows) / nvid
+    js["_per_video"] = {"hbm_bytes": total, "videos_sampled": nvid,
+                        "by_kernel_bytes": {k: n * hbm / nvid for k, n, f, w, hbm in sorted(rows, key=lambda r: -r[4] * r[1])},
+                        "algorithmic_bytes": 3216 * 300 * 10000, "note": "sum over all launches of one step (PMC FETCH_SIZE x 2 + WRITE_SIZE); "
+                        "algorithmic = 3216 B/box x 3 M boxes (config 2)"}
+    with open(out_csv, "a") as fo:
+        fo.write("# per video step: %.3f GB over %d videos sampled\n" % (total / 1e9, nvid))
     json.dump(js, open(out_json, "w"), indent=1)
     print(open(out_csv).read())
 

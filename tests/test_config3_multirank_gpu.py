@@ -3,7 +3,10 @@
     exchange over gloo (VDET_BENCH_ONE_GPU=1): barriers, the all-gather inside the timed step, MAX over ranks;
 (b) eight "virtual ranks" in one process: shard_round_robin / shard_lpt + per-video results + the gather
     reproduce the serial result for 11 videos of different sizes.
-The RCCL transport itself (one rank per GPU over xGMI) needs the driver's multi-GPU node."""
+(c) the RCCL transport itself, as far as one GPU goes: a world of ONE rank with backend "nccl" -- process group with
+    device_id, RCCL communicator, all_gather_into_tensor of device tensors issued from bench.py's three streams inside
+    the timed step, and vdetlib_amd.dist's ragged gather on device tensors.  Eight ranks over xGMI need the driver's
+    multi-GPU node."""
 import json
 import os
 import subprocess
@@ -33,6 +36,82 @@ def test_bench_two_ranks_one_gpu_dry_run():
     assert "all-gather" in r["config"]["workload"]
 
 
+def test_rccl_exchange_executes_in_a_world_of_one():
+    """bench.py --force-exchange under torch.distributed.run with ONE rank: init_process_group("nccl", device_id=...),
+    the fixed-shape all-gathers of the tubelet payload and the kept counts from every stream in flight, inside the timed
+    step; the gathered slot equals what was sent; the line carries the exchange time and bytes."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29549", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "3",
+           "--frames", "12", "--boxes", "2000", "--classes", "16", "--no-cpu", "--force-exchange"]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    r = json.loads(lines[0])
+    x = r["exchange"]
+    assert x["backend"] == "nccl" and x["world"] == 1 and x["own_slot_matches"] is True
+    assert x["exchange_ms"] > 0 and x["payload_bytes_per_rank"] > 0
+    assert "all-gather" in r["config"]["workload"] and r["n_gpus"] == 1
+
+
+def test_rccl_ragged_gather_of_device_tensors():
+    """vdetlib_amd.dist on the RCCL backend (world of one, forced): counts + padded payload of DEVICE tensors, an empty
+    contribution, and gather_video_results == the local results."""
+    import torch
+    import torch.distributed as dist
+    from vdetlib_amd import dist as vd
+    assert not dist.is_initialized()
+    old = {k: os.environ.get(k) for k in ("MASTER_ADDR", "MASTER_PORT", "WORLD_SIZE", "RANK")}
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29551", WORLD_SIZE="1", RANK="0")
+    try:
+        dev = torch.device("cuda", torch.cuda.current_device())
+        vd.init(backend="nccl", device=dev, force=True)
+        assert dist.get_backend() == "nccl"
+        t = torch.arange(12, dtype=torch.float32, device=dev).reshape(4, 3)
+        parts = vd.all_gather_ragged(t, force=True)
+        assert len(parts) == 1 and torch.equal(parts[0], t)
+        empty = vd.all_gather_ragged(torch.zeros((0, 5), dtype=torch.int32, device=dev), force=True)
+        assert len(empty) == 1 and tuple(empty[0].shape) == (0, 5)
+        g = vd.all_gather_fixed(t, force=True)
+        assert tuple(g.shape) == (1, 4, 3) and torch.equal(g[0], t)
+        idx = torch.randint(0, 100, (3, 2, 4, 5), dtype=torch.int32, device=dev)
+        cnt = torch.randint(0, 6, (3, 2, 4), dtype=torch.int32, device=dev)
+        res = vd.gather_video_results([7, 2, 9], idx, cnt, force=True)
+        assert sorted(res) == [2, 7, 9]
+        for k, v in enumerate([7, 2, 9]):
+            assert torch.equal(res[v][0], idx[k]) and torch.equal(res[v][1], cnt[k])
+        torch.cuda.synchronize()
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _gather_worker(rank, world, port, owners, serial, ret):
+    """one gloo rank: contributes the results of the videos it owns, must end up with everybody's"""
+    import torch
+    import torch.distributed as dist
+    from vdetlib_amd import dist as vd
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank))
+    vd.init(backend="gloo")
+    mine = owners[rank]
+    shape_i, shape_c = next(iter(serial.values()))[0].shape, next(iter(serial.values()))[1].shape
+    idx = torch.from_numpy(np.stack([serial[v][0] for v in mine])) if mine else torch.zeros((0,) + shape_i, dtype=torch.int32)
+    cnt = torch.from_numpy(np.stack([serial[v][1] for v in mine])) if mine else torch.zeros((0,) + shape_c, dtype=torch.int32)
+    res = vd.gather_video_results(mine, idx, cnt)
+    ok = sorted(res) == sorted(v for o in owners for v in o)
+    for v in res:
+        ok = ok and np.array_equal(res[v][0].numpy(), serial[v][0]) and np.array_equal(res[v][1].numpy(), serial[v][1])
+    ret[rank] = bool(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def test_eight_virtual_ranks_reproduce_the_serial_result():
     import torch
     from vdetlib_amd import ops, dist as vd
@@ -50,22 +129,31 @@ def test_eight_virtual_ranks_reproduce_the_serial_result():
 
     serial = {v: run(v) for v in range(len(vids))}
     world = 8
+    lpt_owners = vd.shard_lpt([f * b for f, b in shapes], world)
     for owners in ([vd.shard_round_robin(len(vids), r, world) for r in range(world)],
-                   vd.shard_lpt([f * b for f, b in shapes], world)):
-        assert sorted(v for o in owners for v in o) == list(range(len(vids)))       # a partition
+                   lpt_owners,
+                   [[0, 3], [], [5, 1, 2], [], [], [4], [], []]):                   # ranks without a video
+        if len(sum(owners, [])) == len(vids):
+            assert sorted(v for o in owners for v in o) == list(range(len(vids)))   # a partition
         per_rank = []
         for mine in owners:
             res = [run(v) for v in mine]
             per_rank.append((mine, torch.stack([a for a, _ in res]) if res else torch.zeros((0, 6, C, K), dtype=torch.int32, device='cuda'),
                              torch.stack([b for _, b in res]) if res else torch.zeros((0, 6, C), dtype=torch.int32, device='cuda')))
-        # what all_gather_ragged delivers on every rank = the per-rank tensors in rank order
-        merged = {}
-        for mine, gi, gc in per_rank:
-            for k, v in enumerate(mine):
-                merged[v] = (gi[k], gc[k])
-        assert sorted(merged) == sorted(serial)
-        for v in serial:
-            assert torch.equal(merged[v][0], serial[v][0]) and torch.equal(merged[v][1], serial[v][1])
+        # the exchange itself: eight gloo ranks, each contributing what it owns (ragged, possibly nothing) through
+        # dist.gather_video_results; every rank must end up with every video's serial result
+        import socket
+        import torch.multiprocessing as mp
+        host = {v: (serial[v][0].cpu().numpy(), serial[v][1].cpu().numpy()) for v in serial}
+        for k, (mine, gi, gc) in enumerate(per_rank):          # (what the rank computed on the GPU is what it will send)
+            for j, v in enumerate(mine):
+                assert torch.equal(gi[j], serial[v][0]) and torch.equal(gc[j], serial[v][1])
+        if owners is lpt_owners:
+            continue                                             # (two of the three shardings go through the process group)
+        sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+        ret = mp.Manager().dict()
+        mp.spawn(_gather_worker, args=(world, port, [list(o) for o in owners], host, ret), nprocs=world, join=True)
+        assert dict(ret) == {r: True for r in range(world)}
     lpt = vd.shard_lpt([f * b for f, b in shapes], world)
     loads = [sum(shapes[v][0] * shapes[v][1] for v in o) for o in lpt]
     rr = [sum(shapes[v][0] * shapes[v][1] for v in vd.shard_round_robin(len(vids), r, world)) for r in range(world)]

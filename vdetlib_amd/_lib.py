@@ -180,7 +180,7 @@ class Context(object):
         self.check(self.lib.vdet_last_launches(self.h, n))
         names = ["iou_bits", "adj_build", "sort", "walk", "temporal", "merge_sort", "iou_bits_general", "other",
                  "transpose_keys", "track_pick", "track_link", "track_suppress", "rescore_spatial", "rescore_series",
-                 "sort_fallback", "_15"]
+                 "sort_fallback", "track_loop"]
         return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(names)}
 
 

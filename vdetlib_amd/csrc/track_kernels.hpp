@@ -109,16 +109,17 @@ struct ResolveArgs {           // the materialised warm chains (null chains: non
     int32_t *nodes;
 };
 
-__global__ __launch_bounds__(256) void track_pick_kernel(const uint32_t *__restrict__ keys, uint16_t *lists,
-                                                         const int32_t *__restrict__ cnt, int F, int B, int C,
-                                                         const float *__restrict__ scores, double thres, int max_tracks,
-                                                         TrackState *__restrict__ st, float *__restrict__ anchors,
-                                                         const LazyLists lz, const ResolveArgs rv)
+// (block-uniform control flow: every early return below is taken by the whole block)
+__device__ __forceinline__ void track_pick_body(const int c, const uint32_t *__restrict__ keys, uint16_t *lists,
+                                                const int32_t *__restrict__ cnt, int F, int B, int C,
+                                                const float *__restrict__ scores, double thres, int max_tracks,
+                                                TrackState *__restrict__ st, float *__restrict__ anchors,
+                                                const LazyLists &lz, const ResolveArgs &rv)
 {
     __shared__ uint32_t sk[256];
     __shared__ int sf[256];
     __shared__ int sslot;
-    const int c = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     TrackState s = st[c];
     if (!s.active) return;
     uint32_t bk = 0;
@@ -246,6 +247,15 @@ __global__ __launch_bounds__(256) void track_pick_kernel(const uint32_t *__restr
         for (int i = tid; i < F; i += 256) nd[i] = ns[i];
     }
     if (tid == 0) st[c].resolved = 1;
+}
+
+__global__ __launch_bounds__(256) void track_pick_kernel(const uint32_t *__restrict__ keys, uint16_t *lists,
+                                                         const int32_t *__restrict__ cnt, int F, int B, int C,
+                                                         const float *__restrict__ scores, double thres, int max_tracks,
+                                                         TrackState *__restrict__ st, float *__restrict__ anchors,
+                                                         const LazyLists lz, const ResolveArgs rv)
+{
+    track_pick_body(blockIdx.x, keys, lists, cnt, F, B, C, scores, thres, max_tracks, st, anchors, lz, rv);
 }
 
 // IoU of the current track box (as the "i" box) with a proposal (as "j"), utils/nms.pyx arithmetic
@@ -514,14 +524,15 @@ __device__ __forceinline__ unsigned long long memo_load(const unsigned long long
 // MODE 2: materialise (anchor = warm[blockIdx.x], rows into chain slot blockIdx.x of `tracks` / `nodes`): run once after
 //         the warm-up, when every step of these chains is known -- the tracking loop then COPIES a predicted anchor's
 //         tubelet (the tail of track_pick_kernel) instead of walking its ~300 dependent steps again, track after track
+// chain = the class (MODE 0) or the warm-chain slot (MODE 1 / 2); dir = +1 / -1
 template <int LT, int MODE, int MAXB>
-__global__ __launch_bounds__(LT, (MODE == 1 && LT == 256 && MAXB == 8) ? 5 : 1) void track_link_memo_kernel(const float4 *__restrict__ boxes, int F, int B, int max_tracks,
-                                                             float link_t32, int reach, const TrackState *__restrict__ st,
-                                                             float *__restrict__ tracks,
-                                                             const uint32_t *__restrict__ group_flags,
-                                                             const FrameIndex ix, double link_thres,
-                                                             unsigned long long *memo, unsigned int *__restrict__ stats,
-                                                             const int32_t *__restrict__ warm, int32_t *__restrict__ nodes)
+__device__ __forceinline__ void track_link_memo_body(const int chain, const int dir, const float4 *__restrict__ boxes, int F, int B, int max_tracks,
+                                                     float link_t32, int reach, const TrackState *__restrict__ st,
+                                                     float *__restrict__ tracks,
+                                                     const uint32_t *__restrict__ group_flags,
+                                                     const FrameIndex &ix, double link_thres,
+                                                     unsigned long long *memo, unsigned int *__restrict__ stats,
+                                                     const int32_t *__restrict__ warm, int32_t *__restrict__ nodes)
 {
     __shared__ float sv[2][LT / 64];
     __shared__ int si[2][LT / 64];
@@ -532,17 +543,16 @@ __global__ __launch_bounds__(LT, (MODE == 1 && LT == 256 && MAXB == 8) ? 5 : 1) 
     constexpr int NPF = (260 + LT - 1) / LT;
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int dir = blockIdx.y == 0 ? 1 : -1;
     int anchor_frame, anchor_box;
     float *trk = nullptr;
     constexpr bool WARM = MODE == 1;
     if (MODE != 0) {
-        const int flat = warm[blockIdx.x];
+        const int flat = warm[chain];
         if (flat < 0) return;
         anchor_frame = flat / B;
         anchor_box = flat - anchor_frame * B;
     } else {
-        const int c = blockIdx.x;
+        const int c = chain;
         const TrackState s = st[c];
         if (!s.active || s.resolved) return;
         anchor_frame = s.anchor_frame;
@@ -550,12 +560,12 @@ __global__ __launch_bounds__(LT, (MODE == 1 && LT == 256 && MAXB == 8) ? 5 : 1) 
     }
     if (MODE != 1) {
         if (MODE == 0) {
-            const TrackState s = st[blockIdx.x];
-            trk = tracks + ((int64_t)blockIdx.x * max_tracks + s.ntracks) * F * 5;
-            if (nodes) nodes += ((int64_t)blockIdx.x * max_tracks + s.ntracks) * F;      // which proposal each row of the track is
+            const TrackState s = st[chain];
+            trk = tracks + ((int64_t)chain * max_tracks + s.ntracks) * F * 5;
+            if (nodes) nodes += ((int64_t)chain * max_tracks + s.ntracks) * F;      // which proposal each row of the track is
         } else {
-            trk = tracks + (int64_t)blockIdx.x * F * 5;
-            if (nodes) nodes += (int64_t)blockIdx.x * F;
+            trk = tracks + (int64_t)chain * F * 5;
+            if (nodes) nodes += (int64_t)chain * F;
         }
         const float qnan = __uint_as_float(0x7FC00000u);
         if (dir > 0) { for (int i = anchor_frame * 5 + tid; i < F * 5; i += LT) trk[i] = qnan; }
@@ -714,6 +724,19 @@ __global__ __launch_bounds__(LT, (MODE == 1 && LT == 256 && MAXB == 8) ? 5 : 1) 
         node = bidx; fprev = f; ++step;
     }
     if (stats && tid == 0) { atomicAdd(&stats[WARM ? 2 : 0], nhit); atomicAdd(&stats[WARM ? 3 : 1], nmiss); }
+}
+
+template <int LT, int MODE, int MAXB>
+__global__ __launch_bounds__(LT, (MODE == 1 && LT == 256 && MAXB == 8) ? 5 : 1) void track_link_memo_kernel(const float4 *__restrict__ boxes, int F, int B, int max_tracks,
+                                                             float link_t32, int reach, const TrackState *__restrict__ st,
+                                                             float *__restrict__ tracks,
+                                                             const uint32_t *__restrict__ group_flags,
+                                                             const FrameIndex ix, double link_thres,
+                                                             unsigned long long *memo, unsigned int *__restrict__ stats,
+                                                             const int32_t *__restrict__ warm, int32_t *__restrict__ nodes)
+{
+    track_link_memo_body<LT, MODE, MAXB>(blockIdx.x, blockIdx.y == 0 ? 1 : -1, boxes, F, B, max_tracks, link_t32, reach, st, tracks,
+                                         group_flags, ix, link_thres, memo, stats, warm, nodes);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -980,6 +1003,70 @@ __global__ void track_init_kernel(TrackState *__restrict__ st, int C)
     TrackState s;
     s.active = 1; s.ntracks = 0; s.last_key = 0; s.last_flat = -1; s.anchor_frame = 0; s.anchor_box = 0; s.anchor_score = 0.f; s.resolved = 0;
     st[c] = s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The whole tracking loop of vdet/track.py:207-252 in ONE launch (round 3).  Nothing in an iteration of that loop
+// crosses classes -- the anchor, the tubelet, the lists it suppresses and the stop rule all belong to one class; the
+// only shared object is the link memo, whose entries are deterministic -- so one persistent block per class runs
+// pick -> (copy | link forward, link backward) -> suppress (irregular frames only) -> commit for all max_tracks
+// iterations without returning to the host queue: 1 launch instead of 4 per track, and no block waits for the
+// slowest class of its iteration.  Same device functions as the per-iteration kernels, in the same order per class:
+// bit-identical results (VDET_TRACK_LOOP=0 selects the per-iteration launches; tested against each other).
+// block = 256; dynamic LDS = 4 dead masks of sp.mask_words words (track_suppress_list).
+// ------------------------------------------------------------------------------------------------
+struct LoopArgs {
+    const uint32_t *keys;
+    uint16_t *lists;
+    const int32_t *cnt;
+    const float *scores;
+    double thres, link_thres;
+    float *anchors;
+    float link_t32;
+    int reach;
+    unsigned long long *memo;
+    unsigned int *stats;
+    int32_t *nodes;
+    int32_t *ntracks_out;
+    int need_suppress;
+};
+
+__global__ __launch_bounds__(256) void track_loop_kernel(const LoopArgs a, const LazyLists lz, const ResolveArgs rv, const SuppressParams sp)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int F = sp.F, B = sp.B, C = sp.C, T = sp.max_tracks;
+    TrackState *st = const_cast<TrackState *>(sp.st);
+    for (int t = 0; t < T; ++t) {
+        track_pick_body(c, a.keys, a.lists, a.cnt, F, B, C, a.scores, a.thres, T, st, a.anchors, lz, rv);
+        __threadfence_block();
+        __syncthreads();
+        const TrackState s = st[c];
+        if (!s.active) break;
+        if (!s.resolved) {     // the anchor was not among the materialised warm chains: walk its two half tubelets here
+            track_link_memo_body<256, 0, 8>(c, 1, sp.boxes, F, B, T, a.link_t32, a.reach, st, const_cast<float *>(sp.tracks),
+                                            sp.group_flags, sp.ix, a.link_thres, a.memo, a.stats, nullptr, a.nodes);
+            __syncthreads();
+            track_link_memo_body<256, 0, 8>(c, -1, sp.boxes, F, B, T, a.link_t32, a.reach, st, const_cast<float *>(sp.tracks),
+                                            sp.group_flags, sp.ix, a.link_thres, a.memo, a.stats, nullptr, a.nodes);
+        }
+        __threadfence_block();
+        __syncthreads();
+        if (a.need_suppress && !(sp.lazy && sp.group_flags && *sp.n_irregular == 0)) {
+            // eager track_det_nms of this class's lists on the frames the pick does not maintain (irregular frames)
+            lds_mask_t mask = lds_mask_ptr(smem, w * sp.mask_words);
+            for (int f = w; f < F; f += 4) {
+                track_suppress_list(sp, mask, lane, f * C + c);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            }
+            __threadfence_block();
+            __syncthreads();
+        }
+        if (tid == 0) st[c].ntracks = s.ntracks + 1;        // track_commit_kernel
+        __threadfence_block();
+        __syncthreads();
+    }
+    if (tid == 0) a.ntracks_out[c] = st[c].ntracks;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -53,7 +53,7 @@ struct DevBuf {
 };
 
 enum Stage { ST_IOU_BITS = 0, ST_ADJ = 1, ST_SORTK = 2, ST_WALK = 3, ST_TEMPORAL = 4, ST_SORT = 5, ST_IOU_GEN = 6, ST_OTHER = 7,
-             ST_TRANSPOSE = 8, ST_TPICK = 9, ST_TLINK = 10, ST_TSUPP = 11, ST_RSPATIAL = 12, ST_RSERIES = 13, ST_SORTFB = 14, ST_COUNT = 16 };
+             ST_TRANSPOSE = 8, ST_TPICK = 9, ST_TLINK = 10, ST_TSUPP = 11, ST_RSPATIAL = 12, ST_RSERIES = 13, ST_SORTFB = 14, ST_TLOOP = 15, ST_COUNT = 16 };
 
 struct Counters {            // one small device block
     // sticky until vdet_sync (or a synchronous graph build) reads and clears them
@@ -146,6 +146,8 @@ struct vdet_ctx {
     bool wmeta_built = false;     // ... which also wrote the packed walk's records (WalkMeta) of the regular frames
     bool walk_careful = false;    // VDET_WALK_CAREFUL=1: per-survivor bookkeeping also on regular frames (A-B knob / tests)
     bool link_memo = true;        // VDET_LINK_MEMO=0: every link step scans (A-B knob / tests)
+    bool track_loop = true;       // VDET_TRACK_LOOP=0: four launches per track (pick / link / suppress / commit) instead of one persistent
+                                  // block per class for the whole tracking loop (A-B knob / tests)
     bool binsort = false;         // VDET_BINSORT=1: untied volume columns by the equalised counting sort (binsort_kernels.hpp) instead of the
                                   // LSD radix kernel.  Bit-identical; measured at the LSD kernel's speed (3.32 vs 3.37 ms per c2 video), so off
     bool last_sort_binned = false;   // the last per-(frame, class) sort went through binsort_kernel (vdet_query 9)
@@ -836,6 +838,7 @@ int vdet_create(vdet_ctx **out, int device)
     if (const char *e = getenv("VDET_RESCORE_ADJ")) c->rescore_adj = atoi(e) != 0;
     if (const char *e = getenv("VDET_LINK_MEMO")) c->link_memo = atoi(e) != 0;
     if (const char *e = getenv("VDET_BINSORT")) c->binsort = atoi(e) != 0;
+    if (const char *e = getenv("VDET_TRACK_LOOP")) c->track_loop = atoi(e) != 0;
     if (const char *e = getenv("VDET_LINK_WARM")) c->link_warm = atoi(e);
     if (const char *e = getenv("VDET_LINK_MAXB")) c->link_maxb = atoi(e) == 16 ? 16 : 8;
     if (const char *e = getenv("VDET_AUX_STREAM")) c->use_aux = atoi(e) != 0;
@@ -1452,6 +1455,18 @@ int vdet_nms_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scor
     if (materialized)      // predicted anchors: their tubelets exist already, the pick kernel copies them
         rv = ResolveArgs{c->linkwarm.as<int32_t>(), materialized, c->linkchains.as<float>(), c->linknodes.as<int32_t>(), d_tracks,
                          c->tracknode.as<int32_t>()};
+    if (c->track_loop && c->link_memo && c->link_threads == 256 && !c->debug_sync && max_tracks > 0) {
+        // the whole loop in one launch: one persistent block per class (track_loop_kernel)
+        LoopArgs la{};
+        la.keys = c->tkeys.as<uint32_t>(); la.lists = c->order.as<uint16_t>(); la.cnt = c->ncand.as<int32_t>();
+        la.scores = d_scores; la.thres = thres; la.link_thres = link_thres; la.anchors = d_anchors;
+        la.link_t32 = link_t32; la.reach = reach;
+        la.memo = c->linkmemo.as<unsigned long long>(); la.stats = c->linkstats.as<unsigned int>();
+        la.nodes = c->tracknode.as<int32_t>(); la.ntracks_out = d_ntracks;
+        la.need_suppress = need_suppress ? 1 : 0;
+        StageTimer tm(c, ST_TLOOP);
+        hipLaunchKernelGGL(track_loop_kernel, dim3((unsigned)C), dim3(256), (size_t)sp.mask_words * 16, c->stream, la, lz, rv, sp);
+    } else
     for (int t = 0; t < max_tracks; ++t) {
         {
             StageTimer tm(c, ST_TPICK);

@@ -16,11 +16,16 @@ def env_world():
     return int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
-def init(backend=None, device=None):
-    """Initialise torch.distributed from the torchrun environment (no-op for a single process)."""
+def init(backend=None, device=None, force=False):
+    """Initialise torch.distributed from the torchrun environment (no-op for a single process, unless ``force``:
+    a world of ONE still gets its process group -- and with backend "nccl" its RCCL communicator -- so that the
+    exchange step can be executed on a single-GPU box exactly as it runs on eight)."""
     world, rank, local = env_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        os.environ.setdefault("RANK", "0")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this driver
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
@@ -59,14 +64,19 @@ def class_slice(n_classes, rank, world):
     return c0, c0 + per + (1 if rank < rem else 0)
 
 
-def all_gather_ragged(t, group=None):
+def _collective(group, force):
+    """Is there a collective to run?  (a world of one only when the caller insists: ``force``)"""
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force)
+
+
+def all_gather_ragged(t, group=None, force=False):
     """All-gather tensors whose first dimension differs per rank: counts first, then one padded
     fixed-capacity payload (a single large collective instead of many small ones -- xGMI rings are
     per-link bound).  Returns the list of per-rank tensors (on every rank)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not _collective(group, force):
         return [t]
     if _stage_on_host(t, group):
-        return [p.to(t.device) for p in all_gather_ragged(t.cpu(), group)]
+        return [p.to(t.device) for p in all_gather_ragged(t.cpu(), group, force)]
     world = dist.get_world_size(group)
     n = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
     counts = torch.empty(world, dtype=torch.int64, device=t.device)
@@ -86,34 +96,34 @@ def _stage_on_host(t, group):
     return t.is_cuda and dist.get_backend(group) == "gloo"
 
 
-def all_gather_fixed(t, group=None):
+def all_gather_fixed(t, group=None, force=False):
     """All-gather of same-shape tensors (every rank holds one video of the same geometry): ONE
     collective, no count exchange and therefore no host synchronisation -- the call only enqueues, so
     a rank can keep several videos in flight on different streams.  Returns [world, *t.shape]."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not _collective(group, force):
         return t[None]
     world = dist.get_world_size(group)
     t = t.contiguous()
     if t.dim() == 0:
         t = t[None]
     if _stage_on_host(t, group):
-        return all_gather_fixed(t.cpu(), group).to(t.device)
+        return all_gather_fixed(t.cpu(), group, force).to(t.device)
     # concatenated layout along dim 0 (accepted by both RCCL and gloo), viewed as [world, ...]
     out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
     dist.all_gather_into_tensor(out, t, group=group)
     return out.view((world,) + tuple(t.shape))
 
 
-def gather_video_results(video_ids, keep_idx, keep_cnt, group=None):
+def gather_video_results(video_ids, keep_idx, keep_cnt, group=None, force=False):
     """Combine per-video NMS results across ranks.
 
     video_ids: list of the global ids of this rank's videos; keep_idx [V,F,C,K] int32 and
     keep_cnt [V,F,C] int32 for those videos (same F,C,K on all ranks).  Returns
     {video_id: (keep_idx [F,C,K], keep_cnt [F,C])} for ALL videos, on every rank."""
     ids = torch.tensor(video_ids, dtype=torch.int64, device=keep_idx.device).reshape(-1)
-    g_ids = all_gather_ragged(ids, group)
-    g_idx = all_gather_ragged(keep_idx, group)
-    g_cnt = all_gather_ragged(keep_cnt, group)
+    g_ids = all_gather_ragged(ids, group, force)
+    g_idx = all_gather_ragged(keep_idx, group, force)
+    g_cnt = all_gather_ragged(keep_cnt, group, force)
     out = {}
     for r in range(len(g_ids)):
         for k, vid in enumerate(g_ids[r].tolist()):

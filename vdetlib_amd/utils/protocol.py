@@ -44,21 +44,29 @@ def proto_load(file_path):
         return json.load(f)
 
 
+def _json_text(obj):
+    return json.dumps(obj, indent=2)
+
+
 def proto_dump(obj, file_path):
-    """:223-236 -- ``json.dumps(obj, indent=2)``; gzip level 1 when the name ends in .gz, falling
-    back to a plain file (name without .gz) if the buffer exceeds what gzip can take."""
-    if os.path.splitext(file_path)[1] == '.gz':
+    """Contract of :223-236: the protocol as JSON text with two-space indentation; a name ending in ``.gz`` is written
+    gzip-compressed at level 1 -- unless gzip refuses the buffer (OverflowError: more than it can frame), in which case
+    whatever was started is removed and the text goes, uncompressed, to the same name without ``.gz``."""
+    text = _json_text(obj)
+    stem_path, ext = os.path.splitext(file_path)
+    target = file_path
+    if ext == '.gz':
         try:
-            with gzip.GzipFile(file_path, 'w', 1) as f:
-                f.write(json.dumps(obj, indent=2).encode('utf-8'))
-                return
+            with gzip.GzipFile(file_path, mode='w', compresslevel=1) as gz:
+                gz.write(text.encode('utf-8'))
+            return
         except OverflowError:
-            print("Buffer exceeds 2GB, fallback to regular file.")
+            print("{}: too large for gzip, writing {} uncompressed instead.".format(file_path, stem_path))
             if os.path.isfile(file_path):
                 os.remove(file_path)
-            file_path = os.path.splitext(file_path)[0]
-    with open(file_path, 'w') as f:
-        json.dump(obj, f, indent=2)
+            target = stem_path
+    with open(target, 'w') as out:
+        out.write(text)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -246,25 +254,38 @@ def tubelets_proto_from_tracks_proto(tracks_proto, class_index):
     return tubelets
 
 
+def _annotated_boxes_by_frame(annot_proto, class_index):
+    """frame -> ground-truth bboxes of ``class_index``.  A track contributes its boxes up to (not including) the first
+    one of another class -- the reference leaves a track at the first class mismatch (:474-478)."""
+    by_frame = {}
+    for annot_track in annot_proto['annotations']:
+        for annot_box in annot_track['track']:
+            if annot_box['class_index'] != class_index:
+                break
+            by_frame.setdefault(annot_box['frame'], []).append(annot_box['bbox'])
+    return by_frame
+
+
 def tubelets_overlap(tubelets_proto, annot_proto, class_idx):
-    """:467-489 -- best same-class ground-truth IoU per tubelet box ('gt_overlap', in place); a
-    tubelet whose mean overlap is 1 (within float eps) is flagged gt=1.  Only the FIRST box of an
-    annotation track is class-checked (the reference breaks out of the track on a mismatch)."""
+    """Contract of :467-489, in place: every tubelet box gets ``gt_overlap`` = its best IoU with a same-frame
+    ground-truth box of the tubelet's class (the integer 0 when nothing overlaps), and a tubelet whose boxes all coincide
+    with ground truth (mean overlap 1 up to float eps) is flagged ``gt = 1``.  ``class_idx`` is unused, as in the
+    reference (each tubelet carries its own class)."""
+    gt_cache = {}
     for tubelet in tubelets_proto:
-        class_index = tubelet['class_index']
+        cls = tubelet['class_index']
+        if cls not in gt_cache:
+            gt_cache[cls] = _annotated_boxes_by_frame(annot_proto, cls)
+        overlaps = []
         for tubelet_box in tubelet['boxes']:
-            tubelet_box['gt_overlap'] = 0
-            for annot_track in annot_proto['annotations']:
-                for annot_box in annot_track['track']:
-                    if annot_box['class_index'] != class_index:
-                        break
-                    if tubelet_box['frame'] == annot_box['frame']:
-                        cur_iou = float(iou([annot_box['bbox']], [tubelet_box['bbox']]).ravel()[0])
-                        if 'gt_overlap' not in tubelet_box or cur_iou > tubelet_box['gt_overlap']:
-                            tubelet_box['gt_overlap'] = cur_iou
-        ious = [box['gt_overlap'] for box in tubelet['boxes']]
-        mean_iou = np.asarray(ious).mean()
-        if abs(mean_iou - 1) < np.finfo(float).eps:
+            best = 0
+            for gt_bbox in gt_cache[cls].get(tubelet_box['frame'], ()):
+                value = float(iou([gt_bbox], [tubelet_box['bbox']]).ravel()[0])
+                if value > best:
+                    best = value
+            tubelet_box['gt_overlap'] = best
+            overlaps.append(best)
+        if abs(np.asarray(overlaps).mean() - 1) < np.finfo(float).eps:
             tubelet['gt'] = 1
     return tubelets_proto
 
@@ -283,28 +304,33 @@ def tubelet_box_proto_at_frame(tubelet, frame_id):
     return None
 
 
+def _assert_same(first, second, keys):
+    for key in keys:
+        assert first[key] == second[key]
+
+
 def merge_score_protos(proto_1, proto_2, scheme='combine'):
-    """:504-525 -- shallow copy of proto_1: 'combine' EXTENDS proto_1's tubelet list in place,
-    'max' overwrites proto_1's boxes in place where proto_2 scores higher."""
+    """Contract of :504-525.  The result is a SHALLOW copy of proto_1 (its tubelet list and boxes are proto_1's own
+    objects -- the reference's aliasing, which callers rely on): the method names are joined with '_' when they
+    differ; 'combine' appends proto_2's tubelets to that shared list; 'max' walks both protos tubelet by tubelet and
+    box by box (same gt / class / frame / anchor asserted) and, wherever proto_2's box has the higher det_score,
+    overwrites the fields proto_1's box has with copies of proto_2's."""
     assert scheme in ['combine', 'max']
     assert proto_1['video'] == proto_2['video']
-    new_proto = copy.copy(proto_1)
-    if proto_1['method'] != proto_2['method']:
-        new_proto['method'] = '_'.join([proto_1['method'], proto_2['method']])
+    merged = copy.copy(proto_1)
+    methods = [proto_1['method'], proto_2['method']]
+    if methods[0] != methods[1]:
+        merged['method'] = '_'.join(methods)
     if scheme == 'combine':
-        new_proto['tubelets'].extend(copy.copy(proto_2['tubelets']))
-    else:
-        for tubelet1, tubelet2 in zip(new_proto['tubelets'], proto_2['tubelets']):
-            assert tubelet1['gt'] == tubelet2['gt']
-            assert tubelet1['class'] == tubelet2['class']
-            assert tubelet1['class_index'] == tubelet2['class_index']
-            for box1, box2 in zip(tubelet1['boxes'], tubelet2['boxes']):
-                assert box1['frame'] == box2['frame']
-                assert box1['anchor'] == box2['anchor']
-                if box1['det_score'] < box2['det_score']:
-                    for key in box1:
-                        box1[key] = copy.copy(box2[key])
-    return new_proto
+        merged['tubelets'] += list(proto_2['tubelets'])
+        return merged
+    for mine, other in zip(merged['tubelets'], proto_2['tubelets']):
+        _assert_same(mine, other, ('gt', 'class', 'class_index'))
+        for box, rival in zip(mine['boxes'], other['boxes']):
+            _assert_same(box, rival, ('frame', 'anchor'))
+            if rival['det_score'] > box['det_score']:
+                box.update({key: copy.copy(rival[key]) for key in list(box)})
+    return merged
 
 
 def _det_file_for(frame, det_dir):

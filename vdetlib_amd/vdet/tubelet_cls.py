@@ -135,27 +135,32 @@ def dets_spatial_max_pooling(vid_proto, track_proto, det_proto, class_idx, overl
     return score_proto
 
 
+def _class_dets_by_frame(det_proto, class_idx):
+    """frame -> (bboxes [n,4], class scores [n]) of a det_proto, detections in protocol order"""
+    grouped = defaultdict(lambda: ([], []))
+    for det in det_proto['detections']:
+        bboxes, scores = grouped[det['frame']]
+        bboxes.append(det['bbox'])
+        scores.append(det['scores'][class_idx - 1]['score'])
+    return {frame: (np.asarray(bb), np.asarray(sc)) for frame, (bb, sc) in grouped.items()}
+
+
 def anchor_propagate(vid_proto, track_proto, det_proto, class_idx):
-    """:353-383 -- every box of a tubelet gets the class score of the detection that overlaps the
-    anchor box (anchor == 0) most."""
+    """Contract of :353-383: a tubelet's anchor is its one box with ``anchor == 0``; the detection of that frame that
+    overlaps the anchor box most (first one on ties) lends its ``class_idx`` score to EVERY box of the tubelet."""
     assert vid_proto['video'] == track_proto['video']
     tubelets_proto = tubelets_proto_from_tracks_proto(track_proto['tracks'], class_idx)
     logging.info("Propagating anchor scores in {} for {}...".format(vid_proto['video'],
                                                                      imagenet_vdet_classes[class_idx]))
-    frame_to_det_idx = defaultdict(list)
-    for i, det in enumerate(det_proto['detections']):
-        frame_to_det_idx[det['frame']].append(i)
+    dets = _class_dets_by_frame(det_proto, class_idx)
+    empty = (np.asarray([]), np.asarray([]))
     for tubelet in tubelets_proto:
-        anchor_box = [box for box in tubelet['boxes'] if box['anchor'] == 0]
-        assert len(anchor_box) == 1
-        anchor_box = anchor_box[0]
-        det_idx = frame_to_det_idx[anchor_box['frame']]
-        det_boxes = np.asarray([det_proto['detections'][i]['bbox'] for i in det_idx])
-        det_scores = np.asarray([det_proto['detections'][i]['scores'][class_idx - 1]['score'] for i in det_idx])
-        overlaps = iou([anchor_box['bbox']], det_boxes)[0]
-        anchor_score = det_scores[np.argmax(overlaps)]
+        anchors = [box for box in tubelet['boxes'] if box['anchor'] == 0]
+        assert len(anchors) == 1
+        det_boxes, det_scores = dets.get(anchors[0]['frame'], empty)
+        best = int(np.argmax(iou([anchors[0]['bbox']], det_boxes)[0]))
         for box in tubelet['boxes']:
-            box['det_score'] = anchor_score
+            box['det_score'] = det_scores[best]
     return {'video': vid_proto['video'], 'method': "anchor_propagate", 'tubelets': tubelets_proto}
 
 
