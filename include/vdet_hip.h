@@ -237,6 +237,32 @@ int vdet_nms_volume_topk(vdet_ctx *ctx, const float *d_boxes, const float *d_sco
                          int64_t cap);
 
 /*
+ * Batched small videos (BASELINE configs[0] / [4] shapes: hundreds of frames x <= 300 boxes x 30 classes -- a single
+ * such video is launch-bound).  The frames of V videos are concatenated along F; h_frame_off [V+1] (host, starts at 0,
+ * strictly increasing) gives every video its frame range.  What does not look across frames -- the suppression graph,
+ * the per-(frame, class) sorts and NMS walks (vdet/video_det.py:79-106 over utils/nms.pyx) -- runs ONCE for the whole
+ * batch; tracking and re-scoring (vdet/track.py:189-252, vdet/tubelet_cls.py:493-535, :284-303, :386-414) run per
+ * video on its frame range, 4 + 3 launches each.  Results are what vdet_nms_track_volume + vdet_rescore_tracks return
+ * for each video on its own, laid out video after video:
+ *   d_tracks [sum_v C*T*F_v*5] (video v at C*T*5*h_frame_off[v]), d_anchors [V,C,T,3], d_ntracks [V,C],
+ *   d_keep_idx [F,C,cap] / d_keep_cnt [F,C] over the concatenated frames (d_keep_cnt null: no NMS output),
+ *   d_det_score / d_pooled [sum_v C*T*F_v] f64, d_boxes_out [sum_v C*T*F_v*4] (d_pooled null: no re-scoring).
+ */
+int vdet_video_batch(vdet_ctx *ctx, const float *d_boxes, const float *d_scores, const int64_t *h_frame_off,
+                     int64_t V, int64_t B, int64_t C, double nms_thres, double thres, int max_tracks,
+                     double link_thres, int max_frames, float *d_tracks, float *d_anchors, int32_t *d_ntracks,
+                     int64_t cap, int32_t *d_keep_idx, int32_t *d_keep_cnt, double overlap_thres, int window,
+                     double *d_det_score, double *d_pooled, float *d_boxes_out);
+
+/*
+ * vdet_volume_pass over V concatenated videos: a temporal window stops at its video's first / last frame (frames of
+ * another video count as padding, like frames outside [0, F) of a single video).  Same outputs and layouts.
+ */
+int vdet_volume_pass_batch(vdet_ctx *ctx, const float *d_scores, const int64_t *h_frame_off, int64_t V, int64_t B,
+                           int64_t C, int window, float pad_max, const float *h_taps, float bias, float pad_conv,
+                           float *d_out_max, float *d_out_conv, int use_score_thresh, float score_thresh);
+
+/*
  * Descending argsort of every (frame, class) score column of a volume: the order utils/nms.pyx:25
  * (`scores.argsort()[::-1]`) and vdet/video_det.py:93 (`argsort(-cls_scores)`) walk, with the build's
  * deterministic tie rule (equal scores by DESCENDING index, -0.0 == +0.0, NaN first).

@@ -1,0 +1,93 @@
+"""vdet_video_batch / vdet_volume_pass_batch: V small videos concatenated along F (BASELINE configs[0] / [4] shapes) give,
+video by video, exactly what the single-video entry points give -- NMS survivors, tubelets, anchors, re-scored tubelets,
+temporal outputs -- and a sample of them is checked against the oracle directly."""
+import numpy as np
+import pytest
+import torch
+
+import synth
+from vdetlib_amd import ops, _lib
+
+pytestmark = pytest.mark.gpu
+
+KW = dict(nms_thres=0.3, thres=0.2, max_tracks=4, link_thres=0.4)
+
+
+def _videos(frames, B, C, seed=300, irregular_at=None):
+    vids = []
+    for v, f in enumerate(frames):
+        b, s = synth.coherent_video(seed + v, f, B, C)
+        if irregular_at is not None and v == irregular_at[0]:
+            b[irregular_at[1], 3] = [30, 30, 29, 40]          # zero width: that frame is irregular (eager track_det_nms)
+            s[irregular_at[1], 3] = 0.01
+        vids.append((b, s))
+    off = np.concatenate([[0], np.cumsum(frames)])
+    boxes = torch.from_numpy(np.concatenate([b for b, _ in vids])).cuda()
+    scores = torch.from_numpy(np.concatenate([s for _, s in vids])).cuda()
+    return vids, off, boxes, scores
+
+
+def _eq(a, b):
+    return torch.equal(a.nan_to_num(-7.0), b.nan_to_num(-7.0))
+
+
+@pytest.mark.parametrize("irregular", [None, (2, 5)])
+def test_batch_equals_one_video_at_a_time(irregular):
+    frames = [7, 1, 12, 3, 9]
+    B, C = 150, 6
+    vids, off, boxes, scores = _videos(frames, B, C, irregular_at=irregular)
+    cx = _lib.Context(torch.cuda.current_device())
+    out = ops.video_batch(boxes, scores, off, overlap_thres=0.6, window=3, ctx=cx, **KW)
+    one = _lib.Context(torch.cuda.current_device())
+    one.set_cache(True)
+    for v, (b, s) in enumerate(vids):
+        tb, ts = torch.from_numpy(b).cuda(), torch.from_numpy(s).cuda()
+        ki, kc, tr, an, nt = ops.nms_track_volume(tb, ts, ctx=one, **KW)
+        det, pool, bx = ops.rescore_tracks(tr, nt, tb, ts, overlap_thres=0.6, window=3, ctx=one)
+        f0, f1 = int(off[v]), int(off[v + 1])
+        assert torch.equal(out["keep_cnt"][f0:f1], kc) and torch.equal(out["keep_idx"][f0:f1], ki), v
+        assert torch.equal(out["ntracks"][v], nt), v
+        for c in range(C):
+            n = int(nt[c])
+            assert _eq(out["anchors"][v, c, :n], an[c, :n]), (v, c)
+            assert _eq(out["tracks"][v][c, :n], tr[c, :n]), (v, c)
+            assert _eq(out["det"][v][c, :n], det[c, :n]) and _eq(out["pooled"][v][c, :n], pool[c, :n]), (v, c)
+            assert _eq(out["tboxes"][v][c, :n], bx[c, :n]), (v, c)
+    cx.close(); one.close()
+
+
+def test_batch_sample_against_the_oracle(oracle):
+    frames = [6, 10, 4]
+    B, C = 120, 3
+    vids, off, boxes, scores = _videos(frames, B, C, seed=900)
+    out = ops.video_batch(boxes, scores, off, overlap_thres=0.6, window=3, **KW)
+    v = 1
+    b, s = vids[v]
+    wt, wn, wpool, wbx = oracle.rescored_tubelets(b, s, KW["nms_thres"], KW["thres"], KW["max_tracks"], KW["link_thres"], 0.6, 3)
+    assert np.array_equal(out["ntracks"][v].cpu().numpy(), wn)
+    for c in range(C):
+        n = int(wn[c])
+        assert np.array_equal(out["tracks"][v][c, :n].cpu().numpy(), wt[c, :n], equal_nan=True)
+        np.testing.assert_allclose(out["pooled"][v][c, :n].cpu().numpy(), wpool[c, :n], rtol=0, atol=1e-9)
+        assert np.array_equal(out["tboxes"][v][c, :n].cpu().numpy(), wbx[c, :n], equal_nan=True)
+    widx, wcnt = oracle.nms_volume(b, s, KW["nms_thres"])
+    f0, f1 = int(off[v]), int(off[v + 1])
+    assert np.array_equal(out["keep_cnt"][f0:f1].cpu().numpy(), wcnt) and np.array_equal(out["keep_idx"][f0:f1].cpu().numpy(), widx)
+
+
+@pytest.mark.parametrize("C,window", [(8, 3), (8, 5), (6, 3), (5, 7)])
+def test_volume_pass_stops_at_video_borders(C, window):
+    """fast tiled kernel (C % 4 == 0, window 3 / 5), the two-operator vec4 kernel and the scalar fallback"""
+    frames = [5, 1, 2, 9, 3]
+    B = 37 if C == 5 else 64
+    rng = np.random.default_rng(C * 10 + window)
+    parts = [rng.standard_normal((f, B, C)).astype(np.float32) for f in frames]
+    off = np.concatenate([[0], np.cumsum(frames)])
+    taps = list(rng.standard_normal(window).astype(np.float32))
+    vol = torch.from_numpy(np.concatenate(parts)).cuda()
+    pooled, conv = ops.volume_pass(vol, window, taps, frame_off=off)
+    for v, p in enumerate(parts):
+        t = torch.from_numpy(p).cuda()
+        pm, pc = ops.volume_pass(t, window, taps)
+        f0, f1 = int(off[v]), int(off[v + 1])
+        assert torch.equal(pooled[f0:f1], pm) and torch.equal(conv[f0:f1], pc), v

@@ -241,15 +241,17 @@ def test_nms_volume_chains_stacks_hubs(torch_cuda, oracle, seed, t):
 
 
 def test_packed_walk_random_sweep(torch_cuda, monkeypatch):
-    """Eight candidates per pass (walk_list_packed) against one survivor at a time (VDET_WALK_PACKED=0) on 150 random
+    """Sixteen / eight candidates per pass (walk_list_packed2 / walk_list_packed) against one survivor at a time (VDET_WALK_PACKED=0) on 150 random
     volumes: frame sizes around the 64 / 128 / 256 boundaries, dense clusters (long lists, many in-group suppressions),
     integral / fractional boxes, tied scores, thresholds 0.05 .. 0.99, with and without a score threshold."""
     from vdetlib_amd import ops, _lib
     torch = torch_cuda
     monkeypatch.setenv("VDET_WALK_PACKED", "0")
     cx0 = _lib.Context(torch.cuda.current_device())
+    monkeypatch.setenv("VDET_WALK_PACKED", "2")
+    cx8 = _lib.Context(torch.cuda.current_device())      # sixteen candidates per pass (walk_list_packed2)
     monkeypatch.delenv("VDET_WALK_PACKED")
-    cx1 = _lib.Context(torch.cuda.current_device())
+    cx1 = _lib.Context(torch.cuda.current_device())      # the default: eight (walk_list_packed)
     rng = np.random.RandomState(4242)
     for it in range(150):
         B = int(rng.choice([2, 3, 7, 63, 64, 65, 127, 128, 129, 255, 256, 257, 500, 1000, 2049]))
@@ -270,4 +272,6 @@ def test_packed_walk_random_sweep(torch_cuda, monkeypatch):
         st = None if rng.randint(2) else float(rng.uniform(0, 0.5))
         i0, c0 = ops.nms_volume(tb, ts, t, score_thresh=st, ctx=cx0)
         i1, c1 = ops.nms_volume(tb, ts, t, score_thresh=st, ctx=cx1)
+        i8, c8 = ops.nms_volume(tb, ts, t, score_thresh=st, ctx=cx8)
         assert torch.equal(c0, c1) and torch.equal(i0, i1), (it, B, F, C, t, kind)
+        assert torch.equal(c0, c8) and torch.equal(i0, i8), (it, B, F, C, t, kind)

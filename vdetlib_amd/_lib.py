@@ -45,6 +45,9 @@ SYMBOLS = {
     "vdet_nms_volume": (_ci, [_vp, _vp, _vp, _ci, _i64, _i64, _i64, _f64, _ci, _f32, _vp, _vp, _i64]),
     "vdet_nms_volume_topk": (_ci, [_vp, _vp, _vp, _ci, _i64, _i64, _i64, _f64, _ci, _f32, _ci, _vp, _vp, _i64]),
     "vdet_argsort_volume": (_ci, [_vp, _vp, _ci, _i64, _i64, _i64, _ci, _f32, _vp, _vp]),
+    "vdet_video_batch": (_ci, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _f64, _f64, _ci, _f64, _ci, _vp, _vp, _vp, _i64, _vp, _vp,
+                               _f64, _ci, _vp, _vp, _vp]),
+    "vdet_volume_pass_batch": (_ci, [_vp, _vp, _vp, _i64, _i64, _i64, _ci, _f32, _vp, _f32, _f32, _vp, _vp, _ci, _f32]),
     "vdet_volume_pass": (_ci, [_vp, _vp, _i64, _i64, _i64, _ci, _f32, _vp, _f32, _f32, _vp, _vp, _ci, _f32]),
     "vdet_track_volume": (_ci, [_vp, _vp, _vp, _i64, _i64, _i64, _f64, _f64, _ci, _f64, _ci, _vp, _vp, _vp]),
     "vdet_nms_track_volume": (_ci, [_vp, _vp, _vp, _i64, _i64, _i64, _f64, _f64, _ci, _f64, _ci, _vp, _vp, _vp,

@@ -1197,7 +1197,7 @@ struct WalkParams {
     int mask_words;           // u32 words of one wave's dead mask
     const uint32_t *group_flags;   // kFlagRegular per group (the K1s path ran), or null
     int wave_words;           // u32 words of LDS per wave (mask + the packed walk's ring)
-    int packed;               // regular frames take walk_list_packed
+    int packed;               // regular frames take walk_list_packed (1) / walk_list_packed2 (2: sixteen candidates per pass)
     const WalkMeta *wmeta;    // per box: coordinates + list (adj_build_kernel), and the graph's threshold: the packed walk
     float t32;                // tests the members of a group against each other geometrically
 };
@@ -1454,6 +1454,156 @@ __device__ __forceinline__ void walk_list_packed(const WalkParams &prm, lds_mask
     nk_out = nk;
 }
 
+// ------------------------------------------------------------------------------------------------
+// SIXTEEN candidates per pass (round 3).  The packed walk above is bound by its chain of dependent steps: every
+// group of 8 waits one L2 round trip for its survivors' lists before the next group can look at the dead mask
+// (~175 groups x ~2 us per (frame, class) problem at 8 waves per SIMD -- the hardware's limit -- is the kernel's
+// 3 ms).  The same argument that makes a group legal makes TWO groups legal at once: whether a survivor of the first
+// eight (A) suppresses a member of the next eight (B) is a property of their two boxes, so lane (i, j) also evaluates
+// pair (A_i, B_j) and (B_i, B_j), three ballots give the 16 x 16 conflict matrix, and B's members need not wait for
+// A's lists to land in the mask.  All sixteen lists are requested together: one round trip per sixteen candidates.
+// Same survivors in the same order as walk_list_packed (VDET_WALK_PACKED=1 selects it; tested against each other
+// and against the one-at-a-time walk).
+// ------------------------------------------------------------------------------------------------
+constexpr int kPackRing2 = 88;                 // >= 15 left over + 64 of a chunk
+__device__ __forceinline__ int ring_wrap2(int s) { return s >= kPackRing2 ? s - kPackRing2 : s; }
+
+__device__ __forceinline__ void walk_list_packed2(const WalkParams &prm, lds_mask_t mask, const int lane, const int rb,
+                                                  const uint16_t *__restrict__ order, const int ncand,
+                                                  int32_t *__restrict__ out, const int64_t cap, int &nk_out)
+{
+    lds_mask_t ring = mask + prm.mask_words;
+    lds_f4_t ringb = (lds_f4_t)ring;                              // slot s: words 8s .. 8s+3 = meta, float4 2s+1 = box
+    const WalkMeta *__restrict__ wmeta = prm.wmeta + rb;
+    const float t32 = prm.t32;
+    const int k = lane >> 3, sub = lane & 7;
+    constexpr unsigned long long M = 0x0101010101010101ull;
+    int qh = 0, qn = 0, nk = 0;                                   // ring head, queued candidates, survivors (wave-uniform)
+    const int last = max(ncand - 1, 0);
+    int c_cur = (int)order[(uint32_t)min(lane, last)];
+    int c_nxt = (int)order[(uint32_t)min(64 + lane, last)];
+    uint2 m_cur = make_uint2(0u, 0u);
+    float4 b_cur = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane < ncand) {                                           // chunk 0: everything is alive
+        const WalkMeta *wm = wmeta + (uint32_t)c_cur;
+        b_cur = wm->box; const uint4 rw = wm->row; m_cur = make_uint2(rw.x, rw.y);
+    }
+    // the survivors' lists of one group -> dead bits (see walk_list_packed: aligned 16-byte pieces, whole pieces applied)
+    auto apply = [&](const AdjVec &a0, const AdjVec &a1, bool has0, bool has1, uint32_t off, int deg) {
+        if (has0) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const uint32_t d = a0.v[t];
+                lds_or(mask, (int)((d & 0xFFFFu) >> 5), 1u << (d & 31u));
+                lds_or(mask, (int)(d >> 21), 1u << ((d >> 16) & 31u));
+            }
+        }
+        if (__ballot(has1) != 0ull) {
+            if (has1) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const uint32_t d = a1.v[t];
+                    lds_or(mask, (int)((d & 0xFFFFu) >> 5), 1u << (d & 31u));
+                    lds_or(mask, (int)(d >> 21), 1u << ((d >> 16) & 31u));
+                }
+            }
+            unsigned long long lg = __ballot(sub == 0 && deg > 128);
+            while (lg) {                                             // rare: long lists
+                const int l = __ffsll((unsigned long long)lg) - 1;
+                lg &= lg - 1;
+                const uint32_t o = __builtin_amdgcn_readlane(off, l);
+                const int dl = __builtin_amdgcn_readlane(deg, l);
+                for (int e0 = 128; e0 < dl; e0 += 64) {
+                    const uint32_t e = prm.adj[o + min(e0 + lane, dl - 1)];
+                    if (e0 + lane < dl) lds_or(mask, (int)(e >> 5), 1u << (e & 31u));
+                }
+            }
+        }
+    };
+    for (int q0 = 0; q0 < ncand; q0 += 64) {
+        const int c = c_cur;
+        const int c_nn = (int)order[(uint32_t)min(q0 + 128 + lane, last)];
+        uint2 m_nxt = make_uint2(0u, 0u);
+        float4 b_nxt = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((q0 + 64 + lane) < ncand && !((mask[c_nxt >> 5] >> (c_nxt & 31)) & 1u)) {
+            const WalkMeta *wm = wmeta + (uint32_t)c_nxt;
+            b_nxt = wm->box; const uint4 rw = wm->row; m_nxt = make_uint2(rw.x, rw.y);
+        }
+        const bool alive = (q0 + lane) < ncand && !((mask[c >> 5] >> (c & 31)) & 1u);
+        const unsigned long long am = __ballot(alive);
+        if (alive) {
+            const int s = ring_wrap2(qh + qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u)));
+            ring[8 * s] = (uint32_t)c;
+            ring[8 * s + 1] = m_cur.x;
+            ring[8 * s + 2] = m_cur.y;
+            lds_f4v bv; bv.x = b_cur.x; bv.y = b_cur.y; bv.z = b_cur.z; bv.w = b_cur.w;
+            ringb[2 * s + 1] = bv;
+        }
+        qn += __popcll(am);
+        const bool flush = q0 + 64 >= ncand;
+        while (qn >= 16 || (flush && qn > 0)) {
+            const int nga = min(8, qn), ngb = min(8, qn - nga);
+            const int sa = ring_wrap2(qh + k), sb = ring_wrap2(qh + 8 + k);
+            const bool va = k < nga, vb = k < ngb;
+            const int cma = va ? (int)ring[8 * sa] : 0, cmb = vb ? (int)ring[8 * sb] : 0;
+            const lds_f4v via = ringb[2 * sa + 1], vja = ringb[2 * ring_wrap2(qh + sub) + 1];
+            const lds_f4v vib = ringb[2 * sb + 1], vjb = ringb[2 * ring_wrap2(qh + 8 + sub) + 1];
+            const float4 bia = make_float4(via.x, via.y, via.z, via.w), bja = make_float4(vja.x, vja.y, vja.z, vja.w);
+            const float4 bib = make_float4(vib.x, vib.y, vib.z, vib.w), bjb = make_float4(vjb.x, vjb.y, vjb.z, vjb.w);
+            const bool livea = va && !((mask[cma >> 5] >> (cma & 31)) & 1u);
+            const bool liveb = vb && !((mask[cmb >> 5] >> (cmb & 31)) & 1u);
+            const unsigned long long lma = __ballot(livea), lmb = __ballot(liveb);
+            const float aia = box_area(bia), aja = box_area(bja), aib = box_area(bib), ajb = box_area(bjb);
+            const bool haa = (pair_pred(bia, aia, bja, aja, t32) & 1u) != 0u;      // A_k suppresses A_sub
+            const bool hab = (pair_pred(bia, aia, bjb, ajb, t32) & 1u) != 0u;      // A_k suppresses B_sub
+            const bool hbb = (pair_pred(bib, aib, bjb, ajb, t32) & 1u) != 0u;      // B_k suppresses B_sub
+            const bool suba = ((lma >> (8 * sub)) & 1ull) != 0ull, subb = ((lmb >> (8 * sub)) & 1ull) != 0ull;
+            const unsigned long long caa = __ballot(haa && k < sub && livea && suba);
+            const unsigned long long cab = __ballot(hab && livea && subb);
+            const unsigned long long cbb = __ballot(hbb && k < sub && liveb && subb);
+            unsigned long long sva = lma & M, svb = lmb & M;           // bit 8k <=> member k survives
+            if (caa | cab | cbb) {
+                unsigned long long s1 = 0ull, s2 = 0ull;
+                for (int j = 0; j < 8; ++j) {
+                    const unsigned long long col = (caa >> j) & M;           // bit 8i <=> A_i suppresses A_j
+                    if (((lma >> (8 * j)) & 1ull) && !(col & s1)) s1 |= 1ull << (8 * j);
+                }
+                for (int j = 0; j < 8; ++j) {
+                    const unsigned long long ca = (cab >> j) & M, cb = (cbb >> j) & M;
+                    if (((lmb >> (8 * j)) & 1ull) && !(ca & s1) && !(cb & s2)) s2 |= 1ull << (8 * j);
+                }
+                sva = s1; svb = s2;
+            }
+            const bool sura = (sva >> (lane & 56)) & 1ull, surb = (svb >> (lane & 56)) & 1ull;
+            if (sva | svb) {
+                const int na = __popcll(sva);
+                const int posa = nk + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(sva >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sva, 0u));
+                const int posb = nk + na + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(svb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)svb, 0u));
+                if (sura && sub == 0 && (int64_t)posa < cap) out[(uint32_t)posa] = cma;
+                if (surb && sub == 0 && (int64_t)posb < cap) out[(uint32_t)posb] = cmb;
+                nk += na + __popcll(svb);
+                // all sixteen lists are requested before the first one is applied
+                const uint32_t offa = sura ? ring[8 * sa + 1] : 0u, offb = surb ? ring[8 * sb + 1] : 0u;
+                const int dega = sura ? (int)ring[8 * sa + 2] : 0, degb = surb ? (int)ring[8 * sb + 2] : 0;
+                const AdjVec *pa = reinterpret_cast<const AdjVec *>(prm.adj + offa);
+                const AdjVec *pb = reinterpret_cast<const AdjVec *>(prm.adj + offb);
+                const bool a_has0 = 8 * sub < dega, a_has1 = 64 + 8 * sub < dega;
+                const bool b_has0 = 8 * sub < degb, b_has1 = 64 + 8 * sub < degb;
+                const AdjVec a0 = pa[a_has0 ? sub : 0];
+                const AdjVec a1 = pa[a_has1 ? 8 + sub : 0];
+                const AdjVec b0 = pb[b_has0 ? sub : 0];
+                const AdjVec b1 = pb[b_has1 ? 8 + sub : 0];
+                apply(a0, a1, a_has0, a_has1, offa, dega);
+                apply(b0, b1, b_has0, b_has1, offb, degb);
+            }
+            qh = ring_wrap2(qh + nga + ngb);
+            qn -= nga + ngb;
+        }
+        c_cur = c_nxt; c_nxt = c_nn; m_cur = m_nxt; b_cur = b_nxt;
+    }
+    nk_out = nk;
+}
+
 __global__ __launch_bounds__(256) void walk_kernel(const WalkParams prm)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1488,7 +1638,8 @@ __global__ __launch_bounds__(256) void walk_kernel(const WalkParams prm)
     int nk = 0;
     int bad = 0;
     if (regular && prm.packed && N >= 2) {     // (singleton groups have no graph: adj_build_kernel never saw them)
-        walk_list_packed(prm, mask, lane, rb, order, ncand, out, cap, nk);
+        if (prm.packed == 2) walk_list_packed2(prm, mask, lane, rb, order, ncand, out, cap, nk);
+        else walk_list_packed(prm, mask, lane, rb, order, ncand, out, cap, nk);
         if (lane == 0) prm.keep_cnt[p] = nk;
         if ((int64_t)nk > cap && lane == 0) atomicOr(prm.status, kStCap);
         return;

@@ -17,6 +17,16 @@ namespace vdet {
 
 struct Taps { float w[32]; };
 
+// Batched videos (round 3): the frames of several videos concatenated along F.  seg[f] = {first frame, one past the
+// last frame} of the video frame f belongs to; a temporal window never reaches across: frames outside the video
+// count as padding, exactly like frames outside [0, F) of a single video.  seg == null: one video.
+__device__ __forceinline__ bool seg_in(const int2 *__restrict__ seg, int64_t f, int64_t g, int64_t F)
+{
+    if (!seg) return g >= 0 && g < F;
+    const int2 r = seg[f];
+    return g >= (int64_t)r.x && g < (int64_t)r.y;
+}
+
 __device__ __forceinline__ float4 splat4(float v) { return make_float4(v, v, v, v); }
 
 // np.max semantics: NaN propagates (v_max_f32 alone would drop it)
@@ -44,7 +54,7 @@ struct MaxAcc {
 template <int W, int MODE>
 __global__ __launch_bounds__(256) void temporal_vec4_kernel(const float4 *__restrict__ in, float4 *__restrict__ out,
                                                             int64_t F, int64_t S4, int64_t fchunk, float pad,
-                                                            float bias, Taps taps)
+                                                            float bias, Taps taps, const int2 *__restrict__ seg)
 {
     constexpr int H = W / 2;
     const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -70,20 +80,27 @@ __global__ __launch_bounds__(256) void temporal_vec4_kernel(const float4 *__rest
         const int64_t gc = min(g, F - 1);
         const float4 v = in[gc * S4 + s];
         win[W - 1] = (g == gc) ? v : padv;
+        float4 wv[W];
+#pragma unroll
+        for (int k = 0; k < W; ++k) wv[k] = win[k];
+        if (seg) {      // batched videos: neighbours in another video are padding (the raw values stay in the window)
+#pragma unroll
+            for (int k = 0; k < W; ++k) if (!seg_in(seg, f, f - H + k, F)) wv[k] = padv;
+        }
         float4 r;
         if (MODE == 0) {
             MaxAcc a;
-            a.init(win[0]);
+            a.init(wv[0]);
 #pragma unroll
-            for (int k = 1; k < W; ++k) a.add(win[k]);
+            for (int k = 1; k < W; ++k) a.add(wv[k]);
             r = a.get();
         } else {
             r = splat4(bias);
 #pragma unroll
             for (int k = 0; k < W; ++k) {
                 const float t = taps.w[k];
-                r.x = r.x + t * win[k].x; r.y = r.y + t * win[k].y;
-                r.z = r.z + t * win[k].z; r.w = r.w + t * win[k].w;
+                r.x = r.x + t * wv[k].x; r.y = r.y + t * wv[k].y;
+                r.z = r.z + t * wv[k].z; r.w = r.w + t * wv[k].w;
             }
         }
         out[f * S4 + s] = r;
@@ -97,7 +114,7 @@ template <int W>
 __global__ __launch_bounds__(256) void temporal_both_vec4_kernel(const float4 *__restrict__ in, float4 *__restrict__ out_max,
                                                                  float4 *__restrict__ out_conv, int64_t F, int64_t S4,
                                                                  int64_t fchunk, float pad_max, float pad_conv, float bias,
-                                                                 Taps taps)
+                                                                 Taps taps, const int2 *__restrict__ seg)
 {
     constexpr int H = W / 2;
     const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -122,16 +139,19 @@ __global__ __launch_bounds__(256) void temporal_both_vec4_kernel(const float4 *_
         const int64_t gc = min(g, F - 1);
         win[W - 1] = in[gc * S4 + s];
         ok[W - 1] = (g == gc);
-        MaxAcc a;
-        a.init(ok[0] ? win[0] : pm);
+        bool okf[W];
 #pragma unroll
-        for (int k = 1; k < W; ++k) a.add(ok[k] ? win[k] : pm);
+        for (int k = 0; k < W; ++k) okf[k] = seg ? seg_in(seg, f, f - H + k, F) : ok[k];
+        MaxAcc a;
+        a.init(okf[0] ? win[0] : pm);
+#pragma unroll
+        for (int k = 1; k < W; ++k) a.add(okf[k] ? win[k] : pm);
         out_max[f * S4 + s] = a.get();
         float4 r = splat4(bias);
 #pragma unroll
         for (int k = 0; k < W; ++k) {
             const float t = taps.w[k];
-            const float4 v = ok[k] ? win[k] : pc;
+            const float4 v = okf[k] ? win[k] : pc;
             r.x = r.x + t * v.x; r.y = r.y + t * v.y;
             r.z = r.z + t * v.z; r.w = r.w + t * v.w;
         }
@@ -185,7 +205,7 @@ __global__ __launch_bounds__(NT) void volume_pass_kernel(const float4 *__restric
                                                          float4 *__restrict__ out_conv, uint32_t *__restrict__ keys,
                                                          int F, int B, int C4, int TB, int tb_shift, int fchunk,
                                                          float pad_max, float pad_conv, float bias, Taps taps,
-                                                         int use_thr, float thr)
+                                                         int use_thr, float thr, const int2 *__restrict__ seg)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char vp_smem[];
     uint32_t *tile = reinterpret_cast<uint32_t *>(vp_smem);      // [2][C][TB] keys, columns XOR-swizzled per class group
@@ -246,6 +266,10 @@ __global__ __launch_bounds__(NT) void volume_pass_kernel(const float4 *__restric
             for (int i = 0; i < ITEMS; ++i) win[i][k] = win[i][k + 1];
         }
         ok[W - 1] = (f + H <= F - 1);
+        if (seg) {      // batched videos: the window stops at the video's first / last frame (wave-uniform: scalar loads)
+#pragma unroll
+            for (int k = 0; k < W; ++k) ok[k] = seg_in(seg, f, f - H + k, F);
+        }
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) win[i][W - 1] = nxt[i];
         {   // next iteration's newest frame: issued now, first used after this iteration's stores and barrier
@@ -317,7 +341,7 @@ __global__ __launch_bounds__(NT) void volume_pass_kernel(const float4 *__restric
 template <int MODE>
 __global__ __launch_bounds__(256) void temporal_scalar_kernel(const float *__restrict__ in, float *__restrict__ out,
                                                               int64_t F, int64_t S, int W, float pad, float bias,
-                                                              Taps taps)
+                                                              Taps taps, const int2 *__restrict__ seg)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= F * S) return;
@@ -330,7 +354,7 @@ __global__ __launch_bounds__(256) void temporal_scalar_kernel(const float *__res
             const int64_t g = f + k - H;
             const int64_t gc = min(max(g, (int64_t)0), F - 1);
             float v = in[gc * S + s];
-            v = (g == gc) ? v : pad;
+            v = (g == gc && seg_in(seg, f, g, F)) ? v : pad;
             nan |= (v != v);
             m = (k == 0) ? v : fmaxf(m, v);
         }
@@ -341,7 +365,7 @@ __global__ __launch_bounds__(256) void temporal_scalar_kernel(const float *__res
             const int64_t g = f + k - H;
             const int64_t gc = min(max(g, (int64_t)0), F - 1);
             float v = in[gc * S + s];
-            v = (g == gc) ? v : pad;
+            v = (g == gc && seg_in(seg, f, g, F)) ? v : pad;
             acc = acc + taps.w[k] * v;
         }
         out[i] = acc;

@@ -748,14 +748,14 @@ __global__ __launch_bounds__(LT, (MODE == 1 && LT == 256 && MAXB == 8) ? 5 : 1) 
 // never correctness: the memo only ever holds next(f, j, dir), which no prediction can change.
 // One block per class; warm[c * m + k] = flat index or -1.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void track_warm_anchors_kernel(const uint32_t *__restrict__ keys, const uint16_t *__restrict__ lists,
-                                                                 const int32_t *__restrict__ cnt, int F, int B, int C,
-                                                                 const float *__restrict__ scores, double thres, int m,
-                                                                 int32_t *__restrict__ warm)
+__device__ __forceinline__ void track_warm_anchors_body(const int c, const uint32_t *__restrict__ keys, const uint16_t *__restrict__ lists,
+                                                        const int32_t *__restrict__ cnt, int F, int B, int C,
+                                                        const float *__restrict__ scores, double thres, int m,
+                                                        int32_t *__restrict__ warm)
 {
     __shared__ uint32_t sk[256];
     __shared__ int sf[256];
-    const int c = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     uint32_t lk = 0xFFFFFFFFu;       // cursor: the last candidate taken (key, flat); everything at or before it is out
     int lf = -1;
     for (int k = 0; k < m; ++k) {
@@ -798,6 +798,14 @@ __global__ __launch_bounds__(256) void track_warm_anchors_kernel(const uint32_t 
     }
 }
 
+__global__ __launch_bounds__(256) void track_warm_anchors_kernel(const uint32_t *__restrict__ keys, const uint16_t *__restrict__ lists,
+                                                                 const int32_t *__restrict__ cnt, int F, int B, int C,
+                                                                 const float *__restrict__ scores, double thres, int m,
+                                                                 int32_t *__restrict__ warm)
+{
+    track_warm_anchors_body(blockIdx.x, keys, lists, cnt, F, B, C, scores, thres, m, warm);
+}
+
 // ------------------------------------------------------------------------------------------------
 // track_det_nms of the new track against every frame it crosses: one wave per (frame, class).
 // ------------------------------------------------------------------------------------------------
@@ -821,6 +829,7 @@ struct SuppressParams {
     int mask_words;
     int lazy;                      // 1: the lists of regular frames are maintained by the pick
     const int *n_irregular;        // device counter of irregular frames (frame_flags_kernel)
+    int rb_bias;                   // batched videos: groups[] holds absolute row offsets, boxes / row_meta are the video's own
 };
 
 // one (frame, class) list p = f * C + c, one wave
@@ -834,7 +843,7 @@ __device__ __forceinline__ void track_suppress_list(const SuppressParams &prm, l
     if (tx1 != tx1) return;                           // the track has no box on this frame
     const float4 tb = make_float4(tx1, row[1], row[2], row[3]);
     const float tarea = box_area(tb);
-    const int B = prm.B, rb = prm.groups[f].box_off;
+    const int B = prm.B, rb = prm.groups[f].box_off - prm.rb_bias;
     uint16_t *list = prm.lists + (int64_t)p * B;
     const int n = prm.cnt[p];
     if (n == 0) return;
@@ -1031,10 +1040,10 @@ struct LoopArgs {
     int need_suppress;
 };
 
-__global__ __launch_bounds__(256) void track_loop_kernel(const LoopArgs a, const LazyLists lz, const ResolveArgs rv, const SuppressParams sp)
+__device__ __forceinline__ void track_loop_body(const int c, const LoopArgs &a, const LazyLists &lz, const ResolveArgs &rv, const SuppressParams &sp,
+                                                unsigned char *smem)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int F = sp.F, B = sp.B, C = sp.C, T = sp.max_tracks;
     TrackState *st = const_cast<TrackState *>(sp.st);
     for (int t = 0; t < T; ++t) {
@@ -1067,6 +1076,12 @@ __global__ __launch_bounds__(256) void track_loop_kernel(const LoopArgs a, const
         __syncthreads();
     }
     if (tid == 0) a.ntracks_out[c] = st[c].ntracks;
+}
+
+__global__ __launch_bounds__(256) void track_loop_kernel(const LoopArgs a, const LazyLists lz, const ResolveArgs rv, const SuppressParams sp)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    track_loop_body(blockIdx.x, a, lz, rv, sp, smem);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1317,13 +1332,12 @@ __global__ void rescore_series_kernel(double *__restrict__ sc, double *__restric
 // neither missing nor filled and bounds the gaps next to it), same error rule (no present score at all).
 constexpr int kSeriesWaveMaxF = 1536;
 
-__global__ __launch_bounds__(256) void rescore_series_wave_kernel(double *__restrict__ sc, double *__restrict__ out2,
-                                                                  const int32_t *__restrict__ ntracks, int F, int C, int T,
-                                                                  int window, int *__restrict__ err, int stride_bytes)
+__device__ __forceinline__ void rescore_series_wave_body(const int blk, unsigned char *series_smem, double *__restrict__ sc, double *__restrict__ out2,
+                                                         const int32_t *__restrict__ ntracks, int F, int C, int T,
+                                                         int window, int *__restrict__ err, int stride_bytes)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char series_smem[];
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int ct = blockIdx.x * 4 + w;
+    const int ct = blk * 4 + w;
     if (ct >= C * T) return;
     volatile double *v = reinterpret_cast<volatile double *>(series_smem + (size_t)w * stride_bytes);
     volatile unsigned char *miss = series_smem + (size_t)w * stride_bytes + (size_t)F * 8;
@@ -1378,6 +1392,14 @@ __global__ __launch_bounds__(256) void rescore_series_wave_kernel(double *__rest
         }
         o[a + i] = m;
     }
+}
+
+__global__ __launch_bounds__(256) void rescore_series_wave_kernel(double *__restrict__ sc, double *__restrict__ out2,
+                                                                  const int32_t *__restrict__ ntracks, int F, int C, int T,
+                                                                  int window, int *__restrict__ err, int stride_bytes)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char series_smem[];
+    rescore_series_wave_body(blockIdx.x, series_smem, sc, out2, ntracks, F, C, T, window, err, stride_bytes);
 }
 
 }  // namespace vdet

@@ -19,6 +19,7 @@
 #include "temporal_kernels.hpp"
 #include "tubelet_kernels.hpp"
 #include "track_kernels.hpp"
+#include "batch_kernels.hpp"
 #include "gemm_kernels.hpp"
 
 using namespace vdet;
@@ -141,7 +142,9 @@ struct vdet_ctx {
     int link_threads = 256;       // VDET_LINK_THREADS=64|128|256: threads per link chain (A-B knob)
     bool series_serial = false;   // VDET_SERIES_SERIAL=1: one thread per tubelet series (A-B knob / tests)
     bool link_materialize = true; // VDET_LINK_MATERIALIZE=0: the tracking loop walks every tubelet itself (A-B knob / tests)
-    bool walk_packed = true;      // VDET_WALK_PACKED=0: regular frames walk one survivor at a time (A-B knob / tests)
+    int walk_packed = 1;          // VDET_WALK_PACKED=0: regular frames walk one survivor at a time; 1 (default): eight candidates per pass;
+                                  // 2: sixteen (walk_list_packed2: measured 3.09 vs 2.96 ms -- the walk is bound by L1 / LDS throughput, not by
+                                  // its chain of round trips) (A-B knob / tests)
     float gt32 = 0.f;             // threshold of the last graph build (the packed walk's in-group test)
     bool wmeta_built = false;     // ... which also wrote the packed walk's records (WalkMeta) of the regular frames
     bool walk_careful = false;    // VDET_WALK_CAREFUL=1: per-survivor bookkeeping also on regular frames (A-B knob / tests)
@@ -151,6 +154,10 @@ struct vdet_ctx {
     bool binsort = false;         // VDET_BINSORT=1: untied volume columns by the equalised counting sort (binsort_kernels.hpp) instead of the
                                   // LSD radix kernel.  Bit-identical; measured at the LSD kernel's speed (3.32 vs 3.37 ms per c2 video), so off
     bool last_sort_binned = false;   // the last per-(frame, class) sort went through binsort_kernel (vdet_query 9)
+    DevBuf vidtab;                // batched videos: {first frame, frames} per video
+    std::vector<VidDesc> h_vids;
+    DevBuf segtab;                // batched videos: per-frame {first, one past last} frame of its video
+    std::vector<int2> h_seg;
     DevBuf sortctl;               // binsort_kernel's work counter + the list of problems it handed to the LSD kernel
     // second stream of the context: the memo warm-up runs on it, next to the NMS walk of the same video
     hipStream_t aux_stream = nullptr;
@@ -667,8 +674,8 @@ int launch_sort_walk(vdet_ctx *c, const SortWalkArgs &a, int nmax, int64_t order
     wp.status = &c->d_cnt->status;
     wp.mask_words = (int)(r16((size_t)4 * ((std::max(nmax, 1) + 31) / 32)) / 4);
     wp.group_flags = (c->sym_built && !c->walk_careful) ? c->gflags.as<uint32_t>() : nullptr;   // frames whose graph is symmetric
-    wp.packed = (wp.group_flags && c->walk_packed && c->wmeta_built) ? 1 : 0;    // eight candidates per pass (walk_list_packed)
-    wp.wave_words = wp.mask_words + (wp.packed ? 8 * kPackRing : 0);             // + the ring of alive candidates
+    wp.packed = (wp.group_flags && c->walk_packed && c->wmeta_built) ? c->walk_packed : 0;    // 1: eight, 2: sixteen candidates per pass
+    wp.wave_words = wp.mask_words + (wp.packed == 2 ? 8 * kPackRing2 : wp.packed ? 8 * kPackRing : 0);   // + the ring of alive candidates
     wp.wmeta = c->wmeta.as<WalkMeta>();
     wp.t32 = c->gt32;
     {
@@ -832,7 +839,7 @@ int vdet_create(vdet_ctx **out, int device)
     if (const char *e = getenv("VDET_NO_INDEX")) c->no_index = atoi(e) != 0;
     if (const char *e = getenv("VDET_NO_LAZY")) c->no_lazy = atoi(e) != 0;
     if (const char *e = getenv("VDET_WALK_CAREFUL")) c->walk_careful = atoi(e) != 0;
-    if (const char *e = getenv("VDET_WALK_PACKED")) c->walk_packed = atoi(e) != 0;
+    if (const char *e = getenv("VDET_WALK_PACKED")) c->walk_packed = std::max(0, std::min(2, atoi(e)));
     if (const char *e = getenv("VDET_LINK_MATERIALIZE")) c->link_materialize = atoi(e) != 0;
     if (const char *e = getenv("VDET_SERIES_SERIAL")) c->series_serial = atoi(e) != 0;
     if (const char *e = getenv("VDET_RESCORE_ADJ")) c->rescore_adj = atoi(e) != 0;
@@ -914,7 +921,7 @@ int vdet_destroy(vdet_ctx *c)
                       &c->rowz, &c->rowmeta, &c->groupz, &c->adj, &c->comp, &c->origidx, &c->out64,
                       &c->trk_frames, &c->trk_boxes, &c->b1, &c->b2, &c->iou_out, &c->order, &c->ncand, &c->keepidx,
                       &c->keepcnt, &c->gflags, &c->pairs, &c->tkeys, &c->tstate, &c->visited, &c->heads, &c->xkeys, &c->xord, &c->xncand, &c->linkmemo, &c->linkstats, &c->linkwarm, &c->linkchains, &c->linknodes, &c->tracknode, &c->rtodo,
-                      &c->xbox, &c->xcum, &c->xinfo, &c->wmeta, &c->reachtab, &c->sortctl};
+                      &c->xbox, &c->xcum, &c->xinfo, &c->wmeta, &c->reachtab, &c->sortctl, &c->segtab, &c->vidtab};
     for (DevBuf *b : bufs) b->release();
     for (DevBuf &b : c->tmp) b.release();
     for (auto &e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -1511,6 +1518,145 @@ int vdet_nms_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scor
     return VDET_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// V small videos in one call (BASELINE configs[0] / [4] shapes: hundreds of frames x <= 300 boxes x 30 classes, where
+// one video alone is launch-bound at ~60 launches): the frames of all videos are concatenated along F -- per-frame NMS
+// problems do not know which video they belong to, so suppression graph, sort and walk are ONE launch sequence for the
+// whole batch -- and only the stages that follow a video in time (tracking, re-scoring) run per video, on sub-ranges
+// of the same buffers: 4 + 3 launches each instead of ~60, no host synchronisation in between.
+// ---------------------------------------------------------------------------------------------
+int vdet_video_batch(vdet_ctx *c, const float *d_boxes, const float *d_scores, const int64_t *h_frame_off, int64_t V, int64_t B,
+                     int64_t C, double nms_thres, double thres, int max_tracks, double link_thres, int max_frames,
+                     float *d_tracks, float *d_anchors, int32_t *d_ntracks, int64_t cap, int32_t *d_keep_idx, int32_t *d_keep_cnt,
+                     double overlap_thres, int window, double *d_det_score, double *d_pooled, float *d_boxes_out)
+{
+    if (!c) return VDET_EINVAL;
+    const bool want_nms = d_keep_cnt != nullptr, want_rescore = d_pooled != nullptr;
+    if (want_nms && (cap < 0 || (cap > 0 && !d_keep_idx))) return fail(c, VDET_EINVAL, "null output");
+    if (V <= 0 || B <= 0 || C <= 0 || max_tracks < 0 || !h_frame_off) return fail(c, VDET_EINVAL, "bad shape");
+    if (!d_boxes || !d_scores || !d_ntracks || (max_tracks > 0 && (!d_tracks || !d_anchors))) return fail(c, VDET_EINVAL, "null buffer");
+    if (want_rescore && (!d_det_score || !d_boxes_out)) return fail(c, VDET_EINVAL, "null buffer");
+    if (want_rescore && (window < 1 || window % 2 != 1)) return fail(c, VDET_EINVAL, "Window size must be odd!");
+    if (B > 32767) return fail(c, VDET_EINVAL, "B = %lld boxes per frame; the limit is 32767", (long long)B);
+    if (((uintptr_t)d_boxes & 15) != 0) return fail(c, VDET_EINVAL, "d_boxes must be 16-byte aligned");
+    if (h_frame_off[0] != 0) return fail(c, VDET_EINVAL, "frame offsets must start at 0");
+    int64_t Fmax = 0;
+    for (int64_t v = 0; v < V; ++v) {
+        if (h_frame_off[v + 1] <= h_frame_off[v]) return fail(c, VDET_EINVAL, "every video needs at least one frame");
+        Fmax = std::max(Fmax, h_frame_off[v + 1] - h_frame_off[v]);
+    }
+    const int64_t F = h_frame_off[V];
+    if (F * C > 0x7FFFFFF0ll || F * B > 0x7FFFFFF0ll || V * C > 0x7FFFFFF0ll) return fail(c, VDET_EINVAL, "volume too large");
+    HIPCHK(c, hipSetDevice(c->device));
+    timing_reset(c);
+    const float t32 = thresh_to_f32(nms_thres);
+    int rc;
+    // ---- the batch as one volume of F frames: graph, sorted lists, NMS survivors
+    c->graph_valid = c->lists_valid = c->nodes_valid = false;
+    rc = build_graph(c, reinterpret_cast<const float4 *>(d_boxes), volume_plan(c, F, B), t32, nms_thres, true);
+    if (rc) return rc;
+    c->prep.boxes = d_boxes; c->prep.F = F; c->prep.B = B; c->prep.t32 = t32;
+    c->graph_valid = true;
+    {
+        const bool saved = c->no_transpose;
+        c->no_transpose = false;
+        SortWalkArgs a{};
+        a.sort_only = true;
+        a.mode = 0; a.P = (int)(F * C); a.B = (int)B; a.C = (int)C;
+        a.scores = d_scores;
+        rc = launch_sort_walk(c, a, (int)B, F * C * B);
+        c->no_transpose = saved;
+        if (rc) return rc;
+    }
+    if (want_nms) {
+        SortWalkArgs a{};
+        a.walk_only = true;
+        a.mode = 0; a.P = (int)(F * C); a.B = (int)B; a.C = (int)C;
+        a.scores = d_scores;
+        a.keep_idx = d_keep_idx; a.keep_cnt = d_keep_cnt; a.cap = cap;
+        rc = launch_sort_walk(c, a, (int)B, F * C * B);
+        if (rc) return rc;
+    }
+    c->lists_valid = false;          // consumed by the tracking below
+    HIPCHK(c, hipMemsetAsync(d_ntracks, 0, (size_t)(V * C) * 4, c->stream));
+    if (max_tracks == 0) return VDET_OK;
+    // ---- per video: tracking (+ re-scoring) on its frame range
+    const bool regular_ok = c->sym_built;
+    const float link_t32 = thresh_to_f32(link_thres);
+    const uint32_t *g_flags = regular_ok ? c->gflags.as<uint32_t>() : nullptr;
+    const bool have_ix = g_flags && c->index_valid && !c->no_index;
+    const int T = max_tracks;
+    const int wm = std::min(T + 6, 24);
+    HIPCHK(c, c->tracknode.reserve((size_t)(C * T * F) * 4));
+    HIPCHK(c, hipMemsetAsync(c->tracknode.p, 0xFF, (size_t)(C * T * F) * 4, c->stream));
+    HIPCHK(c, c->linkmemo.reserve((size_t)2 * F * B * 8));
+    HIPCHK(c, c->linkstats.reserve(16));
+    HIPCHK(c, hipMemsetAsync(c->linkmemo.p, 0, (size_t)2 * F * B * 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->linkstats.p, 0, 16, c->stream));
+    HIPCHK(c, c->linkwarm.reserve((size_t)V * C * wm * 4));
+    HIPCHK(c, c->linkchains.reserve((size_t)C * wm * F * 5 * 4));
+    HIPCHK(c, c->linknodes.reserve((size_t)C * wm * F * 4));
+    HIPCHK(c, hipMemsetAsync(c->linknodes.p, 0xFF, (size_t)C * wm * F * 4, c->stream));
+    HIPCHK(c, c->tstate.reserve((size_t)(V * C) * sizeof(TrackState)));
+    hipLaunchKernelGGL(track_init_kernel, dim3((unsigned)((V * C + 63) / 64)), dim3(64), 0, c->stream, c->tstate.as<TrackState>(), (int)(V * C));
+    HIPCHK(c, c->visited.reserve((size_t)(F * C)));
+    HIPCHK(c, hipMemsetAsync(c->visited.p, 0, (size_t)(F * C), c->stream));
+    HIPCHK(c, c->heads.reserve((size_t)(F * C) * 16));
+    HIPCHK(c, hipMemsetAsync(c->heads.p, 0, (size_t)(F * C) * 16, c->stream));
+    const bool need_suppress = c->no_lazy || !g_flags || !c->all_regular;
+    const int mask_words = (int)((((size_t)4 * ((B + 31) / 32) + 15) & ~(size_t)15) / 4);
+    // ---- all videos side by side: one launch per stage, the video is a grid dimension (batch_kernels.hpp)
+    if (Fmax > kSeriesWaveMaxF) return fail(c, VDET_EINVAL, "a video of %lld frames: the batched call takes at most %d per video", (long long)Fmax, kSeriesWaveMaxF);
+    (void)host_sync(c);      // (an earlier copy from the host table may be in flight)
+    c->h_vids.resize((size_t)V);
+    for (int64_t v = 0; v < V; ++v) c->h_vids[(size_t)v] = VidDesc{(int32_t)h_frame_off[v], (int32_t)(h_frame_off[v + 1] - h_frame_off[v])};
+    HIPCHK(c, c->vidtab.reserve((size_t)V * sizeof(VidDesc)));
+    HIPCHK(c, hipMemcpyAsync(c->vidtab.p, c->h_vids.data(), (size_t)V * sizeof(VidDesc), hipMemcpyHostToDevice, c->stream));
+    BatchTrack bt{};
+    bt.vids = c->vidtab.as<VidDesc>();
+    bt.Ftot = (int)F; bt.B = (int)B; bt.C = (int)C; bt.T = T; bt.wm = wm;
+    bt.boxes = reinterpret_cast<const float4 *>(d_boxes); bt.scores = d_scores;
+    bt.keys = c->tkeys.as<uint32_t>(); bt.lists = c->order.as<uint16_t>(); bt.cnt = c->ncand.as<int32_t>();
+    bt.group_flags = g_flags;
+    bt.ix = have_ix ? frame_index_of(c) : FrameIndex{nullptr, nullptr, nullptr, nullptr};
+    bt.memo = c->linkmemo.as<unsigned long long>(); bt.stats = c->linkstats.as<unsigned int>();
+    bt.warm = c->linkwarm.as<int32_t>(); bt.chains = c->linkchains.as<float>(); bt.chain_nodes = c->linknodes.as<int32_t>();
+    bt.track_nodes = c->tracknode.as<int32_t>();
+    bt.tracks = d_tracks; bt.anchors = d_anchors; bt.ntracks = d_ntracks;
+    bt.st = c->tstate.as<TrackState>();
+    bt.heads = c->heads.as<int32_t>(); bt.visited = c->visited.as<uint8_t>();
+    bt.groups = c->groups.as<GroupDesc>(); bt.row_meta = c->rowmeta.as<uint2>(); bt.adj = c->adj.as<uint16_t>();
+    bt.group_z = c->groupz.as<uint32_t>();
+    bt.thres = thres; bt.link_thres = link_thres; bt.nms_thres = nms_thres;
+    bt.link_t32 = link_t32; bt.t32 = t32;
+    bt.reach_all = max_frames > 0 ? (int)std::ceil((max_frames + 1) / 2.0) - 1 : -1;
+    bt.need_suppress = need_suppress ? 1 : 0; bt.lazy = c->no_lazy ? 0 : 1; bt.mask_words = mask_words;
+    bt.status = &c->d_cnt->status; bt.n_irregular = &c->d_cnt->irregular;
+    {
+        StageTimer tm(c, ST_TLINK);
+        hipLaunchKernelGGL(batch_warm_anchors_kernel, dim3((unsigned)C, (unsigned)V), dim3(256), 0, c->stream, bt);
+        hipLaunchKernelGGL((batch_link_kernel<256, 1>), dim3((unsigned)(C * wm), 2, (unsigned)V), dim3(256), 0, c->stream, bt);
+        hipLaunchKernelGGL((batch_link_kernel<64, 2>), dim3((unsigned)(C * wm), 2, (unsigned)V), dim3(64), 0, c->stream, bt);
+    }
+    {
+        StageTimer tm(c, ST_TLOOP);
+        hipLaunchKernelGGL(batch_loop_kernel, dim3((unsigned)C, (unsigned)V), dim3(256), (size_t)mask_words * 16, c->stream, bt);
+    }
+    if (want_rescore) {
+        {
+            StageTimer tm(c, ST_RSPATIAL);
+            hipLaunchKernelGGL(batch_rescore_spatial_kernel, dim3((unsigned)((Fmax * C * T + 3) / 4), (unsigned)V), dim3(256), 0, c->stream, bt,
+                               overlap_thres, d_det_score, d_boxes_out);
+        }
+        StageTimer tm(c, ST_RSERIES);
+        const int stride = (int)(((size_t)Fmax * 9 + 15) & ~(size_t)15);
+        hipLaunchKernelGGL(batch_rescore_series_kernel, dim3((unsigned)((C * T + 3) / 4), (unsigned)V), dim3(256), (size_t)stride * 4, c->stream, bt,
+                           d_det_score, d_pooled, window, &c->d_cnt->eindex, stride);
+    }
+    HIPCHK(c, hipGetLastError());
+    return VDET_OK;
+}
+
 int vdet_rescore_tracks(vdet_ctx *c, const float *d_tracks, const int32_t *d_ntracks, const float *d_boxes,
                         const float *d_scores, int64_t F, int64_t B, int64_t C, int max_tracks, double overlap_thres,
                         int window, double *d_det_score, double *d_pooled, float *d_boxes_out)
@@ -1811,7 +1957,7 @@ int vdet_conv1d_f32(vdet_ctx *c, const float *h_in, int Cin, int L, const float 
 
 // ---------------------------------------------------------------------------------------------
 static int temporal_launch(vdet_ctx *c, int mode, const float *d_in, float *d_out, int64_t F, int64_t S, int W,
-                           float pad, float bias, const Taps &taps)
+                           float pad, float bias, const Taps &taps, const int2 *d_seg = nullptr)
 {
     if (F == 0 || S == 0) return VDET_OK;
     HIPCHK(c, hipSetDevice(c->device));
@@ -1829,7 +1975,7 @@ static int temporal_launch(vdet_ctx *c, int mode, const float *d_in, float *d_ou
         const dim3 grid(gx, (unsigned)((F + fchunk - 1) / fchunk));
         const float4 *in4 = reinterpret_cast<const float4 *>(d_in);
         float4 *out4 = reinterpret_cast<float4 *>(d_out);
-#define VDET_TL(WW, MM) hipLaunchKernelGGL((temporal_vec4_kernel<WW, MM>), grid, dim3(256), 0, c->stream, in4, out4, F, S4, fchunk, pad, bias, taps)
+#define VDET_TL(WW, MM) hipLaunchKernelGGL((temporal_vec4_kernel<WW, MM>), grid, dim3(256), 0, c->stream, in4, out4, F, S4, fchunk, pad, bias, taps, d_seg)
         if (mode == 0) {
             if (W == 3) VDET_TL(3, 0); else if (W == 5) VDET_TL(5, 0); else if (W == 7) VDET_TL(7, 0); else VDET_TL(9, 0);
         } else {
@@ -1839,8 +1985,8 @@ static int temporal_launch(vdet_ctx *c, int mode, const float *d_in, float *d_ou
     } else {
         const int64_t n = F * S;
         const dim3 grid((unsigned)((n + 255) / 256));
-        if (mode == 0) hipLaunchKernelGGL(temporal_scalar_kernel<0>, grid, dim3(256), 0, c->stream, d_in, d_out, F, S, W, pad, bias, taps);
-        else hipLaunchKernelGGL(temporal_scalar_kernel<1>, grid, dim3(256), 0, c->stream, d_in, d_out, F, S, W, pad, bias, taps);
+        if (mode == 0) hipLaunchKernelGGL(temporal_scalar_kernel<0>, grid, dim3(256), 0, c->stream, d_in, d_out, F, S, W, pad, bias, taps, d_seg);
+        else hipLaunchKernelGGL(temporal_scalar_kernel<1>, grid, dim3(256), 0, c->stream, d_in, d_out, F, S, W, pad, bias, taps, d_seg);
     }
     HIPCHK(c, hipGetLastError());
     return VDET_OK;
@@ -1868,8 +2014,17 @@ int vdet_temporal_conv_f32(vdet_ctx *c, const float *d_in, float *d_out, int64_t
     return temporal_launch(c, 1, d_in, d_out, F, S, K, pad, bias, taps);
 }
 
+static int temporal_maxpool_conv_impl(vdet_ctx *c, const float *d_in, float *d_out_max, float *d_out_conv, int64_t F, int64_t S,
+                                      int window, float pad_max, const float *h_taps, float bias, float pad_conv, const int2 *d_seg);
+
 int vdet_temporal_maxpool_conv_f32(vdet_ctx *c, const float *d_in, float *d_out_max, float *d_out_conv, int64_t F, int64_t S,
                                    int window, float pad_max, const float *h_taps, float bias, float pad_conv)
+{
+    return temporal_maxpool_conv_impl(c, d_in, d_out_max, d_out_conv, F, S, window, pad_max, h_taps, bias, pad_conv, nullptr);
+}
+
+static int temporal_maxpool_conv_impl(vdet_ctx *c, const float *d_in, float *d_out_max, float *d_out_conv, int64_t F, int64_t S,
+                                      int window, float pad_max, const float *h_taps, float bias, float pad_conv, const int2 *d_seg)
 {
     if (!c) return VDET_EINVAL;
     if (window < 1 || window % 2 != 1) return fail(c, VDET_EINVAL, "Window size must be odd!");
@@ -1881,9 +2036,11 @@ int vdet_temporal_maxpool_conv_f32(vdet_ctx *c, const float *d_in, float *d_out_
     const bool vec = (S % 4 == 0) && (((uintptr_t)d_in | (uintptr_t)d_out_max | (uintptr_t)d_out_conv) & 15) == 0 &&
                      (window == 3 || window == 5 || window == 7);
     if (!vec) {   // shapes the fused kernel does not cover: the two passes
-        int rc = vdet_temporal_maxpool_f32(c, d_in, d_out_max, F, S, window, pad_max);
+        Taps t0{};
+        int rc = temporal_launch(c, 0, d_in, d_out_max, F, S, window, pad_max, 0.0f, t0, d_seg);
         if (rc) return rc;
-        return vdet_temporal_conv_f32(c, d_in, d_out_conv, F, S, h_taps, window, bias, pad_conv);
+        for (int k = 0; k < window; ++k) t0.w[k] = h_taps[k];
+        return temporal_launch(c, 1, d_in, d_out_conv, F, S, window, pad_conv, bias, t0, d_seg);
     }
     HIPCHK(c, hipSetDevice(c->device));
     timing_reset(c);
@@ -1899,7 +2056,7 @@ int vdet_temporal_maxpool_conv_f32(vdet_ctx *c, const float *d_in, float *d_out_
     const dim3 grid(gx, (unsigned)((F + fchunk - 1) / fchunk));
     const float4 *in4 = reinterpret_cast<const float4 *>(d_in);
     float4 *om = reinterpret_cast<float4 *>(d_out_max), *oc = reinterpret_cast<float4 *>(d_out_conv);
-#define VDET_TB(WW) hipLaunchKernelGGL((temporal_both_vec4_kernel<WW>), grid, dim3(256), 0, c->stream, in4, om, oc, F, S4, fchunk, pad_max, pad_conv, bias, taps)
+#define VDET_TB(WW) hipLaunchKernelGGL((temporal_both_vec4_kernel<WW>), grid, dim3(256), 0, c->stream, in4, om, oc, F, S4, fchunk, pad_max, pad_conv, bias, taps, d_seg)
     if (window == 3) VDET_TB(3); else if (window == 5) VDET_TB(5); else VDET_TB(7);
 #undef VDET_TB
     HIPCHK(c, hipGetLastError());
@@ -1907,9 +2064,52 @@ int vdet_temporal_maxpool_conv_f32(vdet_ctx *c, const float *d_in, float *d_out_
 }
 
 // ---------------------------------------------------------------------------------------------
+static int volume_pass_impl(vdet_ctx *c, const float *d_scores, int64_t F, int64_t B, int64_t C, int window, float pad_max,
+                            const float *h_taps, float bias, float pad_conv, float *d_out_max, float *d_out_conv,
+                            int use_score_thresh, float score_thresh, const int2 *d_seg);
+
 int vdet_volume_pass(vdet_ctx *c, const float *d_scores, int64_t F, int64_t B, int64_t C, int window, float pad_max,
                      const float *h_taps, float bias, float pad_conv, float *d_out_max, float *d_out_conv,
                      int use_score_thresh, float score_thresh)
+{
+    return volume_pass_impl(c, d_scores, F, B, C, window, pad_max, h_taps, bias, pad_conv, d_out_max, d_out_conv, use_score_thresh,
+                            score_thresh, nullptr);
+}
+
+// frame offsets of V concatenated videos -> per-frame {first, one past last} table on the device (kept in the context)
+static int upload_segments(vdet_ctx *c, const int64_t *h_frame_off, int64_t V, int64_t *Ftot)
+{
+    if (!h_frame_off || V <= 0 || h_frame_off[0] != 0) return fail(c, VDET_EINVAL, "frame offsets must start at 0");
+    for (int64_t v = 0; v < V; ++v)
+        if (h_frame_off[v + 1] < h_frame_off[v]) return fail(c, VDET_EINVAL, "frame offsets must not decrease");
+    const int64_t F = h_frame_off[V];
+    if (F > 0x7FFFFFF0ll) return fail(c, VDET_EINVAL, "too many frames");
+    (void)host_sync(c);      // (an earlier copy from the host table may be in flight)
+    c->h_seg.resize((size_t)std::max<int64_t>(F, 1));
+    for (int64_t v = 0; v < V; ++v)
+        for (int64_t f = h_frame_off[v]; f < h_frame_off[v + 1]; ++f) c->h_seg[(size_t)f] = make_int2((int)h_frame_off[v], (int)h_frame_off[v + 1]);
+    HIPCHK(c, c->segtab.reserve(c->h_seg.size() * sizeof(int2)));
+    if (F) HIPCHK(c, hipMemcpyAsync(c->segtab.p, c->h_seg.data(), (size_t)F * sizeof(int2), hipMemcpyHostToDevice, c->stream));
+    *Ftot = F;
+    return VDET_OK;
+}
+
+int vdet_volume_pass_batch(vdet_ctx *c, const float *d_scores, const int64_t *h_frame_off, int64_t V, int64_t B, int64_t C,
+                           int window, float pad_max, const float *h_taps, float bias, float pad_conv, float *d_out_max,
+                           float *d_out_conv, int use_score_thresh, float score_thresh)
+{
+    if (!c) return VDET_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    int64_t F = 0;
+    const int rc = upload_segments(c, h_frame_off, V, &F);
+    if (rc) return rc;
+    return volume_pass_impl(c, d_scores, F, B, C, window, pad_max, h_taps, bias, pad_conv, d_out_max, d_out_conv, use_score_thresh,
+                            score_thresh, c->segtab.as<int2>());
+}
+
+static int volume_pass_impl(vdet_ctx *c, const float *d_scores, int64_t F, int64_t B, int64_t C, int window, float pad_max,
+                            const float *h_taps, float bias, float pad_conv, float *d_out_max, float *d_out_conv,
+                            int use_score_thresh, float score_thresh, const int2 *d_seg)
 {
     if (!c) return VDET_EINVAL;
     if (window < 1 || window % 2 != 1) return fail(c, VDET_EINVAL, "Window size must be odd!");
@@ -1941,8 +2141,9 @@ int vdet_volume_pass(vdet_ctx *c, const float *d_scores, int64_t F, int64_t B, i
     }
     if (!items) {
         // shapes the fused kernel does not cover: the temporal pass(es) now, the key transpose with the sort
-        if (conv) return vdet_temporal_maxpool_conv_f32(c, d_scores, d_out_max, d_out_conv, F, B * C, window, pad_max, h_taps, bias, pad_conv);
-        return vdet_temporal_maxpool_f32(c, d_scores, d_out_max, F, B * C, window, pad_max);
+        if (conv) return temporal_maxpool_conv_impl(c, d_scores, d_out_max, d_out_conv, F, B * C, window, pad_max, h_taps, bias, pad_conv, d_seg);
+        Taps t0{};
+        return temporal_launch(c, 0, d_scores, d_out_max, F, B * C, window, pad_max, 0.0f, t0, d_seg);
     }
     HIPCHK(c, hipSetDevice(c->device));
     timing_reset(c);
@@ -1981,7 +2182,7 @@ int vdet_volume_pass(vdet_ctx *c, const float *d_scores, int64_t F, int64_t B, i
     if (nokeys) keys = nullptr;
     int Fi = (int)F, Bi = (int)B, C4i = (int)C4;
     void *args[] = {&in4, &om, &oc, &keys, &Fi, &Bi, &C4i, &TB, &tb_shift, (void *)&fchunk, &pad_max, &pad_conv, &bias, &taps,
-                    &use_score_thresh, &score_thresh};
+                    &use_score_thresh, &score_thresh, (void *)&d_seg};
     {
         StageTimer tm(c, ST_TEMPORAL);
         HIPCHK(c, hipLaunchKernel(fn, grid, dim3((unsigned)NT), args, lds, c->stream));

@@ -167,8 +167,9 @@ def temporal_maxpool_conv(vol, window, taps, pad_max=-1e5, bias=0.0, pad_conv=0.
     return out_m, out_c
 
 
-def volume_pass(scores, window=3, taps=None, pad_max=-1e5, bias=0.0, pad_conv=0.0, score_thresh=None, ctx=None):
-    """ONE read of a score volume [F,B,C]: ``temporal_maxpool(scores, window, pad_max)``, optionally
+def volume_pass(scores, window=3, taps=None, pad_max=-1e5, bias=0.0, pad_conv=0.0, score_thresh=None, ctx=None, frame_off=None):
+    """(``frame_off`` [V+1]: the volume is V videos concatenated along F -- a temporal window stops at its video's ends.)
+    ONE read of a score volume [F,B,C]: ``temporal_maxpool(scores, window, pad_max)``, optionally
     ``temporal_conv(scores, taps, bias, pad_conv)`` (len(taps) == window), and -- left inside the context for
     the next ``nms_volume`` / ``track_volume`` / ``nms_track_volume`` call on the SAME scores tensor (cache
     enabled) -- the class-major sort keys of every (frame, class) problem (include/vdet_hip.h: vdet_volume_pass).
@@ -189,12 +190,75 @@ def volume_pass(scores, window=3, taps=None, pad_max=-1e5, bias=0.0, pad_conv=0.
     ctx = _ctx_for(scores, ctx)
     out_m = torch.empty_like(scores)
     out_c = torch.empty_like(scores) if t is not None else None
-    ctx.check(ctx.lib.vdet_volume_pass(ctx.h, scores.data_ptr(), F, B, C, int(window), float(pad_max),
-                                       t.ctypes.data if t is not None else None, float(bias), float(pad_conv),
-                                       out_m.data_ptr(), out_c.data_ptr() if out_c is not None else None,
-                                       0 if score_thresh is None else 1,
-                                       0.0 if score_thresh is None else float(score_thresh)))
+    tail = (int(window), float(pad_max), t.ctypes.data if t is not None else None, float(bias), float(pad_conv),
+            out_m.data_ptr(), out_c.data_ptr() if out_c is not None else None, 0 if score_thresh is None else 1,
+            0.0 if score_thresh is None else float(score_thresh))
+    if frame_off is None:
+        ctx.check(ctx.lib.vdet_volume_pass(ctx.h, scores.data_ptr(), F, B, C, *tail))
+    else:
+        off = _frame_offsets(frame_off, F)
+        ctx.check(ctx.lib.vdet_volume_pass_batch(ctx.h, scores.data_ptr(), off.ctypes.data, len(off) - 1, B, C, *tail))
     return out_m, out_c
+
+
+def _frame_offsets(frame_off, F):
+    off = np.ascontiguousarray(frame_off, dtype=np.int64).reshape(-1)
+    if off.size < 2 or off[0] != 0 or off[-1] != F or np.any(np.diff(off) <= 0):
+        raise ValueError("frame_off must run 0 = o[0] < o[1] < ... < o[V] = F")
+    return off
+
+
+def video_batch(boxes, scores, frame_off, nms_thres=0.3, thres=0.0, max_tracks=10, link_thres=0.5, max_frames=0, cap=None,
+                nms=True, rescore=True, overlap_thres=0.7, window=3, sync=True, ctx=None, pad=True):
+    """V small videos in ONE call (include/vdet_hip.h: vdet_video_batch): boxes [F,B,4] / scores [F,B,C] hold the frames
+    of all videos one after the other, ``frame_off`` [V+1] their frame ranges.  Per video the results are what
+    ``nms_track_volume`` + ``rescore_tracks`` return for it alone.  Returns a dict:
+      keep_idx [F,C,cap] / keep_cnt [F,C] (nms), anchors [V,C,T,3], ntracks [V,C], and per-video VIEWS
+      tracks[v] [C,T,F_v,5], det[v] / pooled[v] [C,T,F_v] f64, tboxes[v] [C,T,F_v,4] (rescore)."""
+    if boxes.dtype != torch.float32 or scores.dtype != torch.float32:
+        raise ValueError("Buffer dtype mismatch, expected 'float32_t'")
+    boxes, scores = boxes.contiguous(), scores.contiguous()
+    F, B, C = scores.shape
+    if tuple(boxes.shape) != (F, B, 4):
+        raise ValueError("boxes must be [F,B,4]")
+    off = _frame_offsets(frame_off, F)
+    V, T = len(off) - 1, int(max_tracks)
+    ctx = _ctx_for(boxes, ctx)
+    dev = boxes.device
+    cap = B if cap is None else int(cap)
+    keep_idx = _keep_buffer((F, C, cap), dev, pad) if nms else None
+    keep_cnt = torch.zeros((F, C), dtype=torch.int32, device=dev) if nms else None
+    tracks = torch.full((C * max(T, 1) * F * 5,), float('nan'), dtype=torch.float32, device=dev)
+    anchors = torch.zeros((V, C, max(T, 1), 3), dtype=torch.float32, device=dev)
+    ntracks = torch.zeros((V, C), dtype=torch.int32, device=dev)
+    det = torch.empty((C * max(T, 1) * F,), dtype=torch.float64, device=dev) if rescore else None
+    pooled = torch.empty_like(det) if rescore else None
+    tboxes = torch.empty((C * max(T, 1) * F * 4,), dtype=torch.float32, device=dev) if rescore else None
+
+    def launch():
+        ctx.check(ctx.lib.vdet_video_batch(
+            ctx.h, boxes.data_ptr(), scores.data_ptr(), off.ctypes.data, V, B, C, float(nms_thres), float(thres), T, float(link_thres),
+            int(max_frames), tracks.data_ptr(), anchors.data_ptr(), ntracks.data_ptr(), cap,
+            keep_idx.data_ptr() if nms else None, keep_cnt.data_ptr() if nms else None, float(overlap_thres), int(window),
+            det.data_ptr() if rescore else None, pooled.data_ptr() if rescore else None, tboxes.data_ptr() if rescore else None))
+
+    def reset():
+        tracks.fill_(float('nan'))
+        if nms and pad:
+            keep_idx.fill_(-1)
+
+    _finish(ctx, launch, sync, reset=reset)
+    out = dict(keep_idx=keep_idx, keep_cnt=keep_cnt, anchors=anchors[:, :, :T], ntracks=ntracks, frame_off=off)
+    tv, dv, pv, bv = [], [], [], []
+    for v in range(V):
+        f0, fv = int(off[v]), int(off[v + 1] - off[v])
+        tv.append(tracks[C * T * 5 * f0: C * T * 5 * (f0 + fv)].view(C, T, fv, 5))
+        if rescore:
+            dv.append(det[C * T * f0: C * T * (f0 + fv)].view(C, T, fv))
+            pv.append(pooled[C * T * f0: C * T * (f0 + fv)].view(C, T, fv))
+            bv.append(tboxes[C * T * 4 * f0: C * T * 4 * (f0 + fv)].view(C, T, fv, 4))
+    out.update(tracks=tv, det=dv, pooled=pv, tboxes=bv)
+    return out
 
 
 def iou(boxes1, boxes2):
