@@ -758,6 +758,35 @@ __global__ __launch_bounds__(kAdjRows) void adj_build_kernel(const float4 *__res
             uint64_t mm[kAdjBatch];
 #pragma unroll
             for (int j = 0; j < kAdjBatch; ++j) mm[j] = (wb + j < w1 && live(wb + j)) ? col[(int64_t)(wb + j) * B] : 0ull;
+            if (staged) {
+                // (round 3) every half word of the batch gets its place in the stage from a prefix sum of the popcounts, so the
+                // 2 * kAdjBatch extraction chains are independent of each other: at 2 waves per SIMD the kernel is bound by the
+                // LATENCY of its dependent instructions (find-first-set -> store -> clear), not by their number.  A row has
+                // ~1.2 neighbours per 32 columns: four unconditional slots per half word, a loop for what is left.
+                uint32_t qs = q;
+#pragma unroll
+                for (int j = 0; j < kAdjBatch; ++j) {
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf) {
+                        uint32_t h = hf ? (uint32_t)(mm[j] >> 32) : (uint32_t)mm[j];
+                        const uint32_t col0 = (uint32_t)((wb + j) * 64 + hf * 32);
+                        uint32_t qx = qs;
+                        qs += (uint32_t)__popc(h);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            if (h != 0u) sstage[qx] = (uint16_t)(col0 + (uint32_t)(__ffs((int)h) - 1));
+                            qx += h != 0u ? 1u : 0u;
+                            h &= h - 1u;
+                        }
+                        while (h) {
+                            sstage[qx++] = (uint16_t)(col0 + (uint32_t)(__ffs((int)h) - 1));
+                            h &= h - 1u;
+                        }
+                    }
+                }
+                q = qs;
+                continue;
+            }
 #pragma unroll
             for (int j = 0; j < kAdjBatch; ++j) {
                 uint64_t m = mm[j];
