@@ -309,6 +309,17 @@ def main():
         fence()
         return bool(again)
 
+    # priming (untimed, before the W warm-up steps): two rounds over the streams, so that every context has sized its
+    # scratch and torch's caching allocator holds a block for every output of every stream -- a first-touch hipMalloc
+    # inside the timed region stalls all streams (seen once as a 2x step time right after a cold start)
+    for _ in range(2 * nstreams):
+        step()
+    for cx in ctxs:
+        try:
+            cx.sync()
+        except _lib.RetryError:
+            pass
+    fence()
     if warm():
         warm()
     t0 = time.perf_counter()
