@@ -330,7 +330,12 @@ def main():
     for cx in ctxs:
         cx.sync()       # surfaces latched device-side failures (capacity / zero union)
     tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if one_gpu else dev)
+    by_rank = None
     if world > 1:
+        # every rank's own time for its K steps (between the same two barriers): the line reports them next to the MAX
+        allt = torch.empty(world, dtype=torch.float64, device=tmax.device)
+        dist.all_gather_into_tensor(allt, tmax)
+        by_rank = [float(x) for x in allt.tolist()]
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     ms_per_step = dt / args.steps * 1e3
@@ -633,6 +638,11 @@ def main():
                        "parallelism": "video-per-gpu x%d, %d distinct videos in flight per GPU%s" % (
                            world, nstreams, ", heavy phases gated one at a time" if args.gate == "heavy" and nstreams > 1 else "")},
             "exchange": exchange,
+            "per_rank": None if by_rank is None else {
+                "ms_per_step": [t / args.steps * 1e3 for t in by_rank],
+                "boxes_per_s": [F * B * args.steps / t for t in by_rank],
+                "hbm_frac_algorithmic": [F * B * args.steps / t * (16 * C + 16) / HBM_PEAK for t in by_rank],
+                "note": "each rank's own wall time for the K timed steps (its video per step + the exchange); value uses the MAX"},
             "single_video_ms": single_video_ms,          # one video at a time (no videos in flight): the latency of one step
             "value_other_scores": value_other,           # the same step on the other synthetic score distribution
             "hbm_traffic_per_video": hbm_total,          # sum of the PMC table (profiles/pmc_traffic.json), all kernels of one step

@@ -237,6 +237,17 @@ int vdet_nms_volume_topk(vdet_ctx *ctx, const float *d_boxes, const float *d_sco
                          int64_t cap);
 
 /*
+ * vdet_nms_volume with the CALLER's order instead of the build's: d_order [F,C,B] uint16 lists every (frame, class)
+ * column's candidates in the order the greedy loop of utils/nms.pyx:26-66 is to visit them (the first d_ncand[f,c]
+ * entries; the rest is ignored), e.g. vdet_argsort_volume's lists with ties rearranged the way a particular machine's
+ * unstable `scores.argsort()[::-1]` (utils/nms.pyx:25) left them -- the volume-scale form of vdet_nms_f32's h_order.
+ * An entry must be a box index < B and appear once per list.
+ */
+int vdet_nms_volume_ordered(vdet_ctx *ctx, const float *d_boxes, const uint16_t *d_order, const int32_t *d_ncand,
+                            int64_t F, int64_t B, int64_t C, double thresh, int32_t *d_keep_idx,
+                            int32_t *d_keep_cnt, int64_t cap);
+
+/*
  * Batched small videos (BASELINE configs[0] / [4] shapes: hundreds of frames x <= 300 boxes x 30 classes -- a single
  * such video is launch-bound).  The frames of V videos are concatenated along F; h_frame_off [V+1] (host, starts at 0,
  * strictly increasing) gives every video its frame range.  What does not look across frames -- the suppression graph,

@@ -166,3 +166,33 @@ def test_threshold_and_fcb_layout():
     o2, n2, nfail2 = run(s, layout="FCB")
     eo2, en2 = expected(s)
     assert np.array_equal(o2, eo2) and np.array_equal(n2, en2) and nfail2 == 0
+
+
+def test_volume_nms_with_a_recorded_tie_order(oracle):
+    """the volume-scale form of nms(dets, thresh, order): quantised scores, ties visited in ASCENDING index order (what a
+    different argsort would leave) -- the lists come from argsort_volume, every tied run is reversed, and the walk follows
+    them: survivors == the oracle's greedy loop fed the same order (utils/nms.pyx:26-66)."""
+    import synth
+    F, B, C = 2, 700, 3
+    boxes, scores = synth.video(31, F, B, C)
+    scores = (np.round(scores * 12) / 12).astype(np.float32)             # 13 distinct values: long tied runs
+    tb, ts = torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda()
+    order, ncand = ops.argsort_volume(ts)
+    o = order.cpu().numpy().astype(np.int64) & 0xFFFF
+    rec = o.copy()
+    for f in range(F):
+        for c in range(C):
+            col = scores[f, o[f, c], c]
+            start = 0
+            for q in range(1, B + 1):
+                if q == B or col[q] != col[start]:
+                    rec[f, c, start:q] = o[f, c, start:q][::-1]          # ties by ascending index
+                    start = q
+    assert not np.array_equal(rec, o)
+    ki, kc = ops.nms_volume_ordered(tb, torch.from_numpy(rec.astype(np.int16)).cuda(), ncand, 0.3)
+    for f in range(F):
+        for c in range(C):
+            d = np.hstack([boxes[f], scores[f, :, c:c + 1]]).astype(np.float32)
+            want = oracle.nms(d, 0.3, order=rec[f, c])
+            n = int(kc[f, c])
+            assert n == len(want) and ki[f, c, :n].cpu().numpy().tolist() == want

@@ -34,6 +34,8 @@ def test_bench_two_ranks_one_gpu_dry_run():
     assert r["n_gpus"] == 2 and r["steps"] == 3 and r["scaling"] == "weak"
     assert r["value"] > 0 and abs(r["value"] - 2 * 12 * 2000 * 3 / (r["ms_per_step"] * 3e-3)) / r["value"] < 1e-6
     assert "all-gather" in r["config"]["workload"]
+    assert len(r["per_rank"]["ms_per_step"]) == 2 and max(r["per_rank"]["ms_per_step"]) == pytest.approx(r["ms_per_step"], rel=1e-6)
+    assert r["exchange"]["world"] == 2 and r["exchange"]["exchange_ms"] > 0
 
 
 def test_rccl_exchange_executes_in_a_world_of_one():

@@ -507,6 +507,8 @@ struct SortWalkArgs {
     bool walk_only = false;       // the lists of a previous call are still valid
     uint16_t *order_out = nullptr;   // default: ctx scratch (c->order / c->ncand)
     int32_t *ncand_out = nullptr;
+    const uint16_t *order_in = nullptr;   // walk_only: the caller's own lists instead of the context's
+    const int32_t *ncand_in = nullptr;
     int mode, P, B, C;
     const float *scores;
     const uint32_t *keys;
@@ -663,8 +665,8 @@ int launch_sort_walk(vdet_ctx *c, const SortWalkArgs &a, int nmax, int64_t order
     WalkParams wp{};
     wp.mode = a.mode; wp.P = a.P; wp.B = a.B; wp.C = a.C;
     wp.groups = c->groups.as<GroupDesc>();
-    wp.order = c->order.as<uint16_t>();
-    wp.ncand = c->ncand.as<int32_t>();
+    wp.order = a.order_in ? a.order_in : c->order.as<uint16_t>();
+    wp.ncand = a.order_in ? a.ncand_in : c->ncand.as<int32_t>();
     wp.row_meta = c->rowmeta.as<uint2>();
     wp.adj = c->adj.as<uint16_t>();
     wp.group_z = c->groupz.as<uint32_t>();
@@ -1261,6 +1263,42 @@ int vdet_nms_volume_topk(vdet_ctx *c, const float *d_boxes, const float *d_score
     c->prep.thr = score_thresh; c->prep.topk = topk;
     c->lists_valid = true;
     return VDET_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+int vdet_nms_volume_ordered(vdet_ctx *c, const float *d_boxes, const uint16_t *d_order, const int32_t *d_ncand, int64_t F, int64_t B,
+                            int64_t C, double thresh, int32_t *d_keep_idx, int32_t *d_keep_cnt, int64_t cap)
+{
+    if (!c) return VDET_EINVAL;
+    if (F < 0 || B < 0 || C < 0 || cap < 0) return fail(c, VDET_EINVAL, "bad shape");
+    if (F == 0 || C == 0) return VDET_OK;
+    if (!d_keep_cnt || (cap > 0 && !d_keep_idx)) return fail(c, VDET_EINVAL, "null output");
+    if (B > 32767) return fail(c, VDET_EINVAL, "B = %lld boxes per frame; the limit is 32767", (long long)B);
+    if (F * C > 0x7FFFFFF0ll || F * B > 0x7FFFFFF0ll) return fail(c, VDET_EINVAL, "volume too large");
+    HIPCHK(c, hipSetDevice(c->device));
+    timing_reset(c);
+    if (B == 0) {
+        HIPCHK(c, hipMemsetAsync(d_keep_cnt, 0, (size_t)(F * C) * 4, c->stream));
+        return VDET_OK;
+    }
+    if (!d_boxes || !d_order || !d_ncand) return fail(c, VDET_EINVAL, "null buffer");
+    if (((uintptr_t)d_boxes & 15) != 0) return fail(c, VDET_EINVAL, "d_boxes must be 16-byte aligned");
+    const float t32 = thresh_to_f32(thresh);
+    const bool same_geo = c->cache_enabled && c->graph_valid && c->prep.boxes == d_boxes && c->prep.F == F &&
+                          c->prep.B == B && memcmp(&c->prep.t32, &t32, 4) == 0;
+    if (!same_geo) {
+        c->graph_valid = c->lists_valid = false;
+        const int rc = build_graph(c, reinterpret_cast<const float4 *>(d_boxes), volume_plan(c, F, B), t32, thresh, true);
+        if (rc) return rc;
+        c->prep.boxes = d_boxes; c->prep.F = F; c->prep.B = B; c->prep.t32 = t32;
+        c->graph_valid = true;
+    }
+    SortWalkArgs a{};
+    a.walk_only = true;
+    a.mode = 1; a.P = (int)(F * C); a.B = (int)B; a.C = (int)C;
+    a.order_in = d_order; a.ncand_in = d_ncand;
+    a.keep_idx = d_keep_idx; a.keep_cnt = d_keep_cnt; a.cap = cap;
+    return launch_sort_walk(c, a, (int)B, F * C * B);
 }
 
 // ---------------------------------------------------------------------------------------------

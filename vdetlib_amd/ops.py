@@ -88,6 +88,29 @@ def nms_volume(boxes, scores, thresh=0.3, score_thresh=None, cap=None, layout="F
     return keep_idx, keep_cnt
 
 
+def nms_volume_ordered(boxes, order, ncand, thresh=0.3, cap=None, ctx=None, pad=True):
+    """``nms_volume`` walking the CALLER's lists: order int16/uint16 [F,C,B] (box indices, e.g. ``argsort_volume``'s with
+    ties rearranged as some machine's unstable ``scores.argsort()[::-1]`` left them, utils/nms.pyx:25), ncand int32 [F,C]
+    (how many entries of each list are candidates).  Returns (keep_idx [F,C,cap], keep_cnt [F,C])."""
+    if boxes.dtype != torch.float32:
+        raise ValueError("Buffer dtype mismatch, expected 'float32_t'")
+    if order.dtype not in (torch.int16, torch.uint16) or ncand.dtype != torch.int32:
+        raise ValueError("order must be (u)int16 [F,C,B], ncand int32 [F,C]")
+    boxes, order, ncand = boxes.contiguous(), order.contiguous(), ncand.contiguous()
+    F, B = boxes.shape[0], boxes.shape[1]
+    C = order.shape[1]
+    if tuple(order.shape) != (F, C, B) or tuple(ncand.shape) != (F, C) or boxes.shape[2] != 4:
+        raise ValueError("boxes [F,B,4], order [F,C,B], ncand [F,C]")
+    cap = B if cap is None else int(cap)
+    ctx = _ctx_for(boxes, ctx)
+    keep_idx = _keep_buffer((F, C, cap), boxes.device, pad)
+    keep_cnt = torch.zeros((F, C), dtype=torch.int32, device=boxes.device)
+    _finish(ctx, lambda: ctx.check(ctx.lib.vdet_nms_volume_ordered(
+        ctx.h, boxes.data_ptr(), order.data_ptr(), ncand.data_ptr(), F, B, C, float(thresh), keep_idx.data_ptr(),
+        keep_cnt.data_ptr(), cap)), True, reset=(lambda: keep_idx.fill_(-1)) if pad else None)
+    return keep_idx, keep_cnt
+
+
 def argsort_volume(scores, score_thresh=None, layout="FBC", ctx=None):
     """Descending argsort of every (frame, class) column of a score volume -- ``scores.argsort()[::-1]`` of
     utils/nms.pyx:25 / ``argsort(-cls_scores)`` of vdet/video_det.py:93 with the build's tie rule (equal scores by
