@@ -80,3 +80,40 @@ def test_sharding_rules():
     loads = [sum([300 * 10000, 30 * 300, 2000 * 300, 300 * 10000, 50 * 300, 700 * 2000][i] for i in o) for o in owned]
     assert abs(loads[0] - loads[1]) <= 700 * 2000
     assert vd.all_gather_ragged(torch.ones(3, 2))[0].shape == (3, 2)      # single process: identity
+
+
+def test_forced_exchange_in_a_world_of_one_gloo():
+    """dist.init(force=True): a single process still gets its process group, and the forced collectives run (the path
+    bench.py --force-exchange takes with RCCL on a single-GPU box)."""
+    assert not dist.is_initialized()
+    old = {k: os.environ.get(k) for k in ("MASTER_ADDR", "MASTER_PORT", "WORLD_SIZE", "RANK")}
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE="1", RANK="0")
+    try:
+        w, r, _ = vd.init(backend="gloo", force=True)
+        assert (w, r) == (1, 0) and dist.is_initialized() and dist.get_world_size() == 1
+        t = torch.arange(6, dtype=torch.float32).reshape(3, 2)
+        assert vd.all_gather_fixed(t)[0].data_ptr() == t.data_ptr()              # not forced: the identity, no collective
+        g = vd.all_gather_fixed(t, force=True)
+        assert tuple(g.shape) == (1, 3, 2) and torch.equal(g[0], t) and g.data_ptr() != t.data_ptr()
+        parts = vd.all_gather_ragged(torch.zeros((0, 4), dtype=torch.int32), force=True)
+        assert len(parts) == 1 and tuple(parts[0].shape) == (0, 4)
+        idx = torch.randint(0, 9, (2, 3, 4, 5), dtype=torch.int32)
+        cnt = torch.randint(0, 6, (2, 3, 4), dtype=torch.int32)
+        res = vd.gather_video_results([4, 1], idx, cnt, force=True)
+        assert sorted(res) == [1, 4] and torch.equal(res[4][0], idx[0]) and torch.equal(res[1][1], cnt[1])
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def test_frame_offsets_are_validated():
+    from vdetlib_amd import ops
+    assert ops._frame_offsets([0, 3, 7], 7).tolist() == [0, 3, 7]
+    for bad in ([1, 3, 7], [0, 3, 3, 7], [0, 8], [0], [0, 3, 6]):
+        with pytest.raises(ValueError):
+            ops._frame_offsets(bad, 7)
