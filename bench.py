@@ -160,7 +160,8 @@ def main():
     ap.add_argument("--no-link", action="store_true", help="NMS + temporal only")
     ap.add_argument("--no-conv", action="store_true", help="skip the temporal convolution pass (temporal max-pool only)")
     ap.add_argument("--separate", action="store_true", help="vdet_nms_volume + vdet_track_volume instead of the fused call")
-    ap.add_argument("--streams", type=int, default=3, help="videos in flight per GPU (one HIP stream + context each; measured: 3 > 4 > 2)")
+    ap.add_argument("--streams", type=int, default=4, help="videos in flight per GPU (one HIP stream + context each; round 3, with the tracking "
+                                                           "loop in one launch: 4 (12.63 ms) > 3 (12.75) = 5 > 2 (14.3); round 2: 3 > 4 > 2)")
     ap.add_argument("--cpu-problems", type=int, default=1200, help="(frame,class) problems timed on the CPU oracle")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--scores", choices=["rand", "randn"], default="rand", help="synthetic score distribution")
