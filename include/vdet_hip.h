@@ -253,7 +253,7 @@ int vdet_nms_volume_ordered(vdet_ctx *ctx, const float *d_boxes, const uint16_t 
  * strictly increasing) gives every video its frame range.  What does not look across frames -- the suppression graph,
  * the per-(frame, class) sorts and NMS walks (vdet/video_det.py:79-106 over utils/nms.pyx) -- runs ONCE for the whole
  * batch; tracking and re-scoring (vdet/track.py:189-252, vdet/tubelet_cls.py:493-535, :284-303, :386-414) run per
- * video on its frame range, 4 + 3 launches each.  Results are what vdet_nms_track_volume + vdet_rescore_tracks return
+ * video on its frame range with the video as a grid dimension (one launch per stage for ALL videos).  Results are what vdet_nms_track_volume + vdet_rescore_tracks return
  * for each video on its own, laid out video after video:
  *   d_tracks [sum_v C*T*F_v*5] (video v at C*T*5*h_frame_off[v]), d_anchors [V,C,T,3], d_ntracks [V,C],
  *   d_keep_idx [F,C,cap] / d_keep_cnt [F,C] over the concatenated frames (d_keep_cnt null: no NMS output),

@@ -1561,7 +1561,8 @@ int vdet_nms_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scor
 // one video alone is launch-bound at ~60 launches): the frames of all videos are concatenated along F -- per-frame NMS
 // problems do not know which video they belong to, so suppression graph, sort and walk are ONE launch sequence for the
 // whole batch -- and only the stages that follow a video in time (tracking, re-scoring) run per video, on sub-ranges
-// of the same buffers: 4 + 3 launches each instead of ~60, no host synchronisation in between.
+// of the same buffers, with the video as a grid dimension (batch_kernels.hpp): one launch per stage for all videos instead of
+// ~60 launches per video, no host synchronisation in between.
 // ---------------------------------------------------------------------------------------------
 int vdet_video_batch(vdet_ctx *c, const float *d_boxes, const float *d_scores, const int64_t *h_frame_off, int64_t V, int64_t B,
                      int64_t C, double nms_thres, double thres, int max_tracks, double link_thres, int max_frames,
