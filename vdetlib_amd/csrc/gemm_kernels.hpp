@@ -6,9 +6,13 @@
 //                            A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15];  D: col = l & 15, row = (l >> 4) + 4 * reg
 //   v_mfma_f32_16x16x4_f32   same A / B maps;                                       D: col = l & 15, row = 4 * (l >> 4) + reg
 // (maps: /opt/skills/guides/cdna_hip_programming.md section 3; the f64 D map differs from the f32 one.)
-// One wave owns a 16 x 64 strip of the output (4 accumulator tiles share every A fragment); K is walked 4 at a
-// time; out-of-range rows / columns / k are zero-filled on load and masked on store, so any n, k, m works.
-// Accumulation order per output element: k ascending, one fused multiply-add per product (an f64 / f32 fma chain).
+// A 256-thread block owns a 64 x 64 tile of the output, wave w its rows [16 w, 16 w + 16) (4 accumulator tiles share every
+// A fragment).  K is walked in chunks of 16: the 64 x 16 slice of the features and the 16 x 64 slice of W are staged in
+// LDS with coalesced, 4-element-per-thread global loads (round 3; round 2 fed every MFMA from scalar global loads), the
+// next chunk's loads are in flight while the current one is multiplied (register prefetch, two LDS buffers, one barrier
+// per chunk), and the A tile is padded to 17 columns so that the 16 rows of a fragment fall into different banks.
+// Out-of-range rows / columns / k are zero-filled on load and masked on store, so any n, k, m works.
+// Accumulation order per output element: k ascending, 4 products per MFMA (the instruction's own order), as before.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -30,36 +34,63 @@ template <> struct MfmaTile<float> {
     static __device__ __forceinline__ int row(int lane, int reg) { return 4 * (lane >> 4) + reg; }
 };
 
-// grid = (ceil(m / 64), ceil(n / 64)); block = 256 = 4 waves, wave w owns rows [16 * (4 * by + w), +16)
+// grid = (ceil(m / 64), ceil(n / 64)); block = 256 = 4 waves, wave w owns rows [64 * by + 16 * w, +16)
 template <typename T>
 __global__ __launch_bounds__(256) void svm_scores_kernel(const T *__restrict__ A, const T *__restrict__ W, const T *__restrict__ bias,
                                                          int64_t n, int64_t k, int64_t m, T *__restrict__ out)
 {
     typedef MfmaTile<T> MT;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int64_t row0 = ((int64_t)blockIdx.y * 4 + w) * 16;
-    const int64_t col0 = (int64_t)blockIdx.x * 64;
-    if (row0 >= n) return;
+    constexpr int BK = 16, AP = BK + 1;
+    __shared__ T As[2][64 * AP];            // [row][k], padded
+    __shared__ T Ws[2][BK * 64];            // [k][col]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int64_t row0 = (int64_t)blockIdx.y * 64, col0 = (int64_t)blockIdx.x * 64;
     const int li = lane & 15, lk = lane >> 4;
+    // my four elements of each staged slice: A row tid / 4, k (tid % 4) * 4 .. + 3;  W k tid / 16, columns (tid % 16) * 4 .. + 3
+    const int ar = tid >> 2, ak = (tid & 3) * 4, wk = tid >> 4, wc = (tid & 15) * 4;
+    const int64_t garow = row0 + ar;
+    T pa[4], pw[4];
+    auto fetch = [&](int64_t k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t kk = k0 + ak + i;
+            pa[i] = (garow < n && kk < k) ? A[garow * k + kk] : (T)0;
+        }
+        const int64_t kw = k0 + wk;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t c = col0 + wc + i;
+            pw[i] = (kw < k && c < m) ? W[kw * m + c] : (T)0;
+        }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { As[buf][ar * AP + ak + i] = pa[i]; Ws[buf][wk * 64 + wc + i] = pw[i]; }
+    };
     typename MT::acc_t acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[t][r] = (T)0;
-    const int64_t ar = row0 + li;
-    const T *arow = A + (ar < n ? ar : 0) * k;
-    for (int64_t k0 = 0; k0 < k; k0 += 4) {
-        const int64_t kk = k0 + lk;
-        const bool kin = kk < k;
-        const T a = (ar < n && kin) ? arow[kk] : (T)0;
-        T b[4];
+    fetch(0);
+    stage(0);
+    __syncthreads();
+    int buf = 0;
+    for (int64_t k0 = 0; k0 < k; k0 += BK) {
+        const bool more = k0 + BK < k;
+        if (more) fetch(k0 + BK);               // in flight while this chunk is multiplied
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int64_t c = col0 + 16 * t + li;
-            b[t] = (kin && c < m) ? W[kk * m + c] : (T)0;
+        for (int q = 0; q < BK / 4; ++q) {
+            const T a = As[buf][(16 * w + li) * AP + 4 * q + lk];
+            T b[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) b[t] = Ws[buf][(4 * q + lk) * 64 + 16 * t + li];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = MT::mma(a, b[t], acc[t]);
         }
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = MT::mma(a, b[t], acc[t]);
+        if (more) stage(buf ^ 1);               // (the other buffer was last read before the previous barrier)
+        __syncthreads();
+        buf ^= 1;
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -68,7 +99,7 @@ __global__ __launch_bounds__(256) void svm_scores_kernel(const T *__restrict__ A
         const T bv = bias ? bias[c] : (T)0;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int64_t rr = row0 + MT::row(lane, r);
+            const int64_t rr = row0 + 16 * w + MT::row(lane, r);
             if (rr < n) out[rr * m + c] = acc[t][r] + bv;
         }
     }
