@@ -115,3 +115,47 @@ def test_file_to_hbm_pipeline(tmp_path, oracle):
         assert np.array_equal(counts, n) and torch.equal(ts.cpu(), torch.from_numpy(s))
         widx, wcnt = oracle.nms_volume(b, s, 0.3, score_thresh=float('-inf'), frames=(0, 10))
         assert np.array_equal(cnt[:10].cpu().numpy(), wcnt[:10]) and np.array_equal(idx[:10].cpu().numpy(), widx[:10])
+
+
+def test_vid_shape_batch_map_parity(oracle):
+    """configs[4] through the BATCHED entry points: four annotated VID-shaped videos of different lengths, ragged proposals
+    padded to one B, frames concatenated -> ops.volume_pass(frame_off=...) + ops.video_batch -> detections -> VOC-style
+    AP, against the oracle's tubelets of every video on its own: identical detections, AP per class and mAP."""
+    import torch
+    from vdetlib_amd import ops, io as vio
+    from vdetlib_amd import eval as vev
+    T, Bmax, C = 3, 300, 30
+    vids = []
+    for seed, F in ((9101, 120), (9102, 200), (9103, 90), (9104, 150)):
+        vid, frame_to_det, annot = vid_shape_video(seed, F=F, Bmax=Bmax, C=C)
+        b, s, counts = vio.arrays_from_frame_to_det(vid, frame_to_det)
+        if b.shape[1] < Bmax:                                     # one B for the whole batch: more padding
+            pad = Bmax - b.shape[1]
+            b = np.concatenate([b, np.tile(vio.pad_boxes(Bmax)[None, b.shape[1]:], (F, 1, 1))], 1)
+            s = np.concatenate([s, np.full((F, pad, C), -np.inf, np.float32)], 1)
+        vids.append((annot, b, s))
+    off = np.concatenate([[0], np.cumsum([b.shape[0] for _, b, _ in vids])])
+    boxes = torch.from_numpy(np.concatenate([b for _, b, _ in vids])).cuda()
+    scores = torch.from_numpy(np.concatenate([s for _, _, s in vids])).cuda()
+    pooled_vol, _ = ops.volume_pass(scores, 3, frame_off=off)
+    out = ops.video_batch(boxes, scores, off, nms_thres=0.3, thres=0.5, max_tracks=T, link_thres=0.4, overlap_thres=0.5, window=3)
+    gpu_dets, cpu_dets, annots = [], [], []
+    for v, (annot, b, s) in enumerate(vids):
+        annots.append(annot)
+        f0, f1 = int(off[v]), int(off[v + 1])
+        assert np.array_equal(pooled_vol[f0:f1, :6].cpu().numpy(), oracle.temporal_maxpool(s[:, :6], 3))
+        wtr, wnt, wsc, wbx = oracle.rescored_tubelets(b, s, 0.3, 0.5, T, 0.4, 0.5, 3)
+        nt = out["ntracks"][v].cpu().numpy()
+        assert np.array_equal(nt, wnt)
+        tr, pooled, ob = out["tracks"][v].cpu().numpy(), out["pooled"][v].cpu().numpy(), out["tboxes"][v].cpu().numpy()
+        for c in range(C):
+            n = int(wnt[c])
+            assert np.array_equal(tr[c, :n], wtr[c, :n], equal_nan=True)
+            np.testing.assert_allclose(pooled[c, :n], wsc[c, :n], rtol=0, atol=1e-9, equal_nan=True)
+            assert np.array_equal(ob[c, :n], wbx[c, :n], equal_nan=True)
+        gpu_dets += vev.detections_from_tracks(annot['video'], tr, nt, pooled, ob)
+        cpu_dets += vev.detections_from_tracks(annot['video'], wtr, wnt, wsc, wbx)
+    gt = vev.ground_truth_from_annots(annots)
+    aps_g, map_g = vev.evaluate(gpu_dets, gt)
+    aps_c, map_c = vev.evaluate(cpu_dets, gt)
+    assert gpu_dets == cpu_dets and aps_g == aps_c and map_g == map_c and map_g > 0.5
