@@ -918,6 +918,7 @@ __device__ __forceinline__ void lsd_sort_problem(const SortParams &prm, const in
     uint16_t *dst = reinterpret_cast<uint16_t *>(smem + prm.lds_idxb_off);
     uint32_t *bases = reinterpret_cast<uint32_t *>(smem + prm.lds_base_off);   // [NW][256]
     uint32_t *tot = bases + NW * 256;                                           // [256] + [1] excluded count
+    __shared__ uint32_t swt[4];                                                 // digit totals of the four scanning waves
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const ProblemRef pr = decode_problem(prm.mode, p, prm.B, prm.C, prm.groups);
@@ -1026,34 +1027,31 @@ __device__ __forceinline__ void lsd_sort_problem(const SortParams &prm, const in
             }
         }
         __syncthreads();
-        if (tid < 256) {   // per digit: exclusive prefix over the waves, total
-            uint32_t run = 0;
+        // digit offsets folded into the per-wave bases in two steps (round 3; three before, the middle one a single wave's
+        // shuffle scan): thread d sums digit d over the waves and the 64 digits of a wave are scanned on the DPP network;
+        // after the barrier every thread adds the earlier waves' totals and writes base[wave][d] = offset of digit d +
+        // keys of digit d in earlier waves -- the scatter then makes ONE table look-up per key
+        uint32_t dsum = 0, dincl = 0;
+        if (tid < 256) {
+#pragma unroll
+            for (int ww = 0; ww < NW; ++ww) dsum += bases[ww * 256 + tid];
+            dincl = dsum;
+#define VDET_SCAN_STEP(CTRL, ROWMASK) dincl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)dincl, CTRL, ROWMASK, 0xf, false);
+            VDET_SCAN_STEP(0x111, 0xf) VDET_SCAN_STEP(0x112, 0xf) VDET_SCAN_STEP(0x114, 0xf) VDET_SCAN_STEP(0x118, 0xf)
+            VDET_SCAN_STEP(0x142, 0xa) VDET_SCAN_STEP(0x143, 0xc)
+#undef VDET_SCAN_STEP
+            if (lane == 63) swt[w] = dincl;
+        }
+        __syncthreads();
+        if (tid < 256) {
+            uint32_t run = dincl - dsum;
+            for (int k = 0; k < w; ++k) run += swt[k];
 #pragma unroll
             for (int ww = 0; ww < NW; ++ww) {
                 const uint32_t c = bases[ww * 256 + tid];
                 bases[ww * 256 + tid] = run;
                 run += c;
             }
-            tot[tid] = run;
-        }
-        __syncthreads();
-        if (w == 0) {      // exclusive scan of the 256 digit totals by one wave (4 digits per lane)
-            const uint32_t a0 = tot[lane * 4], a1 = tot[lane * 4 + 1], a2 = tot[lane * 4 + 2], a3 = tot[lane * 4 + 3];
-            const uint32_t s4 = a0 + a1 + a2 + a3;
-            uint32_t inc = s4;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t t = __shfl_up(inc, d, 64);
-                if (lane >= d) inc += t;
-            }
-            const uint32_t ex = inc - s4;
-            tot[lane * 4] = ex; tot[lane * 4 + 1] = ex + a0; tot[lane * 4 + 2] = ex + a0 + a1; tot[lane * 4 + 3] = ex + a0 + a1 + a2;
-        }
-        __syncthreads();
-        if (tid < 256) {   // fold the digit offsets into the per-wave bases: the scatter then makes ONE table look-up per
-            const uint32_t t = tot[tid];        // key instead of two (the kernel is LDS-bound: profiles/r02_pmc_sq2.csv)
-#pragma unroll
-            for (int ww = 0; ww < NW; ++ww) bases[ww * 256 + tid] += t;
         }
         __syncthreads();
 #pragma unroll
