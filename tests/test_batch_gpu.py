@@ -91,3 +91,29 @@ def test_volume_pass_stops_at_video_borders(C, window):
         pm, pc = ops.volume_pass(t, window, taps)
         f0, f1 = int(off[v]), int(off[v + 1])
         assert torch.equal(pooled[f0:f1], pm) and torch.equal(conv[f0:f1], pc), v
+
+
+def test_batch_options_and_limits():
+    """no tracks / no NMS output / no re-scoring; one video == the single-video call; a video too long for the batched
+    re-scoring (> 1 536 frames) is refused, offsets are validated"""
+    frames = [4, 6]
+    vids, off, boxes, scores = _videos(frames, 90, 3, seed=40)
+    out = ops.video_batch(boxes, scores, off, max_tracks=0, nms=True, rescore=False, nms_thres=0.3)
+    i0, c0 = ops.nms_volume(boxes, scores, 0.3)
+    assert torch.equal(out["keep_cnt"], c0) and torch.equal(out["keep_idx"], i0) and int(out["ntracks"].sum()) == 0
+    out = ops.video_batch(boxes, scores, off, nms=False, rescore=False, **KW)
+    assert out["keep_cnt"] is None and out["pooled"] == [] and len(out["tracks"]) == 2
+    b, s = vids[1]
+    tb, ts = torch.from_numpy(b).cuda(), torch.from_numpy(s).cuda()
+    tr, an, nt = ops.track_volume(tb, ts, **KW)
+    assert torch.equal(out["ntracks"][1], nt) and _eq(out["tracks"][1], tr)
+    one = ops.video_batch(tb, ts, [0, 6], nms=False, rescore=False, **KW)
+    assert torch.equal(one["ntracks"][0], nt) and _eq(one["tracks"][0], tr)
+    with pytest.raises(ValueError):
+        ops.video_batch(boxes, scores, [0, 4, 9], **KW)
+    with pytest.raises(ValueError):
+        ops.video_batch(boxes, scores, [0, 4, 4, 10], **KW)
+    long_b = torch.zeros((1600, 8, 4), device="cuda") + torch.tensor([0.0, 0.0, 9.0, 9.0], device="cuda")
+    long_s = torch.rand((1600, 8, 2), device="cuda")
+    with pytest.raises(ValueError):
+        ops.video_batch(long_b, long_s, [0, 1600], **KW)
