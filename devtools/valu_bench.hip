@@ -105,6 +105,46 @@ __global__ __launch_bounds__(256) void valu_kernel(float *out, float seed)
 #define OP(i) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(c), "v"(b));
             REP8(OP) REP8(OP)
 #undef OP
+        } else if (MODE == 19) {
+#define OP(i) asm volatile("v_pk_max_i16 %0, %0, %1" : "+v"(u[i]) : "v"(u[(i + 1) & 7]));
+            REP8(OP) REP8(OP)
+#undef OP
+        } else if (MODE == 20) {
+#define OP(i) asm volatile("v_pk_min_i16 %0, %0, %1" : "+v"(u[i]) : "v"(u[(i + 1) & 7]));
+            REP8(OP) REP8(OP)
+#undef OP
+        } else if (MODE == 21) {
+#define OP(i) asm volatile("v_pk_sub_i16 %0, %0, %1" : "+v"(u[i]) : "v"(u[(i + 1) & 7]));
+            REP8(OP) REP8(OP)
+#undef OP
+        } else if (MODE == 22) {
+#define OP(i) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(u[i]) : "v"(u[(i + 1) & 7]));
+            REP8(OP) REP8(OP)
+#undef OP
+        } else if (MODE == 23) {
+#define OP(i) asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(u[i]) : "v"(u[(i + 1) & 7]), "v"(u[(i + 2) & 7]));
+            REP8(OP) REP8(OP)
+#undef OP
+        } else if (MODE == 24) {
+#define OP(i) asm volatile("v_cvt_f32_u32 %0, %0" : "+v"(u[i]));
+            REP8(OP) REP8(OP)
+#undef OP
+        } else if (MODE == 25) {
+#define OP(i) asm volatile("v_pk_mad_u16 %0, %0, %1, %2" : "+v"(u[i]) : "v"(u[(i + 1) & 7]), "v"(u[(i + 2) & 7]));
+            REP8(OP) REP8(OP)
+#undef OP
+        } else if (MODE == 26) {
+#define OP(i) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(u[i]) : "v"(u[(i + 1) & 7]));
+            REP8(OP) REP8(OP)
+#undef OP
+        } else if (MODE == 27) {
+#define OP(i) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(u[i]) : "v"(u[(i + 1) & 7]));
+            REP8(OP) REP8(OP)
+#undef OP
+        } else if (MODE == 28) {
+#define OP(i) asm volatile("v_pk_max_u16 %0, %0, %1" : "+v"(u[i]) : "v"(u[(i + 1) & 7]));
+            REP8(OP) REP8(OP)
+#undef OP
         } else {
 #define OP(i) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
             REP8(OP) REP8(OP)
@@ -165,6 +205,16 @@ int main()
         ROW("v_min_f32", 16, 64)
         ROW("v_med3_f32", 17, 64)
         ROW("v_sub_f32", 18, 64)
+        ROW("v_pk_max_i16(x2)", 19, 128)
+        ROW("v_pk_min_i16(x2)", 20, 128)
+        ROW("v_pk_sub_i16(x2)", 21, 128)
+        ROW("v_mul_u32_u24", 22, 64)
+        ROW("v_mad_u32_u24", 23, 64)
+        ROW("v_cvt_f32_u32", 24, 64)
+        ROW("v_pk_mad_u16(x2)", 25, 128)
+        ROW("v_mul_lo_u32", 26, 64)
+        ROW("v_sub_u32", 27, 64)
+        ROW("v_pk_max_u16(x2)", 28, 128)
 #undef ROW
     }
     CHK(hipFree(d_out));

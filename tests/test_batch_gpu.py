@@ -31,10 +31,10 @@ def _eq(a, b):
     return torch.equal(a.nan_to_num(-7.0), b.nan_to_num(-7.0))
 
 
-@pytest.mark.parametrize("irregular", [None, (2, 5)])
-def test_batch_equals_one_video_at_a_time(irregular):
+@pytest.mark.parametrize("irregular,B", [(None, 150), ((2, 5), 150), (None, 151)])
+def test_batch_equals_one_video_at_a_time(irregular, B):
     frames = [7, 1, 12, 3, 9]
-    B, C = 150, 6
+    C = 6                       # (B odd: the compact u16 index pads every second frame)
     vids, off, boxes, scores = _videos(frames, B, C, irregular_at=irregular)
     cx = _lib.Context(torch.cuda.current_device())
     out = ops.video_batch(boxes, scores, off, overlap_thres=0.6, window=3, ctx=cx, **KW)

@@ -342,7 +342,7 @@ def test_track_volume_random_sweep(oracle, seed):
 
 @pytest.mark.parametrize("knob", ["VDET_FORCE_GENERAL", "VDET_NO_INDEX", "VDET_NO_TRANSPOSE", "VDET_NO_LAZY",
                                   "VDET_WAVE_TRANSPOSE=0", "VDET_ATOMIC_RANK=0", "VDET_LINK_MEMO=0", "VDET_LINK_THREADS=64",
-                                  "VDET_LINK_THREADS=128", "VDET_LINK_WARM=0", "VDET_LINK_MAXB=16", "VDET_AUX_STREAM=1", "VDET_WALK_CAREFUL=1", "VDET_WALK_PACKED=0", "VDET_WALK_PACKED=2", "VDET_SERIES_SERIAL=1", "VDET_LINK_MATERIALIZE=0", "VDET_RESCORE_ADJ=0", "VDET_TRACK_LOOP=0", "VDET_BINSORT=1"])
+                                  "VDET_LINK_THREADS=128", "VDET_LINK_WARM=0", "VDET_LINK_MAXB=16", "VDET_LINK_U16=0", "VDET_LINK_LPT=0", "VDET_AUX_STREAM=1", "VDET_WALK_CAREFUL=1", "VDET_WALK_PACKED=0", "VDET_WALK_PACKED=2", "VDET_SERIES_SERIAL=1", "VDET_LINK_MATERIALIZE=0", "VDET_RESCORE_ADJ=0", "VDET_TRACK_LOOP=0", "VDET_BINSORT=1"])
 def test_alternative_kernel_paths_agree(monkeypatch, knob):
     """Every A/B knob selects a different kernel path for the same result (general predicate kernel,
     no x-index, strided key reads, eager track_det_nms, ballot transposition in K1s, ballot ranks in
@@ -364,6 +364,39 @@ def test_alternative_kernel_paths_agree(monkeypatch, knob):
     got_r = ops.rescore_tracks(got[2], got[4], tb, ts, overlap_thres=0.6, window=3, ctx=cx)
     for a, b in zip(list(ref) + list(ref_r), list(got) + list(got_r)):
         assert np.array_equal(a.cpu().numpy(), b.cpu().numpy(), equal_nan=True), knob
+
+
+@pytest.mark.parametrize("B", [301, 64, 1, 2, 777])
+def test_link_compact_index_on_mixed_frames(oracle, monkeypatch, B):
+    """Frames of integer pixel coordinates are scanned through the compact u16 index (two candidates per load, groups at
+    even positions: odd B makes every second frame start on a pad), the others through the float4 index -- in one video:
+    fractional frames, a coordinate of exactly 65535 (still u16) and of 65536 (not), a -0.0 (not).  Tubelets identical to
+    the oracle's and to VDET_LINK_U16=0."""
+    import torch
+    from vdetlib_amd import ops, _lib
+    F, C = 11, 3
+    boxes, scores = synth.coherent_video(4100 + B, F, B, C, jitter=2)
+    boxes = np.abs(boxes)                                       # (no negative coordinates: every frame starts as u16)
+    boxes[..., 2:] = np.maximum(boxes[..., 2:], boxes[..., :2] + 3)
+    boxes[2] += np.float32(0.25)                                # fractional frame
+    boxes[5, 0] = [65000, 10, 65535, 90]                        # the largest u16
+    boxes[6, 0] = [65000, 10, 65536, 90]                        # one more: float4 path
+    boxes[8, B - 1, 0] = np.float32(-0.0)                       # sign bit set: float4 path
+    tb, ts = torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda()
+    kw = dict(nms_thres=0.3, thres=0.0, max_tracks=5, link_thres=0.4)
+    cx = _lib.Context(torch.cuda.current_device())
+    got = ops.track_volume(tb, ts, ctx=cx, **kw)
+    monkeypatch.setenv("VDET_LINK_U16", "0")
+    cf = _lib.Context(torch.cuda.current_device())
+    ref = ops.track_volume(tb, ts, ctx=cf, **kw)
+    for a, b in zip(got, ref):
+        assert np.array_equal(a.cpu().numpy(), b.cpu().numpy(), equal_nan=True)
+    tr, an, nt = (x.cpu().numpy() for x in got)
+    for c in range(C):
+        wt, wa, wn = oracle.greedy_track_volume(boxes, scores[:, :, c], 0.3, 0.0, 5, 0.4, 0)
+        assert nt[c] == wn and np.array_equal(an[c, :wn], wa[:wn]), c
+        assert np.array_equal(tr[c, :wn], wt[:wn], equal_nan=True), c
+    cx.close(); cf.close()
 
 
 def test_link_memo_shares_steps_across_chains(oracle):

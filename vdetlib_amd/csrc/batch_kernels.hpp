@@ -69,8 +69,9 @@ __device__ __forceinline__ VidView vid_view(const BatchTrack &bt, const int v)
     w.lists = bt.lists + f0 * C * B;
     w.cnt = bt.cnt + f0 * C;
     w.group_flags = bt.group_flags ? bt.group_flags + f0 : nullptr;
-    w.ix = FrameIndex{nullptr, nullptr, nullptr, nullptr};
-    if (bt.ix.xbox) w.ix = FrameIndex{bt.ix.xbox + f0 * B, bt.ix.xord + f0 * B, bt.ix.cum + f0 * 257, bt.ix.info + f0 * 4};
+    w.ix = FrameIndex{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    if (bt.ix.xbox) w.ix = FrameIndex{bt.ix.xbox + f0 * B, bt.ix.xord + f0 * B, bt.ix.cum + f0 * 257, bt.ix.info + f0 * 4,
+                                      bt.ix.xbox16, bt.ix.xord16, bt.ix.bias16 + f0 * (B + 1)};
     w.memo = bt.memo + 2 * f0 * B;
     w.warm = bt.warm + (int64_t)v * C * wm;
     w.chains = bt.chains + C * wm * 5 * f0;

@@ -70,6 +70,7 @@ constexpr int kStDivZero = 2;   // evaluated zero-union pair
 constexpr int kStPool = 4;      // adjacency pool too small (internal, retried by the host)
 constexpr int kStPoolAsync = 8; // ... in an asynchronous build (no retry possible: reported by vdet_sync)
 constexpr uint32_t kFlagRegular = 1u;   // group_flags bit: see frame_flags_kernel
+constexpr uint32_t kFlagU16 = 2u;       // group_flags bit: every coordinate of the frame is an integer in [0, 65535] (and not -0.0)
 
 // Sortable key of a float32 score: larger key == earlier in "argsort()[::-1]".
 // -0.0 == +0.0 (numpy compares them equal); NaN sorts last ascending => first descending.
@@ -201,7 +202,16 @@ struct FrameIndex {
     const uint16_t *xord;    // flat: original (in-group) index of each sorted box
     const uint32_t *cum;     // [G*257] cum[k] = #boxes with bucket < k
     const float *info;       // [G*4] xmin, scale (= 256 / (xmax - xmin)), wmax, unused
+    // kFlagU16 frames only (null: not built): the same sorted boxes as four u16 (8 B instead of 16) and their indices,
+    // each group at an EVEN position pair_pos() so that two neighbours leave in one 16-byte / one 4-byte load --
+    // the LINK window scans move 10 instead of 18 bytes per candidate
+    const uint2 *xbox16;
+    const uint16_t *xord16;
+    int64_t bias16;          // (batched videos: position of the view's first frame, see pair_pos)
 };
+
+// position of group g (first box box_off) in xbox16 / xord16: every group adds at most one pad element
+__device__ __host__ __forceinline__ int64_t pair_pos(int64_t box_off_plus_g) { return (box_off_plus_g + 1) & ~(int64_t)1; }
 
 __device__ __forceinline__ int xbucket(float x, float xmin, float scale)
 {
@@ -219,7 +229,9 @@ __global__ void xkey_kernel(const float4 *__restrict__ boxes, uint32_t *__restri
 // one block per frame (group): gather the sorted copy, frame extrema, bucket table
 __global__ __launch_bounds__(256) void frame_index_kernel(const float4 *__restrict__ boxes, const GroupDesc *__restrict__ groups,
                                                           const uint16_t *__restrict__ xord_all, float4 *__restrict__ xbox_all,
-                                                          uint32_t *__restrict__ cum, float *__restrict__ info)
+                                                          uint32_t *__restrict__ cum, float *__restrict__ info,
+                                                          const uint32_t *__restrict__ group_flags, uint2 *__restrict__ xbox16,
+                                                          uint16_t *__restrict__ xord16)
 {
     __shared__ float smin[256], smax[256], swm[256];
     __shared__ uint32_t hist[257];
@@ -230,9 +242,16 @@ __global__ __launch_bounds__(256) void frame_index_kernel(const float4 *__restri
     const uint16_t *xord = xord_all + fo;
     float4 *xbox = xbox_all + fo;
     float mn = 3.0e38f, mx = -3.0e38f, wm = 0.0f;
+    const bool u16 = xbox16 && (group_flags[f] & kFlagU16);
+    const int64_t p16 = pair_pos(fo + f);
     for (int r = tid; r < B; r += 256) {
-        const float4 b = fb[xord[r]];
+        const uint16_t o = xord[r];
+        const float4 b = fb[o];
         xbox[r] = b;
+        if (u16) {
+            xbox16[p16 + r] = make_uint2((uint32_t)b.x | ((uint32_t)b.y << 16), (uint32_t)b.z | ((uint32_t)b.w << 16));
+            xord16[p16 + r] = o;
+        }
         mn = fminf(mn, b.x); mx = fmaxf(mx, b.x); wm = fmaxf(wm, (b.z - b.x) + 1.0f);
     }
     smin[tid] = mn; smax[tid] = mx; swm[tid] = wm;
@@ -282,7 +301,7 @@ __global__ __launch_bounds__(256) void frame_flags_kernel(const float4 *__restri
                                                           int *__restrict__ n_irregular)
 {
     const GroupDesc gd = groups[blockIdx.x];
-    int bad = 0;
+    int bad = 0, wide = 0;
     const float inf = __uint_as_float(0x7F800000u);
     for (int v = threadIdx.x; v < gd.nbox; v += 256) {
         const float4 b = boxes[gd.box_off + v];
@@ -291,10 +310,16 @@ __global__ __launch_bounds__(256) void frame_flags_kernel(const float4 *__restri
         const bool ok = fabsf(b.x) < inf && fabsf(b.y) < inf && fabsf(b.z) < inf && fabsf(b.w) < inf &&
                         w > 0.0f && h > 0.0f && a < inf;
         bad |= ok ? 0 : 1;
+        // pixel coordinates that four u16 hold exactly (NaN fails the compares, -0.0 the sign test)
+        const bool small = b.x == truncf(b.x) && b.y == truncf(b.y) && b.z == truncf(b.z) && b.w == truncf(b.w) &&
+                           fmaxf(fmaxf(b.x, b.y), fmaxf(b.z, b.w)) <= 65535.0f &&
+                           ((__float_as_uint(b.x) | __float_as_uint(b.y) | __float_as_uint(b.z) | __float_as_uint(b.w)) >> 31) == 0u;
+        wide |= small ? 0 : 1;
     }
     const int any_bad = __syncthreads_or(bad);
+    const int any_wide = __syncthreads_or(wide);
     if (threadIdx.x == 0) {
-        group_flags[blockIdx.x] = any_bad ? 0u : kFlagRegular;
+        group_flags[blockIdx.x] = (any_bad ? 0u : kFlagRegular) | (any_wide ? 0u : kFlagU16);
         if (any_bad) atomicAdd(n_irregular, 1);
     }
 }

@@ -317,6 +317,43 @@ __device__ __forceinline__ void link_scan(const float4 *__restrict__ xb, const u
         }
     }
 }
+// The same batch over a kFlagU16 frame's compact index (FrameIndex::xbox16): WP PAIRS of neighbouring ranks per thread,
+// a pair's boxes in one 16-byte and its indices in one 4-byte load.  pb0 = first pair, ranks >= r1 are masked; ranks below
+// the window's start (the first pair's even half) are simply evaluated: the window only has to be a superset.
+__device__ __forceinline__ float4 unpack_box16(uint32_t lo, uint32_t hi)
+{
+    return make_float4((float)(lo & 0xFFFFu), (float)(lo >> 16), (float)(hi & 0xFFFFu), (float)(hi >> 16));
+}
+
+template <int WP, int LT>
+__device__ __forceinline__ void link_scan16(const uint4 *__restrict__ xb2, const uint32_t *__restrict__ xo2, int pb0, int r1,
+                                            int B, int tid, float4 cur, float carea, float link_t32, float t32e, float &bv,
+                                            int &bi, float4 &bb)
+{
+    uint4 xs[WP];
+    uint32_t xi[WP];
+    const int last = (B - 1) >> 1;
+#pragma unroll
+    for (int i = 0; i < WP; ++i) xs[i] = xb2[min(pb0 + i * LT + tid, last)];
+#pragma unroll
+    for (int i = 0; i < WP; ++i) xi[i] = xo2[min(pb0 + i * LT + tid, last)];
+#pragma unroll
+    for (int i = 0; i < WP; ++i) {
+        const int r = 2 * (pb0 + i * LT + tid);
+        const bool in0 = r < r1, in1 = r + 1 < r1;
+        const float4 b0 = unpack_box16(xs[i].x, xs[i].y), b1 = unpack_box16(xs[i].z, xs[i].w);
+        bool bd0, bd1;
+        const bool p0 = pred_regular(cur, carea, b0, box_area(b0), link_t32, t32e, bd0);
+        const bool p1 = pred_regular(cur, carea, b1, box_area(b1), link_t32, t32e, bd1);
+        if (__ballot(((p0 | bd0) & in0) | ((p1 | bd1) & in1))) {
+            const float v0 = link_iou(cur, carea, b0), v1 = link_iou(cur, carea, b1);
+            const int i0 = (int)(xi[i] & 0xFFFFu), i1 = (int)(xi[i] >> 16);
+            if (in0 && v0 >= link_t32 && (v0 > bv || (v0 == bv && i0 < bi))) { bv = v0; bi = i0; bb = b0; }
+            if (in1 && v1 >= link_t32 && (v1 > bv || (v1 == bv && i1 < bi))) { bv = v1; bi = i1; bb = b1; }
+        }
+    }
+}
+
 template <int LT>
 __global__ __launch_bounds__(LT) void track_link_kernel(const float4 *__restrict__ boxes, int F, int B, int max_tracks,
                                                           float link_t32, int reach, const TrackState *__restrict__ st,
@@ -537,10 +574,11 @@ __device__ __forceinline__ void track_link_memo_body(const int chain, const int 
     __shared__ float sv[2][LT / 64];
     __shared__ int si[2][LT / 64];
     __shared__ float4 sb[2][LT / 64];
-    __shared__ uint32_t scum[2][260];          // bucket table + (xmin, scale, wmax) of frame f in slot f & 1
+    __shared__ uint32_t scum[2][261];          // bucket table + (xmin, scale, wmax) + group flags of frame f in slot f & 1
     __shared__ int sstate[4];                  // node, fprev, step, done -- where wave 0's run of known steps ended
+    __shared__ int speek[2];                   // (per step parity) the scanned step turned out to be in the memo
     static_assert(LT % 64 == 0 && LT >= 64 && LT <= 1024, "whole waves");
-    constexpr int NPF = (260 + LT - 1) / LT;
+    constexpr int NPF = (261 + LT - 1) / LT;
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     int anchor_frame, anchor_box;
@@ -586,8 +624,16 @@ __device__ __forceinline__ void track_link_memo_body(const int chain, const int 
     int node = anchor_box, fprev = anchor_frame, step = 1;
     int tbl[2] = {-1, -1};           // which frame's table sits in scum[0] / scum[1]
     unsigned int nhit = 0, nmiss = 0;
+    // A step costs dependent memory round trips, not work.  After a step that had to be scanned, the next one is scanned
+    // WITHOUT asking the memo first (in the warm-up nearly every step is unknown), starting from the winner's box that the
+    // scan already holds; the memo word of the step is fetched alongside the window and only decides, afterwards, whether
+    // the chain goes back to following known steps.  Scanning a known step is redundant, never wrong: the scan and the memo
+    // hold the same next(f, j, dir).  One round trip per step instead of three (memo, current box, window).
+    bool scanning = false;
+    float4 cur_next = make_float4(0.f, 0.f, 0.f, 0.f);
     for (;;) {
         // ---- wave 0: the run of known steps from (fprev, node)
+        if (!scanning) {
         if (w == 0) {
             int done = 0;
             int pend_f = -1;                     // row not yet written: frame, IoU bits, box (load in flight)
@@ -633,32 +679,43 @@ __device__ __forceinline__ void track_link_memo_body(const int chain, const int 
         __syncthreads();
         node = sstate[0]; fprev = sstate[1]; step = sstate[2];
         if (sstate[3]) break;
+        }
         // ---- unknown step: scan frame f with the whole block (as track_link_kernel)
         ++nmiss;
         const int f = anchor_frame + dir * step;
         const int par = step & 1;
-        float4 cur = trunc4(boxes[(int64_t)fprev * B + node]);
+        unsigned long long peek = 0ull;          // (thread 0) was this step in the memo after all?
+        if (scanning && tid == 0) peek = memo_load(&mm[(int64_t)fprev * B + node]);
+        float4 cur = scanning ? cur_next : trunc4(boxes[(int64_t)fprev * B + node]);
         const float carea = box_area(cur);
         const float4 *fb = boxes + (int64_t)f * B;
         float bv = -1.0f;
         int bi = -1;
         float4 bb = cur;
-        const bool fast = group_flags && (group_flags[f] & kFlagRegular) && link_t32 > 1e-30f &&
-                          carea > 0.0f && carea < __uint_as_float(0x7F800000u);
-        if (fast && use_ix) {
-            const int slot = f & 1;
-            const int f2 = min(max(f + dir, 0), F - 1);
+        // the frame's flags travel with its bucket table (prefetched one step ahead): a global load here would be one more
+        // dependent round trip in front of the window loads
+        const int slot = f & 1;
+        uint32_t fflags = 0u;
+        if (use_ix && group_flags) {
             if (tbl[slot] != f) {    // (after a run of known steps) this frame's table was not prefetched
-                for (int i = tid; i < 260; i += LT)
-                    scum[slot][i] = i < 257 ? ix.cum[(int64_t)f * 257 + i] : __float_as_uint(ix.info[f * 4 + (i - 257)]);
+                for (int i = tid; i < 261; i += LT)
+                    scum[slot][i] = i < 257 ? ix.cum[(int64_t)f * 257 + i] : (i < 260 ? __float_as_uint(ix.info[f * 4 + (i - 257)]) : group_flags[f]);
                 __syncthreads();
                 tbl[slot] = f;
             }
+            fflags = scum[slot][260];
+        } else if (group_flags) {
+            fflags = group_flags[f];
+        }
+        const bool fast = (fflags & kFlagRegular) && link_t32 > 1e-30f && carea > 0.0f && carea < __uint_as_float(0x7F800000u);
+        if (fast && use_ix) {
+            const int f2 = min(max(f + dir, 0), F - 1);
             uint32_t pf[NPF];        // the next frame's table: loads issued here, stored to the other slot after the scan
 #pragma unroll
             for (int j = 0; j < NPF; ++j) {
                 const int i = tid + j * LT;
-                pf[j] = i < 257 ? ix.cum[(int64_t)f2 * 257 + min(i, 256)] : __float_as_uint(ix.info[f2 * 4 + min(i - 257, 2)]);
+                pf[j] = i < 257 ? ix.cum[(int64_t)f2 * 257 + min(i, 256)]
+                                : (i < 260 ? __float_as_uint(ix.info[f2 * 4 + (i - 257)]) : group_flags[f2]);
             }
             int r0, r1;
             {
@@ -670,6 +727,20 @@ __device__ __forceinline__ void track_link_memo_body(const int chain, const int 
                 r0 = (int)scum[slot][xbucket(fmaxf(lo, -3.0e38f), xmin, scale)];
                 r1 = (int)scum[slot][xbucket(fminf(hi, 3.0e38f), xmin, scale) + 1];
             }
+            if (ix.xbox16 && (fflags & kFlagU16)) {
+                // integer pixel coordinates: the compact index, two candidates per load
+                const int64_t p16 = pair_pos(ix.bias16 + (int64_t)f * (B + 1));
+                const uint4 *xb2 = reinterpret_cast<const uint4 *>(ix.xbox16 + p16);
+                const uint32_t *xo2 = reinterpret_cast<const uint32_t *>(ix.xord16 + p16);
+                int pb0 = r0 >> 1;
+                const int pe = (r1 + 1) >> 1;
+#define LSCAN16(W) link_scan16<W, LT>(xb2, xo2, pb0, r1, B, tid, cur, carea, link_t32, t32e, bv, bi, bb);
+                while (pe - pb0 > MAXB * LT) { LSCAN16(MAXB) pb0 += MAXB * LT; }
+                const int np = (pe - pb0 + LT - 1) / LT;
+                if (MAXB >= 16 && np > 12) { LSCAN16(16) } else if (MAXB >= 16 && np > 8) { LSCAN16(12) } else if (np > 4) { LSCAN16(8) }
+                else if (np > 2) { LSCAN16(4) } else if (np > 0) { LSCAN16(2) }
+#undef LSCAN16
+            } else {
             const float4 *xb = ix.xbox + (int64_t)f * B;
             const uint16_t *xo = ix.xord + (int64_t)f * B;
             // batches of at most MAXB boxes per thread: 16 = one memory round trip for a typical window at the price of
@@ -678,10 +749,11 @@ __device__ __forceinline__ void track_link_memo_body(const int chain, const int 
             while (r1 - rb0 > MAXB * LT) { LSCAN(MAXB) rb0 += MAXB * LT; }
             const int nb = (r1 - rb0 + LT - 1) / LT;
             if (MAXB >= 16 && nb > 12) { LSCAN(16) } else if (MAXB >= 16 && nb > 8) { LSCAN(12) } else if (nb > 4) { LSCAN(8) } else if (nb > 0) { LSCAN(4) }
+            }
             if (f2 != f) {
 #pragma unroll
                 for (int j = 0; j < NPF; ++j)
-                    if (tid + j * LT < 260) scum[slot ^ 1][tid + j * LT] = pf[j];
+                    if (tid + j * LT < 261) scum[slot ^ 1][tid + j * LT] = pf[j];
                 tbl[slot ^ 1] = f2;
             }
         } else {
@@ -699,6 +771,7 @@ __device__ __forceinline__ void track_link_memo_body(const int chain, const int 
         bi = __builtin_amdgcn_readlane(bi, 63);
         if (lane == 0) { sv[par][w] = bv; si[par][w] = bi; }
         if (bi >= 0 && my_bi == bi) sb[par][w] = bb;
+        if (tid == 0) speek[par] = (peek & kMemoValid) ? 1 : 0;
         __syncthreads();
         float best = sv[par][0];
         int bidx = si[par][0];
@@ -722,6 +795,18 @@ __device__ __forceinline__ void track_link_memo_body(const int chain, const int 
             if (nodes) nodes[f] = bidx;
         }
         node = bidx; fprev = f; ++step;
+        {
+            const int f2 = anchor_frame + dir * step;
+            if (step > reach || f2 < 0 || f2 >= F) break;
+        }
+        if (speek[par]) {           // the step just scanned was known: (warm-up, unlimited reach) its owner goes on from here
+            ++nhit;                 // (counted as found AND as scanned)
+            if (WARM && reach >= F) break;
+            scanning = false;
+        } else {
+            scanning = true;
+            cur_next = trunc4(sb[par][bw]);
+        }
     }
     if (stats && tid == 0) { atomicAdd(&stats[WARM ? 2 : 0], nhit); atomicAdd(&stats[WARM ? 3 : 1], nmiss); }
 }
@@ -733,10 +818,46 @@ __global__ __launch_bounds__(LT, (MODE == 1 && LT == 256 && MAXB == 8) ? 5 : 1) 
                                                              const uint32_t *__restrict__ group_flags,
                                                              const FrameIndex ix, double link_thres,
                                                              unsigned long long *memo, unsigned int *__restrict__ stats,
-                                                             const int32_t *__restrict__ warm, int32_t *__restrict__ nodes)
+                                                             const int32_t *__restrict__ warm, int32_t *__restrict__ nodes,
+                                                             const int32_t *__restrict__ order = nullptr)
 {
-    track_link_memo_body<LT, MODE, MAXB>(blockIdx.x, blockIdx.y == 0 ? 1 : -1, boxes, F, B, max_tracks, link_t32, reach, st, tracks,
+    int chain = blockIdx.x, dir = blockIdx.y == 0 ? 1 : -1;
+    if (order) {         // (warm-up) longest chains first: warm_order_kernel
+        const int e = order[blockIdx.y * gridDim.x + blockIdx.x];
+        chain = e >> 1;
+        dir = (e & 1) ? -1 : 1;
+    }
+    track_link_memo_body<LT, MODE, MAXB>(chain, dir, boxes, F, B, max_tracks, link_t32, reach, st, tracks,
                                          group_flags, ix, link_thres, memo, stats, warm, nodes);
+}
+
+// The warm-up's (chain, direction) pairs by DESCENDING length (frames from the anchor to the video's end in that direction,
+// capped by reach): a chain is a serial sequence of steps, the longest one (~F steps) bounds the kernel from below, and in
+// launch order it may start when most of the chip's block slots have already turned over several times.  One block,
+// counting sort on 256 length classes; order[i] = chain << 1 | (backward ? 1 : 0).
+__global__ __launch_bounds__(1024) void warm_order_kernel(const int32_t *__restrict__ warm, int n, int F, int B, int reach,
+                                                          int32_t *__restrict__ order)
+{
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t base[256];
+    const int tid = threadIdx.x;
+    if (tid < 256) hist[tid] = 0u;
+    __syncthreads();
+    auto bin_of = [&](int e) {
+        const int flat = warm[e >> 1];
+        if (flat < 0) return 255;
+        const int af = flat / B;
+        const int len = min((e & 1) ? af : F - 1 - af, reach);
+        return 254 - (int)(((int64_t)len * 254) / max(F, 1));
+    };
+    for (int e = tid; e < 2 * n; e += 1024) atomicAdd(&hist[bin_of(e)], 1u);
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (int k = 0; k < 256; ++k) { base[k] = run; run += hist[k]; }
+    }
+    __syncthreads();
+    for (int e = tid; e < 2 * n; e += 1024) order[atomicAdd(&base[bin_of(e)], 1u)] = e;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -99,7 +99,7 @@ struct vdet_ctx {
     int n_cu = 256;
     // scratch
     DevBuf boxes, scores, keys, excl, frames, groups, tiles, bits, rowz, rowmeta, groupz, adj, comp, origidx,
-        out64, trk_frames, trk_boxes, b1, b2, iou_out, order, ncand, keepidx, keepcnt, gflags, pairs, tkeys, tstate, visited, heads, xkeys, xord, wmeta, reachtab, xncand, xbox, xcum, xinfo, tmp[8];
+        out64, trk_frames, trk_boxes, b1, b2, iou_out, order, ncand, keepidx, keepcnt, gflags, pairs, tkeys, tstate, visited, heads, xkeys, xord, wmeta, reachtab, xncand, xbox, xbox16, xord16, xcum, xinfo, tmp[8];
     // timing
     bool timing = false;
     bool timing_accumulate = false;   // vdet_set_timing(ctx, 2): keep events across calls until read
@@ -164,9 +164,11 @@ struct vdet_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool use_aux = false;         // VDET_AUX_STREAM=1: warm-up next to the walk on a second stream (A-B knob; measured: no gain,
                                   // 19.2 vs 19.7 ms one video at a time, 17.9 vs 16.9 with 3 in flight -- more streams than hardware queues)
+    bool link_lpt = true;         // VDET_LINK_LPT=0: the warm-up's chains in launch order instead of longest first (A-B knob)
+    bool link_u16 = true;         // VDET_LINK_U16=0: the LINK window scans read the float4 index on every frame (A-B knob)
     int link_maxb = 8;            // VDET_LINK_MAXB=8|16: boxes per thread and batch in the warm-up's window scans (A-B knob)
     int link_warm = -1;           // VDET_LINK_WARM=m: chains warmed per class (-1: max_tracks + 2; 0: none)
-    DevBuf linkmemo, linkstats, linkwarm, linkchains, linknodes, tracknode, rtodo;
+    DevBuf linkmemo, linkstats, linkwarm, linkorder, linkchains, linknodes, tracknode, rtodo;
     // which proposal every row of the last tracking call's tracks is (written by the link kernels; vdet_rescore_tracks
     // then finds a tubelet box's overlapping detections among that proposal's graph neighbours)
     struct NodeKey { const void *tracks = nullptr, *boxes = nullptr; int64_t F = 0, B = 0, C = 0; int T = 0; double nms_thres = 0; } nodekey;
@@ -304,6 +306,10 @@ int build_frame_index(vdet_ctx *c, const float4 *d_boxes, int64_t ntot, int64_t 
     HIPCHK(c, c->xord.reserve((size_t)ntot * 2));
     HIPCHK(c, c->xncand.reserve((size_t)G * 4));
     HIPCHK(c, c->xbox.reserve((size_t)ntot * 16));
+    if (c->link_u16) {      // compact copy for frames of integer pixel coordinates (kFlagU16): every group at an even position
+        HIPCHK(c, c->xbox16.reserve((size_t)(ntot + G + 4) * 8));
+        HIPCHK(c, c->xord16.reserve((size_t)(ntot + G + 4) * 2));
+    }
     HIPCHK(c, c->xcum.reserve((size_t)G * 257 * 4));
     HIPCHK(c, c->xinfo.reserve((size_t)G * 16));
     StageTimer tm(c, ST_OTHER);
@@ -312,7 +318,9 @@ int build_frame_index(vdet_ctx *c, const float4 *d_boxes, int64_t ntot, int64_t 
     int rc = sort_groups_by_keys(c, (int)G, nmax, ntot);
     if (rc) return rc;
     hipLaunchKernelGGL(frame_index_kernel, dim3((unsigned)G), dim3(256), 0, c->stream, d_boxes, c->groups.as<GroupDesc>(),
-                       c->xord.as<uint16_t>(), c->xbox.as<float4>(), c->xcum.as<uint32_t>(), c->xinfo.as<float>());
+                       c->xord.as<uint16_t>(), c->xbox.as<float4>(), c->xcum.as<uint32_t>(), c->xinfo.as<float>(),
+                       c->gflags.as<uint32_t>(), c->link_u16 ? c->xbox16.as<uint2>() : (uint2 *)nullptr,
+                       c->link_u16 ? c->xord16.as<uint16_t>() : (uint16_t *)nullptr);
     HIPCHK(c, hipGetLastError());
     c->index_valid = true; c->index_boxes = d_boxes; c->index_F = G; c->index_B = ntot;
     return VDET_OK;
@@ -320,7 +328,8 @@ int build_frame_index(vdet_ctx *c, const float4 *d_boxes, int64_t ntot, int64_t 
 
 FrameIndex frame_index_of(vdet_ctx *c)
 {
-    return FrameIndex{c->xbox.as<float4>(), c->xord.as<uint16_t>(), c->xcum.as<uint32_t>(), c->xinfo.as<float>()};
+    return FrameIndex{c->xbox.as<float4>(), c->xord.as<uint16_t>(), c->xcum.as<uint32_t>(), c->xinfo.as<float>(),
+                      c->link_u16 ? c->xbox16.as<uint2>() : nullptr, c->link_u16 ? c->xord16.as<uint16_t>() : nullptr, 0};
 }
 
 // The plan of a regular volume (one group of B boxes per frame).  Built on the host once per geometry
@@ -475,7 +484,7 @@ int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32, doub
                                    c->bits.as<uint64_t>(), c->rowz.as<uint32_t>(), c->rowmeta.as<uint2>(),
                                    c->adj.as<uint16_t>(), &c->d_cnt->pool_used, pool_cap,
                                    &c->d_cnt->status, use_sym ? c->gflags.as<uint32_t>() : (const uint32_t *)nullptr,
-                                   use_sym ? frame_index_of(c) : FrameIndex{nullptr, nullptr, nullptr, nullptr}, one_minus_t,
+                                   use_sym ? frame_index_of(c) : FrameIndex{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0}, one_minus_t,
                                    async ? (kStPool | kStPoolAsync) : kStPool,
                                    c->wmeta_built ? c->wmeta.as<WalkMeta>() : (WalkMeta *)nullptr,
                                    use_sym ? c->reachtab.as<float2>() : (const float2 *)nullptr);
@@ -850,6 +859,8 @@ int vdet_create(vdet_ctx **out, int device)
     if (const char *e = getenv("VDET_TRACK_LOOP")) c->track_loop = atoi(e) != 0;
     if (const char *e = getenv("VDET_LINK_WARM")) c->link_warm = atoi(e);
     if (const char *e = getenv("VDET_LINK_MAXB")) c->link_maxb = atoi(e) == 16 ? 16 : 8;
+    if (const char *e = getenv("VDET_LINK_U16")) c->link_u16 = atoi(e) != 0;
+    if (const char *e = getenv("VDET_LINK_LPT")) c->link_lpt = atoi(e) != 0;
     if (const char *e = getenv("VDET_AUX_STREAM")) c->use_aux = atoi(e) != 0;
     if (const char *e = getenv("VDET_LINK_THREADS")) { const int v = atoi(e); if (v == 64 || v == 128 || v == 256) c->link_threads = v; }
     if (const char *e = getenv("VDET_DEBUG_SYNC")) c->debug_sync = atoi(e) != 0;
@@ -922,8 +933,8 @@ int vdet_destroy(vdet_ctx *c)
     DevBuf *bufs[] = {&c->boxes, &c->scores, &c->keys, &c->excl, &c->frames, &c->groups, &c->tiles, &c->bits,
                       &c->rowz, &c->rowmeta, &c->groupz, &c->adj, &c->comp, &c->origidx, &c->out64,
                       &c->trk_frames, &c->trk_boxes, &c->b1, &c->b2, &c->iou_out, &c->order, &c->ncand, &c->keepidx,
-                      &c->keepcnt, &c->gflags, &c->pairs, &c->tkeys, &c->tstate, &c->visited, &c->heads, &c->xkeys, &c->xord, &c->xncand, &c->linkmemo, &c->linkstats, &c->linkwarm, &c->linkchains, &c->linknodes, &c->tracknode, &c->rtodo,
-                      &c->xbox, &c->xcum, &c->xinfo, &c->wmeta, &c->reachtab, &c->sortctl, &c->segtab, &c->vidtab};
+                      &c->keepcnt, &c->gflags, &c->pairs, &c->tkeys, &c->tstate, &c->visited, &c->heads, &c->xkeys, &c->xord, &c->xncand, &c->linkmemo, &c->linkstats, &c->linkwarm, &c->linkorder, &c->linkchains, &c->linknodes, &c->tracknode, &c->rtodo,
+                      &c->xbox, &c->xbox16, &c->xord16, &c->xcum, &c->xinfo, &c->wmeta, &c->reachtab, &c->sortctl, &c->segtab, &c->vidtab};
     for (DevBuf *b : bufs) b->release();
     for (DevBuf &b : c->tmp) b.release();
     for (auto &e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -1424,11 +1435,18 @@ int vdet_nms_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scor
             hipLaunchKernelGGL(track_warm_anchors_kernel, dim3((unsigned)C), dim3(256), 0, ws, c->tkeys.as<uint32_t>(),
                                c->order.as<uint16_t>(), c->ncand.as<int32_t>(), (int)F, (int)B, (int)C, d_scores, thres, wm,
                                c->linkwarm.as<int32_t>());
+            const int32_t *w_order = nullptr;
+            if (c->link_lpt) {       // longest chains first
+                HIPCHK(c, c->linkorder.reserve((size_t)C * wm * 2 * 4));
+                hipLaunchKernelGGL(warm_order_kernel, dim3(1), dim3(1024), 0, ws, c->linkwarm.as<int32_t>(), (int)(C * wm), (int)F, (int)B,
+                                   reach, c->linkorder.as<int32_t>());
+                w_order = c->linkorder.as<int32_t>();
+            }
 #define VDET_WARM(MB) hipLaunchKernelGGL((track_link_memo_kernel<256, 1, MB>), dim3((unsigned)(C * wm), 2), dim3(256), 0, ws, \
                                reinterpret_cast<const float4 *>(d_boxes), (int)F, (int)B, max_tracks, link_t32, reach, \
                                (const TrackState *)nullptr, (float *)nullptr, w_flags, w_ix, link_thres, \
                                c->linkmemo.as<unsigned long long>(), c->linkstats.as<unsigned int>(), c->linkwarm.as<int32_t>(), \
-                               (int32_t *)nullptr)
+                               (int32_t *)nullptr, w_order)
             if (c->link_maxb == 16) VDET_WARM(16); else VDET_WARM(8);
 #undef VDET_WARM
             if (c->link_materialize) {
@@ -1470,7 +1488,7 @@ int vdet_nms_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scor
     sp.adj = c->adj.as<uint16_t>();
     sp.group_z = c->groupz.as<uint32_t>();
     sp.group_flags = regular_ok ? c->gflags.as<uint32_t>() : nullptr;
-    sp.ix = FrameIndex{nullptr, nullptr, nullptr, nullptr};
+    sp.ix = FrameIndex{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
     if (sp.group_flags && c->index_valid && !c->no_index) sp.ix = frame_index_of(c);   // built by build_graph
     sp.thres = nms_thres;
     sp.lists = c->order.as<uint16_t>();
@@ -1657,7 +1675,7 @@ int vdet_video_batch(vdet_ctx *c, const float *d_boxes, const float *d_scores, c
     bt.boxes = reinterpret_cast<const float4 *>(d_boxes); bt.scores = d_scores;
     bt.keys = c->tkeys.as<uint32_t>(); bt.lists = c->order.as<uint16_t>(); bt.cnt = c->ncand.as<int32_t>();
     bt.group_flags = g_flags;
-    bt.ix = have_ix ? frame_index_of(c) : FrameIndex{nullptr, nullptr, nullptr, nullptr};
+    bt.ix = have_ix ? frame_index_of(c) : FrameIndex{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
     bt.memo = c->linkmemo.as<unsigned long long>(); bt.stats = c->linkstats.as<unsigned int>();
     bt.warm = c->linkwarm.as<int32_t>(); bt.chains = c->linkchains.as<float>(); bt.chain_nodes = c->linknodes.as<int32_t>();
     bt.track_nodes = c->tracknode.as<int32_t>();
