@@ -16,5 +16,6 @@ for rep in range(3):
     o, n = ops.argsort_volume(s, layout="FCB")
     t = ctx.last_timing()
     print(kind, (F, B, C), "sort %.3f ms  fallback kernel %.3f ms  columns handed over: %d" % (t["sort"][0], t["sort_fallback"][0], ctx.query(9)), flush=True)
-ref = torch.argsort(s[:2], dim=2, descending=True, stable=True)
-print("matches torch.argsort on 2 frames (no ties):", bool((o[:2].to(torch.int64) == ref).all()))
+ref = torch.argsort(s[:2], dim=2, descending=True, stable=True)     # (equal scores: the build orders by descending index)
+print("same scores in the same order as torch.argsort on 2 frames:",
+      bool((torch.gather(s[:2], 2, o[:2].to(torch.int64)) == torch.gather(s[:2], 2, ref)).all()))

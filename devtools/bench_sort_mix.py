@@ -58,5 +58,6 @@ print("LSD + LSD halves         %.3f ms" % run((0, 2), F // 2), flush=True)
 print("counting + counting      %.3f ms" % run((1, 3), F // 2), flush=True)
 for frac in (0.3, 0.4, 0.5, 0.6, 0.7):
     print("LSD %.0f %% + counting %.0f %%  %.3f ms" % (100 * frac, 100 - 100 * frac, run((0, 1), int(F * frac))), flush=True)
-ref = torch.argsort(s[:1], dim=2, descending=True, stable=True)
-print("matches torch.argsort on frame 0:", bool((order[:1].to(torch.int64) == ref).all()))
+ref = torch.argsort(s[:1], dim=2, descending=True, stable=True)     # (equal scores: the build orders by descending index)
+print("same scores in the same order as torch.argsort on frame 0:",
+      bool((torch.gather(s[:1], 2, order[:1].to(torch.int64)) == torch.gather(s[:1], 2, ref)).all()))
