@@ -141,6 +141,14 @@ __global__ __launch_bounds__(256) void valu_kernel(float *out, float seed)
 #define OP(i) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(u[i]) : "v"(u[(i + 1) & 7]));
             REP8(OP) REP8(OP)
 #undef OP
+        } else if (MODE == 29) {
+#define OP(i) asm volatile("v_alignbit_b32 %0, %0, %1, 31" : "+v"(u[i]) : "v"(u[(i + 1) & 7]));
+            REP8(OP) REP8(OP)
+#undef OP
+        } else if (MODE == 30) {
+#define OP(i) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a[i]) : "s"(c));
+            REP8(OP) REP8(OP)
+#undef OP
         } else if (MODE == 28) {
 #define OP(i) asm volatile("v_pk_max_u16 %0, %0, %1" : "+v"(u[i]) : "v"(u[(i + 1) & 7]));
             REP8(OP) REP8(OP)
@@ -215,6 +223,8 @@ int main()
         ROW("v_mul_lo_u32", 26, 64)
         ROW("v_sub_u32", 27, 64)
         ROW("v_pk_max_u16(x2)", 28, 128)
+        ROW("v_alignbit_b32", 29, 64)
+        ROW("v_max_f32(sgpr operand)", 30, 64)
 #undef ROW
     }
     CHK(hipFree(d_out));

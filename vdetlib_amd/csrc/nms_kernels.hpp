@@ -377,6 +377,37 @@ __device__ __forceinline__ bool pred_regular(float4 br, float rarea, float4 bc, 
     return p;
 }
 
+// The same test as two SIGNED margins (K1s, round 3): r = inter - t32 * uni and q = inter - t_lo * uni, each one fma
+// (sign exact), t_lo = t32 * (1 - 2^-21) rounded.  sign(r) clear <=> the predicate holds; sign(q) clear while sign(r) is
+// set <=> the pair sits in the band just below the threshold where only the IEEE quotient decides (q >= r always, the
+// band is >= 0.875 * 2^-21 * t32 * uni wide, the test above needs 2^-22).  The caller shifts BOTH sign bits into
+// accumulators with one v_alignbit_b32 each -- no compare, no add-with-carry, no per-pair border flag: after 32 pairs the
+// two words differ iff some pair was borderline.  (v_alignbit_b32 turned out to issue at half rate like v_cmp,
+// profiles/r03_valu_bench.csv: 2 fma + 2 alignbit ~ 6 issue slots against fma + mul + 2 v_cmp + v_addc ~ 7.)
+// (r is never -0.0: an exact zero rounds to +0.0, and the product -t32 * uni is never zero on a regular frame)
+// INTS: the frame's coordinates are integers (kFlagU16) and x2 / y2 arrive with the +1 already added -- every sum below
+// is an exact integer whatever the order, so the two "+ 1" of the reference's formula cost nothing.
+template <bool XSORTED, bool INTS>
+__device__ __forceinline__ void pred_margins(float4 br, float rarea, float4 bc, float carea, float t32, float t_lo, float &r, float &q)
+{
+    const float xx1 = XSORTED ? bc.x : amax(br.x, bc.x);
+    const float yy1 = amax(br.y, bc.y);
+    const float xx2 = amin(br.z, bc.z);
+    const float yy2 = amin(br.w, bc.w);
+    const float w = INTS ? amax(0.0f, xx2 - xx1) : amax(0.0f, (xx2 - xx1) + 1.0f);
+    const float h = INTS ? yy2 - yy1 : (yy2 - yy1) + 1.0f;       // (not clamped: see pred_regular)
+    const float inter = w * h;
+    const float uni = (rarea + carea) - inter;
+    r = __builtin_fmaf(-t32, uni, inter);
+    q = __builtin_fmaf(-t_lo, uni, inter);
+}
+
+// acc = (acc << 1) | sign bit of v, one full-rate VALU instruction
+__device__ __forceinline__ void shl1_or_sign(uint32_t &acc, float v)
+{
+    acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(v), 31);
+}
+
 // ------------------------------------------------------------------------------------------------
 // 64 x 64 bit-matrix transpose inside one wave: lane j holds row j as (lo, hi); afterwards lane k
 // holds column k.  Six butterfly stages (distance 32, 16, 8, 4, 2, 1), each exchanging the
@@ -509,6 +540,8 @@ __global__ __launch_bounds__(256) void reach_table_kernel(const float4 *__restri
     }
 }
 
+// (the 32-pair loops are unrolled 8 at a time: fully unrolled, the scheduler hoists the LDS reads of a dozen columns and
+//  ends at 158 registers, 3 waves per SIMD and 2.5 ms)
 template <bool WT>
 __global__ __launch_bounds__(256) void iou_bits_sym_kernel(const float4 *__restrict__ xbox,
                                                            const GroupDesc *__restrict__ groups,
@@ -536,17 +569,23 @@ __global__ __launch_bounds__(256) void iou_bits_sym_kernel(const float4 *__restr
         if (tp.ct * 4 >= W || rtab[tp.ct * 4].y > tr) return;       // (block-uniform)
     }
     const float t32e = t32 * 4.76837158203125e-7f;   // 2^-21
+    const float t_lo = t32 * (1.0f - 4.76837158203125e-7f);
     const TransposeConsts tcs = transpose_consts(lane);
+    // integer pixel coordinates (kFlagU16): x2 + 1 / y2 + 1 are formed once per box instead of once per pair
+    const bool ints = WT && (group_flags[tp.group] & kFlagU16) != 0u;
 
     float4 br = make_float4(0.f, 0.f, 0.f, 0.f);
     if (v < B) br = xbox[gd.box_off + v];
     const float rarea = box_area(br);
+    float4 brx = br;
+    if (ints) { brx.z += 1.0f; brx.w += 1.0f; }
     {
         const int u = tp.ct * 256 + tid;
         float4 bc = make_float4(0.f, 0.f, 0.f, 0.f);
         if (u < B) bc = xbox[gd.box_off + u];
-        sbox[tid] = bc;
         sarea[tid] = box_area(bc);
+        if (ints) { bc.z += 1.0f; bc.w += 1.0f; }
+        sbox[tid] = bc;
     }
     __syncthreads();
     const int rows_left = B - r * 64;
@@ -565,23 +604,32 @@ __global__ __launch_bounds__(256) void iou_bits_sym_kernel(const float4 *__restr
         if (rows_left <= 0 || (c > r && rtab[c].y > my_reach)) continue;
         {
             bool anyb = false;
-            if (WT && c > r) {      // off-diagonal block: every column starts at or to the right of every row (x1 order)
-#pragma unroll
-                for (int kk = 0; kk < 32; ++kk) {
-                    const int k = 31 - kk;
-                    bool border;
-                    const bool p = pred_regular<true>(br, rarea, sbox[q * 64 + k], sarea[q * 64 + k], t32, t32e, border);
-                    anyb |= border;
-                    shl1_or_pred(lo, p);
+            if (WT) {
+                // sign bits of the two margins, shifted in (descending k leaves column k in bit k); lo / hi = the complement
+                uint32_t nr0 = 0, nq0 = 0, nr1 = 0, nq1 = 0;
+#define VDET_MARGIN_BLOCK(XS, IN) \
+                _Pragma("unroll 1") for (int g = 0; g < 4; ++g) { \
+                    _Pragma("unroll") for (int j = 0; j < 8; ++j) { \
+                        const int k = 31 - 8 * g - j; \
+                        float mr, mq; \
+                        pred_margins<XS, IN>(brx, rarea, sbox[q * 64 + k], sarea[q * 64 + k], t32, t_lo, mr, mq); \
+                        shl1_or_sign(nr0, mr); shl1_or_sign(nq0, mq); \
+                    } \
+                } \
+                _Pragma("unroll 1") for (int g = 0; g < 4; ++g) { \
+                    _Pragma("unroll") for (int j = 0; j < 8; ++j) { \
+                        const int k = 31 - 8 * g - j; \
+                        float mr, mq; \
+                        pred_margins<XS, IN>(brx, rarea, sbox[q * 64 + 32 + k], sarea[q * 64 + 32 + k], t32, t_lo, mr, mq); \
+                        shl1_or_sign(nr1, mr); shl1_or_sign(nq1, mq); \
+                    } \
                 }
-#pragma unroll
-                for (int kk = 0; kk < 32; ++kk) {
-                    const int k = 31 - kk;
-                    bool border;
-                    const bool p = pred_regular<true>(br, rarea, sbox[q * 64 + 32 + k], sarea[q * 64 + 32 + k], t32, t32e, border);
-                    anyb |= border;
-                    shl1_or_pred(hi, p);
-                }
+                // (off-diagonal block: every column starts at or to the right of every row in the x1 order)
+                if (ints) { if (c > r) { VDET_MARGIN_BLOCK(true, true) } else { VDET_MARGIN_BLOCK(false, true) } }
+                else { if (c > r) { VDET_MARGIN_BLOCK(true, false) } else { VDET_MARGIN_BLOCK(false, false) } }
+#undef VDET_MARGIN_BLOCK
+                lo = ~nr0; hi = ~nr1;
+                anyb = (nr0 != nq0) | (nr1 != nq1);
             } else {
 #pragma unroll
             for (int kk = 0; kk < 32; ++kk) {
@@ -615,7 +663,9 @@ __global__ __launch_bounds__(256) void iou_bits_sym_kernel(const float4 *__restr
                 // redo this 64 x 64 block with the IEEE quotient
                 lo = hi = tlo = thi = 0;
                 for (int k = 0; k < 64; ++k) {
-                    const bool p = pair_pred_exact_slow(br, rarea, sbox[q * 64 + k], sarea[q * 64 + k], t32);
+                    float4 bk = sbox[q * 64 + k];
+                    if (ints) { bk.z -= 1.0f; bk.w -= 1.0f; }        // (exact: integers)
+                    const bool p = pair_pred_exact_slow(br, rarea, bk, sarea[q * 64 + k], t32);
                     if (k < 32) lo |= p ? (1u << k) : 0u; else hi |= p ? (1u << (k - 32)) : 0u;
                     if (!WT) {
                         const unsigned long long b = __ballot(p);
@@ -699,6 +749,17 @@ __global__ __launch_bounds__(kAdjRows) void adj_build_kernel(const float4 *__res
     // ... and only the words inside the row's IoU >= t window can be non-zero (the rest was
     // zero-filled by the tile skipping or is zero anyway): read just those
     int w0 = 0, w1 = W;
+    // (round 3) the block is a chain of dependent memory round trips at 2 waves per SIMD: everything that only needs the
+    // group's descriptor is requested HERE, in one go, before the first barrier -- the row's box, the frame's extrema, the
+    // row's degree -- instead of one wait after the other further down
+    float4 bx = make_float4(0.f, 0.f, 0.f, 0.f);
+    float ixmin = 0.f, iscale = 0.f, iwmax = 0.f;
+    uint32_t rz = 0u;
+    if (v < B) rz = row_z[gd.box_off + v];
+    if (tr && v < B) {
+        bx = ix.xbox[gd.box_off + v];
+        ixmin = ix.info[td.group * 4 + 0]; iscale = ix.info[td.group * 4 + 1]; iwmax = ix.info[td.group * 4 + 2];
+    }
     if (tr) {
         const float2 *rt = reach_table + reach_slot(gd, td.group);
         for (int i = tid; i < W; i += kAdjRows) srt[i] = rt[i];
@@ -710,8 +771,7 @@ __global__ __launch_bounds__(kAdjRows) void adj_build_kernel(const float4 *__res
         return !tr || c == wr || (c > wr ? srt[c].y <= srt[wr].x : srt[wr].y <= srt[c].x);
     };
     if (tr && v < B) {
-        const float4 bx = ix.xbox[gd.box_off + v];
-        const float xmin = ix.info[td.group * 4 + 0], scale = ix.info[td.group * 4 + 1], wmax = ix.info[td.group * 4 + 2];
+        const float xmin = ixmin, scale = iscale, wmax = iwmax;
         const float wrow = (bx.z - bx.x) + 1.0f;
         // (partners starting to the left are at most wrow / t wide, see xwindow; 1 - one_minus_t <= t)
         const float wleft = fminf(wmax, wrow / fmaxf(1.0f - one_minus_t, 1.0e-6f) * 1.001f);
@@ -723,9 +783,17 @@ __global__ __launch_bounds__(kAdjRows) void adj_build_kernel(const float4 *__res
         w1 = min(W, (r1 + 63) >> 6);
     }
 
+    // the first batch of the row's words is requested before the scan and the slab reservation (a global atomic): their
+    // round trips overlap; inside the loop below the NEXT batch is in flight while this one is taken apart
+    uint64_t mm[kAdjBatch];
+    auto load_batch = [&](uint64_t (&dst)[kAdjBatch], int wb) {
+#pragma unroll
+        for (int j = 0; j < kAdjBatch; ++j) dst[j] = (wb + j < w1 && live(wb + j)) ? col[(int64_t)(wb + j) * B] : 0ull;
+    };
+    if (tr && v < B) load_batch(mm, w0);
     uint32_t deg = 0, zc = 0;
     if (v < B && tr) {
-        deg = row_z[gd.box_off + v];             // regular group: the degree was accumulated by iou_bits_sym_kernel
+        deg = rz;                                // regular group: the degree was accumulated by iou_bits_sym_kernel
     } else if (v < B) {
         for (int wb = w0; wb < w1; wb += 8) {
             uint64_t mm[8];
@@ -734,7 +802,7 @@ __global__ __launch_bounds__(kAdjRows) void adj_build_kernel(const float4 *__res
 #pragma unroll
             for (int j = 0; j < 8; ++j) deg += __popcll(mm[j]);
         }
-        zc = row_z[gd.box_off + v];
+        zc = rz;
     }
     const uint32_t tot = deg + zc;
     // every list starts at an even pool offset (slabs are sums of even sizes): the walks read two
@@ -773,16 +841,16 @@ __global__ __launch_bounds__(kAdjRows) void adj_build_kernel(const float4 *__res
         uint32_t p = (uint32_t)base + lofs;
         row_meta[gd.box_off + vo] = make_uint2(p, tot);
         if (tr && wmeta) {        // regular group: the packed walk's record of this box
-            wmeta[gd.box_off + vo].box = ix.xbox[gd.box_off + v];
+            wmeta[gd.box_off + vo].box = bx;
             wmeta[gd.box_off + vo].row = make_uint4(p, tot, 0u, 0u);
         }
         uint32_t q = lofs;
         // words in batches of 8, all loads issued before the serial bit loops (inside the loop each
         // load would be waited for on its own)
+        if (!tr) load_batch(mm, w0);
         for (int wb = w0; wb < w1; wb += kAdjBatch) {
-            uint64_t mm[kAdjBatch];
-#pragma unroll
-            for (int j = 0; j < kAdjBatch; ++j) mm[j] = (wb + j < w1 && live(wb + j)) ? col[(int64_t)(wb + j) * B] : 0ull;
+            uint64_t nx[kAdjBatch];
+            load_batch(nx, wb + kAdjBatch);          // (all zero past w1)
             if (staged) {
                 // (round 3) every half word of the batch gets its place in the stage from a prefix sum of the popcounts, so the
                 // 2 * kAdjBatch extraction chains are independent of each other: at 2 waves per SIMD the kernel is bound by the
@@ -810,6 +878,8 @@ __global__ __launch_bounds__(kAdjRows) void adj_build_kernel(const float4 *__res
                     }
                 }
                 q = qs;
+#pragma unroll
+                for (int j = 0; j < kAdjBatch; ++j) mm[j] = nx[j];
                 continue;
             }
 #pragma unroll
@@ -826,6 +896,8 @@ __global__ __launch_bounds__(kAdjRows) void adj_build_kernel(const float4 *__res
                     m &= m - 1;
                 }
             }
+#pragma unroll
+            for (int j = 0; j < kAdjBatch; ++j) mm[j] = nx[j];
         }
         if (zc) {  // rare: degenerate boxes.  Recompute which partners have a zero union.
             const float4 brow = boxes[gd.box_off + v];
