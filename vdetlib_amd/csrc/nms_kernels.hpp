@@ -53,8 +53,22 @@ namespace vdet {
 struct GroupDesc {
     int32_t box_off;   // first row of this group in the flat (grouped) box array
     int32_t nbox;      // boxes in the group (<= 32767)
-    int64_t bits_off;  // u64-word offset of the group's [W][nbox] bit matrix inside the batch scratch
+    int64_t bits_off;  // u64-word offset of the group's bit matrix (bit_word) inside the batch scratch
 };
+
+// Bit-matrix layout (round 3): word c of row v lives at  ((v >> 6) * W + c) * 64 + (v & 63),  W = ceil(nbox / 64)  -- the 64
+// rows of a wave are lane-contiguous (512 B per word, as before) and the words of one 64-row group FOLLOW each other, so
+// the ~50 words K2 reads per row group are one contiguous stretch instead of 512-byte pieces 8 * nbox bytes apart.
+__device__ __host__ __forceinline__ int64_t bit_word(int nbox, int v, int c)
+{
+    const int W = (nbox + 63) >> 6;
+    return ((int64_t)(v >> 6) * W + c) * 64 + (v & 63);
+}
+__host__ __device__ __forceinline__ int64_t bit_words_of_group(int nbox)
+{
+    const int64_t W = (nbox + 63) >> 6;
+    return W * W * 64;
+}
 
 struct TileDesc {      // one 256-row tile of one group
     int32_t group;
@@ -113,7 +127,7 @@ __device__ __forceinline__ uint32_t pair_pred(float4 bi, float iarea, float4 bj,
 // ------------------------------------------------------------------------------------------------
 // K1: all-pairs predicate bits.  grid = (n_tiles, col_splits); block = 256 (one lane per row v).
 // The ROW box is the "i" box (the survivor that suppresses), the column box the "j" box:
-// bits[g.bits_off + w*nbox + v] bit k  <=>  box v (as i) suppresses box u = 64*w+k (as j), u != v,
+// bits[g.bits_off + bit_word(nbox, v, w)] bit k  <=>  box v (as i) suppresses box u = 64*w+k (as j), u != v,
 // i.e. row v is v's OUT-list -- what the greedy walk needs when v survives.
 // row_z[flat v] += number of zero-union partners of v.
 // ------------------------------------------------------------------------------------------------
@@ -179,7 +193,7 @@ __global__ __launch_bounds__(256) void iou_bits_kernel(const float4 *__restrict_
                 const uint32_t ps = pair_pred(brow, rarea, brow, rarea, t32);
                 zcnt -= ps >> 1;                                   // ... and no self zero-union
             }
-            if (v < B) bits[gd.bits_off + (int64_t)(wt + q) * B + v] = m;
+            if (v < B) bits[gd.bits_off + bit_word(B, v, wt + q)] = m;
         }
     }
     if (v < B && zcnt) {
@@ -680,12 +694,12 @@ __global__ __launch_bounds__(256) void iou_bits_sym_kernel(const float4 *__restr
         }
         unsigned long long m = (((unsigned long long)hi << 32) | lo) & colvalid;
         if (c == r) m &= ~(1ull << lane);        // no self edge
-        if (v < B) { bits[gd.bits_off + (int64_t)c * B + v] = m; dsum += (uint32_t)__popcll(m); }
+        if (v < B) { bits[gd.bits_off + bit_word(B, v, c)] = m; dsum += (uint32_t)__popcll(m); }
         if (c > r) {
             const int u = c * 64 + lane;
             if (u < B) {
                 const unsigned long long tm = (((unsigned long long)thi << 32) | tlo) & rowvalid;
-                bits[gd.bits_off + (int64_t)r * B + u] = tm;
+                bits[gd.bits_off + bit_word(B, u, r)] = tm;
                 const uint32_t cnt = (uint32_t)__popcll(tm);
                 if (cnt) atomicAdd(&row_deg[gd.box_off + u], cnt);
             }
@@ -742,7 +756,7 @@ __global__ __launch_bounds__(kAdjRows) void adj_build_kernel(const float4 *__res
     const int tid = threadIdx.x;
     const int v = td.row_tile * kRowsPerTile + (blockIdx.x & 1) * kAdjRows + tid;
     const int W = (B + 63) >> 6;
-    const uint64_t *col = bits + gd.bits_off + v;
+    const uint64_t *col = bits + gd.bits_off + bit_word(B, v, 0);      // word c of my row: col[c * 64]
     // regular groups were evaluated in x1-rank space (iou_bits_sym_kernel): translate back
     const uint16_t *tr = (group_flags && (group_flags[td.group] & kFlagRegular)) ? ix.xord + gd.box_off : nullptr;
     const int vo = (tr && v < B) ? (int)tr[v] : v;       // the box this row belongs to
@@ -788,7 +802,7 @@ __global__ __launch_bounds__(kAdjRows) void adj_build_kernel(const float4 *__res
     uint64_t mm[kAdjBatch];
     auto load_batch = [&](uint64_t (&dst)[kAdjBatch], int wb) {
 #pragma unroll
-        for (int j = 0; j < kAdjBatch; ++j) dst[j] = (wb + j < w1 && live(wb + j)) ? col[(int64_t)(wb + j) * B] : 0ull;
+        for (int j = 0; j < kAdjBatch; ++j) dst[j] = (wb + j < w1 && live(wb + j)) ? col[(wb + j) * 64] : 0ull;
     };
     if (tr && v < B) load_batch(mm, w0);
     uint32_t deg = 0, zc = 0;
@@ -798,7 +812,7 @@ __global__ __launch_bounds__(kAdjRows) void adj_build_kernel(const float4 *__res
         for (int wb = w0; wb < w1; wb += 8) {
             uint64_t mm[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) mm[j] = (wb + j < w1) ? col[(int64_t)(wb + j) * B] : 0ull;
+            for (int j = 0; j < 8; ++j) mm[j] = (wb + j < w1) ? col[(wb + j) * 64] : 0ull;
 #pragma unroll
             for (int j = 0; j < 8; ++j) deg += __popcll(mm[j]);
         }

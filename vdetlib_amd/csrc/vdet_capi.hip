@@ -269,7 +269,7 @@ int make_plan(vdet_ctx *c, NmsPlan &pl)
         pl.ntot = std::max<int64_t>(pl.ntot, (int64_t)gd.box_off + gd.nbox);
         pl.nmax = std::max(pl.nmax, gd.nbox);
         if (gd.nbox < 2) { gd.bits_off = 0; continue; }       // singletons: no graph
-        const size_t words = (size_t)((gd.nbox + 63) / 64) * gd.nbox;
+        const size_t words = (size_t)bit_words_of_group(gd.nbox);
         if (cur && cur + words > budget_words) {
             pl.batch_tiles.push_back({t0, (int)pl.tiles.size()});
             pl.batch_pairs.push_back({p0, (int)pl.pairs.size()});
