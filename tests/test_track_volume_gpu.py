@@ -342,7 +342,7 @@ def test_track_volume_random_sweep(oracle, seed):
 
 @pytest.mark.parametrize("knob", ["VDET_FORCE_GENERAL", "VDET_NO_INDEX", "VDET_NO_TRANSPOSE", "VDET_NO_LAZY",
                                   "VDET_WAVE_TRANSPOSE=0", "VDET_ATOMIC_RANK=0", "VDET_LINK_MEMO=0", "VDET_LINK_THREADS=64",
-                                  "VDET_LINK_THREADS=128", "VDET_LINK_WARM=0", "VDET_LINK_MAXB=16", "VDET_LINK_U16=0", "VDET_LINK_LPT=0", "VDET_AUX_STREAM=1", "VDET_WALK_CAREFUL=1", "VDET_WALK_PACKED=0", "VDET_WALK_PACKED=2", "VDET_SERIES_SERIAL=1", "VDET_LINK_MATERIALIZE=0", "VDET_RESCORE_ADJ=0", "VDET_TRACK_LOOP=0", "VDET_BINSORT=1"])
+                                  "VDET_LINK_THREADS=128", "VDET_LINK_WARM=0", "VDET_LINK_MAXB=16", "VDET_LINK_U16=0", "VDET_LINK_LPT=0", "VDET_GRAPH_PIPE=1", "VDET_AUX_STREAM=1", "VDET_WALK_CAREFUL=1", "VDET_WALK_PACKED=0", "VDET_WALK_PACKED=2", "VDET_SERIES_SERIAL=1", "VDET_LINK_MATERIALIZE=0", "VDET_RESCORE_ADJ=0", "VDET_TRACK_LOOP=0", "VDET_BINSORT=1"])
 def test_alternative_kernel_paths_agree(monkeypatch, knob):
     """Every A/B knob selects a different kernel path for the same result (general predicate kernel,
     no x-index, strided key reads, eager track_det_nms, ballot transposition in K1s, ballot ranks in
@@ -397,6 +397,37 @@ def test_link_compact_index_on_mixed_frames(oracle, monkeypatch, B):
         assert nt[c] == wn and np.array_equal(an[c, :wn], wa[:wn]), c
         assert np.array_equal(tr[c, :wn], wt[:wn], equal_nan=True), c
     cx.close(); cf.close()
+
+
+@pytest.mark.parametrize("irregular", [False, True, 2])
+def test_pipelined_graph_build(monkeypatch, oracle, irregular):
+    """VDET_GRAPH_PIPE=1 with a bit-matrix budget that cuts the video into many batches: K2 of batch i runs on the context's
+    second stream next to K1s of batch i+1 (two bit-matrix buffers, events both ways).  Several videos through one context;
+    survivors and tubelets identical to the single-stream build and to the oracle."""
+    import torch
+    from vdetlib_amd import ops, _lib
+    kw = dict(nms_thres=0.3, thres=0.2, max_tracks=3, link_thres=0.5)
+    plain = _lib.Context(torch.cuda.current_device())
+    monkeypatch.setenv("VDET_GRAPH_PIPE", "1")
+    monkeypatch.setenv("VDET_BITS_BUDGET_MB", "1")
+    piped = _lib.Context(torch.cuda.current_device())
+    for seed in (71, 72, 73):
+        boxes, scores = _fused_case(seed, 17, 1300, 4, irregular)
+        tb, ts = torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda()
+        res = []
+        for cx in (plain, piped):
+            try:
+                res.append(ops.nms_track_volume(tb, ts, ctx=cx, **kw))
+            except ZeroDivisionError:           # (a degenerate box met its twin: the reference raises, so do both builds)
+                res.append(None)
+        assert (res[0] is None) == (res[1] is None), seed
+        if res[0] is None:
+            continue
+        for a, b in zip(*res):
+            assert np.array_equal(a.cpu().numpy(), b.cpu().numpy(), equal_nan=True), seed
+        widx, wcnt = oracle.nms_volume(boxes, scores, 0.3)
+        assert np.array_equal(res[1][1].cpu().numpy(), wcnt) and np.array_equal(res[1][0].cpu().numpy(), widx)
+    plain.close(); piped.close()
 
 
 def test_link_memo_shares_steps_across_chains(oracle):

@@ -162,6 +162,10 @@ struct vdet_ctx {
     // second stream of the context: the memo warm-up runs on it, next to the NMS walk of the same video
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    std::vector<hipEvent_t> ev_pipe;   // graph build: K1s of batch i+1 next to K2 of batch i (two events per batch)
+    bool graph_pipe = false;      // VDET_GRAPH_PIPE=1: K2 of batch i on the second stream next to K1s of batch i+1 (two bit-matrix
+                                  // buffers).  A LATENCY option: one video at a time 13.7 -> 13.3 ms, with VDET_AUX_STREAM=1 13.0; with
+                                  // several videos in flight the step gets 0.15 ms slower (more queues taking turns), hence off
     bool use_aux = false;         // VDET_AUX_STREAM=1: warm-up next to the walk on a second stream (A-B knob; measured: no gain,
                                   // 19.2 vs 19.7 ms one video at a time, 17.9 vs 16.9 with 3 in flight -- more streams than hardware queues)
     bool link_lpt = true;         // VDET_LINK_LPT=0: the warm-up's chains in launch order instead of longest first (A-B knob)
@@ -374,7 +378,10 @@ int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32, doub
     c->nodes_valid = false;      // the adjacency lists the recorded track nodes point into are rewritten
     HIPCHK(c, c->groups.reserve(G * sizeof(GroupDesc)));
     HIPCHK(c, c->tiles.reserve(std::max<size_t>(pl.tiles.size(), 1) * sizeof(TileDesc)));
-    HIPCHK(c, c->bits.reserve(std::max<size_t>(pl.bits_words_max, 1) * 8));
+    // (two buffers when the batches are pipelined: K2 of batch i reads one while K1s of batch i+1 fills the other)
+    const bool pipe = c->graph_pipe && !c->timing && pl.batch_tiles.size() > 1;
+    const size_t bits_stride = std::max<size_t>(pl.bits_words_max, 1);
+    HIPCHK(c, c->bits.reserve(bits_stride * 8 * (pipe ? 2 : 1)));
     HIPCHK(c, c->rowz.reserve((size_t)pl.ntot * 4));
     HIPCHK(c, c->rowmeta.reserve((size_t)pl.ntot * 8));
     HIPCHK(c, c->groupz.reserve(G * 4));
@@ -443,22 +450,39 @@ int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32, doub
         } else {
             c->index_valid = false;      // gflags / the x-index describe some earlier boxes
         }
+        hipStream_t s_main = c->stream, s_k2 = c->stream;
+        if (pipe) {
+            if (!c->aux_stream) {
+                HIPCHK(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+                HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+                HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+            }
+            while (c->ev_pipe.size() < 2 * pl.batch_tiles.size()) {
+                hipEvent_t e;
+                HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                c->ev_pipe.push_back(e);
+            }
+            s_k2 = c->aux_stream;
+        }
+        int last_k2 = -1;
         for (size_t bi = 0; bi < pl.batch_tiles.size(); ++bi) {
             const auto bt = pl.batch_tiles[bi];
             const auto bp = pl.batch_pairs[bi];
             const int nt = bt.second - bt.first;
             if (nt <= 0) continue;
+            uint64_t *bits_b = c->bits.as<uint64_t>() + (pipe ? (bi & 1) * bits_stride : 0);
+            if (pipe && bi >= 2) HIPCHK(c, hipStreamWaitEvent(s_main, c->ev_pipe[2 * (bi - 2) + 1], 0));   // this buffer's K2 is done
             if (use_sym && bp.second > bp.first) {
                 StageTimer tm(c, ST_IOU_BITS);
                 if (c->wave_transpose)
                     hipLaunchKernelGGL(iou_bits_sym_kernel<true>, dim3(bp.second - bp.first), dim3(256), 0, c->stream,
                                        c->xbox.as<float4>(), c->groups.as<GroupDesc>(), c->gflags.as<uint32_t>(),
-                                       c->pairs.as<TilePair>() + bp.first, t32, one_minus_t, c->bits.as<uint64_t>(), c->rowz.as<uint32_t>(),
+                                       c->pairs.as<TilePair>() + bp.first, t32, one_minus_t, bits_b, c->rowz.as<uint32_t>(),
                                        c->reachtab.as<float2>());
                 else
                     hipLaunchKernelGGL(iou_bits_sym_kernel<false>, dim3(bp.second - bp.first), dim3(256), 0, c->stream,
                                        c->xbox.as<float4>(), c->groups.as<GroupDesc>(), c->gflags.as<uint32_t>(),
-                                       c->pairs.as<TilePair>() + bp.first, t32, one_minus_t, c->bits.as<uint64_t>(), c->rowz.as<uint32_t>(),
+                                       c->pairs.as<TilePair>() + bp.first, t32, one_minus_t, bits_b, c->rowz.as<uint32_t>(),
                                        c->reachtab.as<float2>());
             }
             // enough column splits to fill the chip when there are few row tiles
@@ -474,14 +498,18 @@ int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32, doub
                 StageTimer tm(c, ST_IOU_GEN);
                 hipLaunchKernelGGL(iou_bits_kernel, dim3(nt, splits), dim3(256), 0, c->stream, d_boxes,
                                    c->groups.as<GroupDesc>(), c->tiles.as<TileDesc>() + bt.first, t32,
-                                   c->bits.as<uint64_t>(), c->rowz.as<uint32_t>(), c->groupz.as<uint32_t>(),
+                                   bits_b, c->rowz.as<uint32_t>(), c->groupz.as<uint32_t>(),
                                    use_sym ? c->gflags.as<uint32_t>() : (const uint32_t *)nullptr);
+            }
+            if (pipe) {
+                HIPCHK(c, hipEventRecord(c->ev_pipe[2 * bi], s_main));
+                HIPCHK(c, hipStreamWaitEvent(s_k2, c->ev_pipe[2 * bi], 0));
             }
             {
                 StageTimer tm(c, ST_ADJ);
-                hipLaunchKernelGGL(adj_build_kernel, dim3(2 * nt), dim3(kAdjRows), 0, c->stream, d_boxes,
+                hipLaunchKernelGGL(adj_build_kernel, dim3(2 * nt), dim3(kAdjRows), 0, s_k2, d_boxes,
                                    c->groups.as<GroupDesc>(), c->tiles.as<TileDesc>() + bt.first,
-                                   c->bits.as<uint64_t>(), c->rowz.as<uint32_t>(), c->rowmeta.as<uint2>(),
+                                   bits_b, c->rowz.as<uint32_t>(), c->rowmeta.as<uint2>(),
                                    c->adj.as<uint16_t>(), &c->d_cnt->pool_used, pool_cap,
                                    &c->d_cnt->status, use_sym ? c->gflags.as<uint32_t>() : (const uint32_t *)nullptr,
                                    use_sym ? frame_index_of(c) : FrameIndex{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0}, one_minus_t,
@@ -489,7 +517,12 @@ int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32, doub
                                    c->wmeta_built ? c->wmeta.as<WalkMeta>() : (WalkMeta *)nullptr,
                                    use_sym ? c->reachtab.as<float2>() : (const float2 *)nullptr);
             }
+            if (pipe) {
+                HIPCHK(c, hipEventRecord(c->ev_pipe[2 * bi + 1], s_k2));
+                last_k2 = (int)bi;
+            }
         }
+        if (pipe && last_k2 >= 0) HIPCHK(c, hipStreamWaitEvent(s_main, c->ev_pipe[2 * last_k2 + 1], 0));   // (the second stream is in order)
         HIPCHK(c, hipGetLastError());
         if (async) {
             c->all_regular = false;      // not known on the host: the tracking loop asks the device (n_irregular)
@@ -861,6 +894,7 @@ int vdet_create(vdet_ctx **out, int device)
     if (const char *e = getenv("VDET_LINK_MAXB")) c->link_maxb = atoi(e) == 16 ? 16 : 8;
     if (const char *e = getenv("VDET_LINK_U16")) c->link_u16 = atoi(e) != 0;
     if (const char *e = getenv("VDET_LINK_LPT")) c->link_lpt = atoi(e) != 0;
+    if (const char *e = getenv("VDET_GRAPH_PIPE")) c->graph_pipe = atoi(e) != 0;
     if (const char *e = getenv("VDET_AUX_STREAM")) c->use_aux = atoi(e) != 0;
     if (const char *e = getenv("VDET_LINK_THREADS")) { const int v = atoi(e); if (v == 64 || v == 128 || v == 256) c->link_threads = v; }
     if (const char *e = getenv("VDET_DEBUG_SYNC")) c->debug_sync = atoi(e) != 0;
@@ -941,6 +975,7 @@ int vdet_destroy(vdet_ctx *c)
     if (c->d_cnt) (void)hipFree(c->d_cnt);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    for (hipEvent_t e : c->ev_pipe) (void)hipEventDestroy(e);
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
