@@ -48,6 +48,31 @@ def test_nms_volume_big_frames(torch_cuda, oracle):
     _check_volume(torch_cuda, oracle, boxes, scores, 0.3, cap=2048)
 
 
+@pytest.mark.parametrize("t", [0.3, 0.5])
+def test_nms_volume_integer_and_fractional_frames(torch_cuda, oracle, t):
+    """K1s takes the integer form of the predicate (x2 + 1 / y2 + 1 added once per box) on frames whose coordinates are all
+    integers in [0, 65535] and the float form elsewhere -- frame by frame in one volume: integer frames, a fractional
+    frame, coordinates of exactly 65535 and of 65536, a -0.0, exact-IoU borderlines on a coarse integer grid."""
+    rng = np.random.RandomState(88)
+    F, B, C = 8, 700, 3
+    boxes = np.zeros((F, B, 4), np.float32)
+    for f in range(F):
+        grid = [1, 4, 8, 1, 16, 1, 2, 1][f]
+        x1 = rng.randint(0, 1200 // grid, B) * grid
+        y1 = rng.randint(0, 600 // grid, B) * grid
+        w = rng.randint(1, 1 + 240 // grid, B) * grid
+        h = rng.randint(1, 1 + 240 // grid, B) * grid
+        boxes[f] = np.stack([x1, y1, x1 + w - 1, y1 + h - 1], 1)
+    boxes[3] += rng.rand(B, 4).astype(np.float32) * 0.5            # fractional frame
+    boxes[5, :40, [0, 2]] += 64000                                  # far right: still u16 ...
+    boxes[5, 0] = [65000, 10, 65535, 300]
+    boxes[6, :40, [0, 2]] += 64000
+    boxes[6, 0] = [65000, 10, 65536, 300]                           # ... one pixel more: float form
+    boxes[7, 5, 1] = np.float32(-0.0)                               # sign bit: float form
+    scores = rng.rand(F, B, C).astype(np.float32)
+    _check_volume(torch_cuda, oracle, boxes, scores, t)
+
+
 def test_nms_volume_capacity_error(torch_cuda):
     from vdetlib_amd import ops
     boxes, scores = synth.video(5, 2, 300, 2)
