@@ -660,6 +660,10 @@ def main():
             "value": boxes_per_s, "unit": "boxes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "unpinned_by_nature": "the linking RULE (the reference's trackers are external MATLAB code: the built-in f32 IoU link "
+                                  "stands in), the temporal-convolution taps (external Caffe TCN: a fixed 3-tap filter), the order of "
+                                  "equal scores inside a frame (the reference's argsort is unstable); everything else is pinned to "
+                                  "outputs of the reference (tests/golden)",
             "config": {"workload": ("configs[1]%s: 1 video/GPU, %d frames x %d boxes x %d classes; per-(frame,class) "
                                    "NMS thresh %.2f + temporal max-pool w=%d" + ("" if args.no_conv else " + 3-tap temporal convolution") + "%s%s") %
                                    ("" if args.no_link else "+[2]", F, B, C, args.thresh, args.window,
