@@ -77,6 +77,7 @@ struct TileDesc {      // one 256-row tile of one group
 
 constexpr int kRowsPerTile = 256;
 constexpr uint16_t kZTag = 0x8000;
+constexpr uint32_t kBkIdxMask = 0x3FFFu;   // index field of a bucketed list entry (bucket_kernels.hpp)
 
 // status bits latched by kernels into ctx->d_status
 constexpr int kStCap = 1;       // survivors > cap
@@ -1338,6 +1339,14 @@ struct WalkParams {
     int packed;               // regular frames take walk_list_packed (1) / walk_list_packed2 (2: sixteen candidates per pass)
     const WalkMeta *wmeta;    // per box: coordinates + list (adj_build_kernel), and the graph's threshold: the packed walk
     float t32;                // tests the members of a group against each other geometrically
+    // bucketed lists (round 4, bucket_kernels.hpp); ent == null: every list is a sorted `order` row
+    const uint32_t *ent;      // [P,B] entries {ord : 18 | 0x3FFF ^ index : 14}, bucket by bucket
+    const uint16_t *bst;      // [P,nbs] bucket starts
+    const int32_t *nsb;       // [P] < 0: this list is a sorted `order` row after all (LSD fallback)
+    int nbs;
+    const uint32_t *bk_raw;   // [P,B] what the buckets were cut from: sortable keys, or float32 scores (bk_floats)
+    int bk_floats;
+    int bk_words;             // u32 words of LDS per wave for the bucket starts
 };
 
 // LDS words through which the lanes of one wave talk to each other (the walks' dead masks): every
@@ -1476,6 +1485,87 @@ typedef volatile __attribute__((address_space(3))) lds_f4v *lds_f4_t;
 
 __device__ __forceinline__ int ring_wrap(int s) { return s >= kPackRing ? s - kPackRing : s; }
 
+// The groups of the packed walks: while the ring holds a full group of eight alive candidates (or, at the end of the list,
+// anything at all), decide the group's survivors and OR their adjacency lists into the dead mask.  qh / qn = ring head and
+// fill, nk = survivors so far (all wave-uniform).
+__device__ __forceinline__ void walk_ring_drain(const WalkParams &prm, lds_mask_t mask, lds_mask_t ring, lds_f4_t ringb, const int lane,
+                                                const float t32, const bool flush, int &qh, int &qn, int &nk,
+                                                int32_t *__restrict__ out, const int64_t cap)
+{
+    const int k = lane >> 3, sub = lane & 7;
+    while (qn >= 8 || (flush && qn > 0)) {
+        const int ng = min(8, qn);
+        const int s = ring_wrap(qh + k);
+        const bool vk = k < ng;
+        const int cm = vk ? (int)ring[8 * s] : 0;
+        // who survives: alive when the group starts, and not suppressed by an earlier surviving member (boxes from the ring)
+        const lds_f4v vi = ringb[2 * s + 1], vj = ringb[2 * ring_wrap(qh + sub) + 1];
+        const float4 bi = make_float4(vi.x, vi.y, vi.z, vi.w), bj = make_float4(vj.x, vj.y, vj.z, vj.w);
+        const bool live = vk && !((mask[cm >> 5] >> (cm & 31)) & 1u);
+        const unsigned long long lm = __ballot(live);
+        const bool hit = (pair_pred(bi, box_area(bi), bj, box_area(bj), t32) & 1u) != 0u;
+        const unsigned long long cmask = __ballot(hit && k < sub && sub < ng && live && ((lm >> (8 * sub)) & 1ull));
+        unsigned long long surv_s = lm & 0x0101010101010101ull;      // bit 8k <=> member k survives
+        if (cmask) {
+            unsigned long long sv = 0ull;
+            for (int j = 0; j < 8; ++j) {
+                const unsigned long long col = (cmask >> j) & 0x0101010101010101ull;   // bit 8i <=> i suppresses j
+                if (((lm >> (8 * j)) & 1ull) && !(col & sv)) sv |= 1ull << (8 * j);
+            }
+            surv_s = sv;
+        }
+        const bool surv = (surv_s >> (lane & 56)) & 1ull;
+        if (surv_s) {
+            const int pos = nk + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(surv_s >> 32),
+                                                               __builtin_amdgcn_mbcnt_lo((uint32_t)surv_s, 0u));
+            if (surv && sub == 0 && (int64_t)pos < cap) out[(uint32_t)pos] = cm;
+            nk += __popcll(surv_s);
+            // the survivors' lists: lane `sub` owns entries [8 sub, 8 sub + 8) and [64 + 8 sub, 64 + 8 sub + 8) -- 8 lanes
+            // read 128 contiguous, aligned bytes per load; a lane whose share lies past the list's end re-reads the
+            // list's first 16 bytes (no extra cache line, no divergent load); only entries that exist go to the LDS
+            const uint32_t off = surv ? ring[8 * s + 1] : 0u;
+            const int deg = surv ? (int)ring[8 * s + 2] : 0;
+            const AdjVec *pa = reinterpret_cast<const AdjVec *>(prm.adj + off);
+            const AdjVec a0 = pa[8 * sub < deg ? sub : 0];
+            const AdjVec a1 = pa[64 + 8 * sub < deg ? 8 + sub : 0];
+            // (a piece that starts inside the list is applied whole: K2 pads every list to a multiple of 8 entries with
+            //  copies of its last entry -- one guard per piece instead of one per entry)
+            const bool has0 = 8 * sub < deg, has1 = 64 + 8 * sub < deg;
+            if (has0) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const uint32_t d = a0.v[t];
+                    lds_or(mask, (int)((d & 0xFFFFu) >> 5), 1u << (d & 31u));
+                    lds_or(mask, (int)(d >> 21), 1u << ((d >> 16) & 31u));
+                }
+            }
+            if (__ballot(has1) != 0ull) {
+                if (has1) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const uint32_t d = a1.v[t];
+                        lds_or(mask, (int)((d & 0xFFFFu) >> 5), 1u << (d & 31u));
+                        lds_or(mask, (int)(d >> 21), 1u << ((d >> 16) & 31u));
+                    }
+                }
+                unsigned long long lg = __ballot(sub == 0 && deg > 128);
+                while (lg) {                                             // rare: long lists
+                    const int l = __ffsll((unsigned long long)lg) - 1;
+                    lg &= lg - 1;
+                    const uint32_t o = __builtin_amdgcn_readlane(off, l);
+                    const int dl = __builtin_amdgcn_readlane(deg, l);
+                    for (int e0 = 128; e0 < dl; e0 += 64) {
+                        const uint32_t e = prm.adj[o + min(e0 + lane, dl - 1)];
+                        if (e0 + lane < dl) lds_or(mask, (int)(e >> 5), 1u << (e & 31u));
+                    }
+                }
+            }
+        }
+        qh = ring_wrap(qh + ng);
+        qn -= ng;
+    }
+}
+
 __device__ __forceinline__ void walk_list_packed(const WalkParams &prm, lds_mask_t mask, const int lane, const int rb,
                                                  const uint16_t *__restrict__ order, const int ncand,
                                                  int32_t *__restrict__ out, const int64_t cap, int &nk_out)
@@ -1484,7 +1574,6 @@ __device__ __forceinline__ void walk_list_packed(const WalkParams &prm, lds_mask
     lds_f4_t ringb = (lds_f4_t)ring;                              // slot s: words 8s .. 8s+3 = meta, float4 2s+1 = box
     const WalkMeta *__restrict__ wmeta = prm.wmeta + rb;
     const float t32 = prm.t32;
-    const int k = lane >> 3, sub = lane & 7;
     int qh = 0, qn = 0, nk = 0;                                   // ring head, queued candidates, survivors (wave-uniform)
     const int last = max(ncand - 1, 0);
     int c_cur = (int)order[(uint32_t)min(lane, last)];
@@ -1515,79 +1604,132 @@ __device__ __forceinline__ void walk_list_packed(const WalkParams &prm, lds_mask
             ringb[2 * s + 1] = bv;
         }
         qn += __popcll(am);
-        const bool flush = q0 + 64 >= ncand;
-        while (qn >= 8 || (flush && qn > 0)) {
-            const int ng = min(8, qn);
-            const int s = ring_wrap(qh + k);
-            const bool vk = k < ng;
-            const int cm = vk ? (int)ring[8 * s] : 0;
-            // who survives: alive when the group starts, and not suppressed by an earlier surviving member (boxes from the ring)
-            const lds_f4v vi = ringb[2 * s + 1], vj = ringb[2 * ring_wrap(qh + sub) + 1];
-            const float4 bi = make_float4(vi.x, vi.y, vi.z, vi.w), bj = make_float4(vj.x, vj.y, vj.z, vj.w);
-            const bool live = vk && !((mask[cm >> 5] >> (cm & 31)) & 1u);
-            const unsigned long long lm = __ballot(live);
-            const bool hit = (pair_pred(bi, box_area(bi), bj, box_area(bj), t32) & 1u) != 0u;
-            const unsigned long long cmask = __ballot(hit && k < sub && sub < ng && live && ((lm >> (8 * sub)) & 1ull));
-            unsigned long long surv_s = lm & 0x0101010101010101ull;      // bit 8k <=> member k survives
-            if (cmask) {
-                unsigned long long sv = 0ull;
-                for (int j = 0; j < 8; ++j) {
-                    const unsigned long long col = (cmask >> j) & 0x0101010101010101ull;   // bit 8i <=> i suppresses j
-                    if (((lm >> (8 * j)) & 1ull) && !(col & sv)) sv |= 1ull << (8 * j);
-                }
-                surv_s = sv;
-            }
-            const bool surv = (surv_s >> (lane & 56)) & 1ull;
-            if (surv_s) {
-                const int pos = nk + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(surv_s >> 32),
-                                                                   __builtin_amdgcn_mbcnt_lo((uint32_t)surv_s, 0u));
-                if (surv && sub == 0 && (int64_t)pos < cap) out[(uint32_t)pos] = cm;
-                nk += __popcll(surv_s);
-                // the survivors' lists: lane `sub` owns entries [8 sub, 8 sub + 8) and [64 + 8 sub, 64 + 8 sub + 8) -- 8 lanes
-                // read 128 contiguous, aligned bytes per load; a lane whose share lies past the list's end re-reads the
-                // list's first 16 bytes (no extra cache line, no divergent load); only entries that exist go to the LDS
-                const uint32_t off = surv ? ring[8 * s + 1] : 0u;
-                const int deg = surv ? (int)ring[8 * s + 2] : 0;
-                const AdjVec *pa = reinterpret_cast<const AdjVec *>(prm.adj + off);
-                const AdjVec a0 = pa[8 * sub < deg ? sub : 0];
-                const AdjVec a1 = pa[64 + 8 * sub < deg ? 8 + sub : 0];
-                // (a piece that starts inside the list is applied whole: K2 pads every list to a multiple of 8 entries with
-                //  copies of its last entry -- one guard per piece instead of one per entry)
-                const bool has0 = 8 * sub < deg, has1 = 64 + 8 * sub < deg;
-                if (has0) {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const uint32_t d = a0.v[t];
-                        lds_or(mask, (int)((d & 0xFFFFu) >> 5), 1u << (d & 31u));
-                        lds_or(mask, (int)(d >> 21), 1u << ((d >> 16) & 31u));
-                    }
-                }
-                if (__ballot(has1) != 0ull) {
-                    if (has1) {
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            const uint32_t d = a1.v[t];
-                            lds_or(mask, (int)((d & 0xFFFFu) >> 5), 1u << (d & 31u));
-                            lds_or(mask, (int)(d >> 21), 1u << ((d >> 16) & 31u));
-                        }
-                    }
-                    unsigned long long lg = __ballot(sub == 0 && deg > 128);
-                    while (lg) {                                             // rare: long lists
-                        const int l = __ffsll((unsigned long long)lg) - 1;
-                        lg &= lg - 1;
-                        const uint32_t o = __builtin_amdgcn_readlane(off, l);
-                        const int dl = __builtin_amdgcn_readlane(deg, l);
-                        for (int e0 = 128; e0 < dl; e0 += 64) {
-                            const uint32_t e = prm.adj[o + min(e0 + lane, dl - 1)];
-                            if (e0 + lane < dl) lds_or(mask, (int)(e >> 5), 1u << (e & 31u));
-                        }
-                    }
-                }
-            }
-            qh = ring_wrap(qh + ng);
-            qn -= ng;
-        }
+        walk_ring_drain(prm, mask, ring, ringb, lane, t32, q0 + 64 >= ncand, qh, qn, nk, out, cap);
         c_cur = c_nxt; c_nxt = c_nn; m_cur = m_nxt; b_cur = b_nxt;
+    }
+    nk_out = nk;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The packed walk over a BUCKETED list (round 4; bucket_kernels.hpp): the list arrives cut into score-ordered buckets of
+// <= 64 entries {ord : 18 | 0x3FFF ^ index : 14} in arrival order.  One bucket per pass, one entry per lane: the lanes
+// whose box is still alive rank themselves among each other (ascending entry value = list order; a loop of lane
+// broadcasts over the alive lanes only -- ~1 400 of a list's 10 000 entries are ever ranked) and enter the ring of
+// alive candidates at head + rank instead of head + lane prefix.  Everything behind the ring is walk_list_packed's.
+// Two alive entries of a bucket with equal ord (equal keys, or two keys of a thin histogram bin that interpolate to the
+// same 1/8192 rank) are not ordered by their entry values: the pass then ranks its alive lanes by the full keys.
+// Bucket starts live in LDS (one u16 each, behind the ring), read two buckets ahead.
+// ------------------------------------------------------------------------------------------------
+typedef volatile __attribute__((address_space(3))) uint16_t *lds_u16_t;
+
+__device__ __forceinline__ void walk_list_bucketed(const WalkParams &prm, lds_mask_t mask, const int lane, const int rb,
+                                                   const uint32_t *__restrict__ ent, const uint16_t *__restrict__ bst,
+                                                   const uint32_t *__restrict__ raw, const int ncand,
+                                                   int32_t *__restrict__ out, const int64_t cap, int &nk_out)
+{
+    lds_mask_t ring = mask + prm.mask_words;
+    lds_f4_t ringb = (lds_f4_t)ring;                              // slot s: words 8s .. 8s+3 = {index, list, length, entry}, float4 2s+1 = box
+    lds_mask_t bsw = ring + 8 * kPackRing;                        // bucket starts, two per word
+    lds_u16_t bs = (lds_u16_t)bsw;
+    const WalkMeta *__restrict__ wmeta = prm.wmeta + rb;
+    const float t32 = prm.t32;
+    int qh = 0, qn = 0, nk = 0;                                   // ring head, queued candidates, survivors (wave-uniform)
+    const int nbk = (ncand + 31) >> 5;                            // buckets in use; start[nbk] == ncand
+    {
+        const uint32_t *bstw = reinterpret_cast<const uint32_t *>(bst);   // (rows are whole words: bucket_nbs)
+        const int nw = (nbk + 2) >> 1;
+        for (int i = lane; i < nw; i += 64) bsw[i] = bstw[i];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    const int last = max(ncand - 1, 0);
+    int s0 = 0;
+    int s1 = __builtin_amdgcn_readfirstlane((int)bs[min(1, nbk)]);
+    int s2 = __builtin_amdgcn_readfirstlane((int)bs[min(2, nbk)]);
+    int s3 = __builtin_amdgcn_readfirstlane((int)bs[min(3, nbk)]);
+    uint32_t e_cur = ent[(uint32_t)min(s0 + lane, last)];
+    uint32_t e_nxt = ent[(uint32_t)min(s1 + lane, last)];
+    uint2 m_cur = make_uint2(0u, 0u);
+    float4 b_cur = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane < s1) {                                              // bucket 0: everything is alive
+        const WalkMeta *wm = wmeta + (uint32_t)(kBkIdxMask ^ (e_cur & kBkIdxMask));
+        b_cur = wm->box; const uint4 rw = wm->row; m_cur = make_uint2(rw.x, rw.y);
+    }
+    for (int b = 0; b < nbk; ++b) {
+        const int n0 = s1 - s0, n1 = s2 - s1;
+        const uint32_t s4v = bs[min(b + 4, nbk)];                 // (consumed at the bottom of the pass)
+        const uint32_t e = e_cur;
+        const int c = (int)(kBkIdxMask ^ (e & kBkIdxMask));
+        const uint32_t e_nn = ent[(uint32_t)min(s2 + lane, last)];
+        const int c_nxt = (int)(kBkIdxMask ^ (e_nxt & kBkIdxMask));
+        uint2 m_nxt = make_uint2(0u, 0u);
+        float4 b_nxt = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane < n1 && !((mask[c_nxt >> 5] >> (c_nxt & 31)) & 1u)) {
+            const WalkMeta *wm = wmeta + (uint32_t)c_nxt;
+            b_nxt = wm->box; const uint4 rw = wm->row; m_nxt = make_uint2(rw.x, rw.y);
+        }
+        const bool alive = lane < n0 && !((mask[c >> 5] >> (c & 31)) & 1u);
+        const unsigned long long am = __ballot(alive);
+        const int na = __popcll(am);
+        if (na) {                                                 // (scalar branch)
+            uint32_t rank = 0u;
+            if (na > 1) {
+                unsigned long long t = am;
+                while (t) {
+                    const int l = __ffsll((unsigned long long)t) - 1;
+                    t &= t - 1;
+                    const uint32_t el = (uint32_t)__builtin_amdgcn_readlane((int)e, l);
+                    rank += el < e ? 1u : 0u;
+                }
+            }
+            const int slot0 = qh + qn;
+            if (alive) {
+                const int s = ring_wrap(slot0 + (int)rank);
+                ring[8 * s] = (uint32_t)c;
+                ring[8 * s + 1] = m_cur.x;
+                ring[8 * s + 2] = m_cur.y;
+                ring[8 * s + 3] = e;
+                lds_f4v bv; bv.x = b_cur.x; bv.y = b_cur.y; bv.z = b_cur.z; bv.w = b_cur.w;
+                ringb[2 * s + 1] = bv;
+            }
+            if (na > 1) {
+                // neighbours in rank order with equal ord?  (the wave's LDS queue is in order: the slots above are written)
+                bool tie = false;
+                if (alive && rank > 0u) {
+                    const uint32_t ep = ring[8 * ring_wrap(slot0 + (int)rank - 1) + 3];
+                    tie = ((ep ^ e) >> 14) == 0u;
+                }
+                if (__ballot(tie) != 0ull) {                      // rare: rank the alive lanes by their full keys
+                    uint32_t ikf = 0u;
+                    if (alive) {
+                        const uint32_t r = raw[(uint32_t)c];
+                        ikf = ~(prm.bk_floats ? score_key(__uint_as_float(r)) : r);
+                    }
+                    uint32_t rank2 = 0u;
+                    unsigned long long t = am;
+                    while (t) {
+                        const int l = __ffsll((unsigned long long)t) - 1;
+                        t &= t - 1;
+                        const uint32_t il = (uint32_t)__builtin_amdgcn_readlane((int)ikf, l);
+                        const int cl = __builtin_amdgcn_readlane(c, l);
+                        rank2 += (il < ikf || (il == ikf && cl > c)) ? 1u : 0u;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    if (alive) {
+                        const int s = ring_wrap(slot0 + (int)rank2);
+                        ring[8 * s] = (uint32_t)c;
+                        ring[8 * s + 1] = m_cur.x;
+                        ring[8 * s + 2] = m_cur.y;
+                        ring[8 * s + 3] = e;
+                        lds_f4v bv; bv.x = b_cur.x; bv.y = b_cur.y; bv.z = b_cur.z; bv.w = b_cur.w;
+                        ringb[2 * s + 1] = bv;
+                    }
+                }
+            }
+            qn += na;
+        }
+        walk_ring_drain(prm, mask, ring, ringb, lane, t32, b + 1 >= nbk, qh, qn, nk, out, cap);
+        e_cur = e_nxt; e_nxt = e_nn; m_cur = m_nxt; b_cur = b_nxt;
+        s0 = s1; s1 = s2; s2 = s3; s3 = __builtin_amdgcn_readfirstlane((int)s4v);
     }
     nk_out = nk;
 }
@@ -1776,7 +1918,9 @@ __global__ __launch_bounds__(256) void walk_kernel(const WalkParams prm)
     int nk = 0;
     int bad = 0;
     if (regular && prm.packed && N >= 2) {     // (singleton groups have no graph: adj_build_kernel never saw them)
-        if (prm.packed == 2) walk_list_packed2(prm, mask, lane, rb, order, ncand, out, cap, nk);
+        if (prm.ent && prm.nsb[p] >= 0)
+            walk_list_bucketed(prm, mask, lane, rb, prm.ent + pr.obase, prm.bst + (int64_t)p * prm.nbs, prm.bk_raw + pr.obase, ncand, out, cap, nk);
+        else if (prm.packed == 2) walk_list_packed2(prm, mask, lane, rb, order, ncand, out, cap, nk);
         else walk_list_packed(prm, mask, lane, rb, order, ncand, out, cap, nk);
         if (lane == 0) prm.keep_cnt[p] = nk;
         if ((int64_t)nk > cap && lane == 0) atomicOr(prm.status, kStCap);

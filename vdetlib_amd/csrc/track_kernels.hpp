@@ -48,6 +48,61 @@ __device__ __forceinline__ bool at_or_before(uint32_t k, int flat, uint32_t ka, 
 // (score desc, flat index asc) == the stable descending sort of vdet/track.py:200.
 // keys: [F*C, B] sortable keys (transpose_keys_kernel);  lists: [F*C, B] u16;  cnt: [F*C].
 // ------------------------------------------------------------------------------------------------
+// Bucketed lists (round 4, bucket_kernels.hpp): a (frame, class) list may arrive as score-ordered BUCKETS of <= 64
+// entries {ord : 18 | 0x3FFF ^ index : 14} instead of a sorted u16 row.  The tracking kernels only ever read the HEAD
+// of a list, one entry after the other, so the u16 row `lists[p]` is materialised lazily: bucket_kernel wrote its first
+// few buckets in exact order, nsb[p] = (buckets ordered so far) << 16 | (entries ordered so far), and whoever is about to
+// read position x >= that length orders the next bucket first (one thread per list -- lists are only ever touched by the
+// thread that owns their frame).  nsb[p] < 0: the row is a fully sorted list (LSD kernel).  ent == null: all rows are.
+struct BucketLists {
+    const uint32_t *ent;        // [P,B]
+    const uint16_t *bst;        // [P,nbs] bucket starts
+    int32_t *nsb;               // [P]
+    int nbs;
+};
+
+// entries of list p known to be in exact order in its u16 row (n = the list's length)
+__device__ __forceinline__ int bucket_sorted_len(const BucketLists &bl, int p, int n)
+{
+    if (!bl.ent) return n;
+    const int st = bl.nsb[p];
+    return st < 0 ? n : (st & 0xFFFF);
+}
+
+// order the next bucket of list p into its u16 row l; kk = the list's sortable keys (larger = earlier).  Returns the new
+// sorted length.  Rank by counting: the bucket's entries are two cache lines.
+__device__ __noinline__ int bucket_extend(const BucketLists &bl, int p, int B, uint16_t *l, const uint32_t *kk)
+{
+    const int k = bl.nsb[p] >> 16;
+    const uint16_t *bs = bl.bst + (int64_t)p * bl.nbs;
+    const int s = bs[k], n = (int)bs[k + 1] - s;
+    const uint32_t *e = bl.ent + (int64_t)p * B + s;
+    for (int i = 0; i < n; ++i) {
+        const uint32_t ei = e[i];
+        const int xi = (int)(kBkIdxMask ^ (ei & kBkIdxMask));
+        int rank = 0;
+        for (int j = 0; j < n; ++j) {
+            const uint32_t ej = e[j];
+            bool before = ej < ei;
+            if (((ej ^ ei) - 1u) < kBkIdxMask) {          // equal ord, another entry: the full keys decide (ties: higher index first)
+                const int xj = (int)(kBkIdxMask ^ (ej & kBkIdxMask));
+                const uint32_t ki = kk[xi], kj = kk[xj];
+                before = kj > ki || (kj == ki && xj > xi);
+            }
+            rank += before ? 1 : 0;
+        }
+        l[s + rank] = (uint16_t)xi;
+    }
+    bl.nsb[p] = ((k + 1) << 16) | (s + n);
+    return s + n;
+}
+
+// make position x of list p readable (x < n)
+__device__ __forceinline__ void bucket_need(const BucketLists &bl, int p, int B, uint16_t *l, const uint32_t *kk, int n, int &upto, int x)
+{
+    while (x >= upto && upto < n) upto = bucket_extend(bl, p, B, l, kk);
+}
+
 // Lazy lists (regular frames: finite boxes with positive areas, so no union can be zero and skipping
 // the evaluation of a pair can not hide a ZeroDivisionError).  The only thing ever read from a
 // (frame, class) list is its best live entry, at most once per track -- so track_det_nms
@@ -68,6 +123,7 @@ struct LazyLists {
     int32_t *t1;                    // [F*C] 0: no track crossed the list yet, else first track + 1
     int32_t *head, *nkp, *pos;      // [F*C]
     float t32;
+    BucketLists bk;                 // how far each u16 row is materialised (ent == null: everywhere)
 };
 
 __device__ __forceinline__ bool lazy_dead(const LazyLists &lz, int f, int e, int F, int B, int c, int max_tracks, int nt)
@@ -129,6 +185,7 @@ __device__ __forceinline__ void track_pick_body(const int c, const uint32_t *__r
         const int n = cnt[p];
         uint16_t *l = lists + (int64_t)p * B;
         const uint32_t *kk = keys + (int64_t)p * B;
+        int upto = bucket_sorted_len(lz.bk, p, n);     // l[0 .. upto) is in exact order; bucket_need extends it
         int t1 = 0;
         if (lz.group_flags && (lz.group_flags[f] & kFlagRegular)) {
             t1 = lz.t1[p];
@@ -141,13 +198,21 @@ __device__ __forceinline__ void track_pick_body(const int c, const uint32_t *__r
             // full list (or an eagerly compacted one): skip entries at/before the cursor (only the
             // previous anchor itself can be there)
             int q = 0;
-            while (q < n && at_or_before(kk[l[q]], f * B + l[q], s.last_key, s.last_flat)) ++q;
+            for (;;) {
+                if (q >= n) break;
+                bucket_need(lz.bk, p, B, l, kk, n, upto, q);
+                if (!at_or_before(kk[l[q]], f * B + l[q], s.last_key, s.last_flat)) break;
+                ++q;
+            }
             if (q >= n) continue;
             // ties inside the frame are listed by DESCENDING index; the global rule wants the lowest
             const uint32_t k0 = kk[l[q]];
             int best = l[q];
-            for (int r = q + 1; r < n && kk[l[r]] == k0; ++r)
+            for (int r = q + 1; r < n; ++r) {
+                bucket_need(lz.bk, p, B, l, kk, n, upto, r);
+                if (kk[l[r]] != k0) break;
                 if (!at_or_before(k0, f * B + l[r], s.last_key, s.last_flat)) best = l[r];
+            }
             const int flat = f * B + best;
             if (bflat < 0 || k0 > bk || (k0 == bk && flat < bflat)) { bk = k0; bflat = flat; }
             continue;
@@ -160,7 +225,10 @@ __device__ __forceinline__ void track_pick_body(const int c, const uint32_t *__r
         for (;;) {
             if (h >= np) {                      // extend the kept prefix by one entry
                 bool got = false;
-                while (ps < n && !got) got = lazy_examine(lz, l, f, B, t1b, t1area, np, ps);
+                while (ps < n && !got) {
+                    bucket_need(lz.bk, p, B, l, kk, n, upto, ps);
+                    got = lazy_examine(lz, l, f, B, t1b, t1area, np, ps);
+                }
                 if (!got) break;                // list exhausted
             }
             const int e = l[h];
@@ -176,7 +244,9 @@ __device__ __forceinline__ void track_pick_body(const int c, const uint32_t *__r
             int r = h + 1;
             for (;;) {
                 if (r >= np) {
-                    if (ps >= n || kk[l[ps]] != k0) break;
+                    if (ps >= n) break;
+                    bucket_need(lz.bk, p, B, l, kk, n, upto, ps);
+                    if (kk[l[ps]] != k0) break;
                     lazy_examine(lz, l, f, B, t1b, t1area, np, ps);
                     continue;
                 }
@@ -869,10 +939,10 @@ __global__ __launch_bounds__(1024) void warm_order_kernel(const int32_t *__restr
 // never correctness: the memo only ever holds next(f, j, dir), which no prediction can change.
 // One block per class; warm[c * m + k] = flat index or -1.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void track_warm_anchors_body(const int c, const uint32_t *__restrict__ keys, const uint16_t *__restrict__ lists,
+__device__ __forceinline__ void track_warm_anchors_body(const int c, const uint32_t *__restrict__ keys, uint16_t *lists,
                                                         const int32_t *__restrict__ cnt, int F, int B, int C,
                                                         const float *__restrict__ scores, double thres, int m,
-                                                        int32_t *__restrict__ warm)
+                                                        int32_t *__restrict__ warm, const BucketLists &bkl)
 {
     __shared__ uint32_t sk[256];
     __shared__ int sf[256];
@@ -885,6 +955,10 @@ __device__ __forceinline__ void track_warm_anchors_body(const int c, const uint3
         for (int f = tid; f < F; f += 256) {
             const int p = f * C + c;
             const int n = min(cnt[p], 2);
+            if (k == 0 && bkl.ent && n > 0) {    // bucketed list: its first two entries in exact order (normally they already are)
+                int upto = bucket_sorted_len(bkl, p, cnt[p]);
+                bucket_need(bkl, p, B, lists + (int64_t)p * B, keys + (int64_t)p * B, cnt[p], upto, n - 1);
+            }
             for (int q = 0; q < n; ++q) {
                 const int e = lists[(int64_t)p * B + q];
                 const uint32_t kk = keys[(int64_t)p * B + e];
@@ -919,12 +993,12 @@ __device__ __forceinline__ void track_warm_anchors_body(const int c, const uint3
     }
 }
 
-__global__ __launch_bounds__(256) void track_warm_anchors_kernel(const uint32_t *__restrict__ keys, const uint16_t *__restrict__ lists,
+__global__ __launch_bounds__(256) void track_warm_anchors_kernel(const uint32_t *__restrict__ keys, uint16_t *lists,
                                                                  const int32_t *__restrict__ cnt, int F, int B, int C,
                                                                  const float *__restrict__ scores, double thres, int m,
-                                                                 int32_t *__restrict__ warm)
+                                                                 int32_t *__restrict__ warm, const BucketLists bk)
 {
-    track_warm_anchors_body(blockIdx.x, keys, lists, cnt, F, B, C, scores, thres, m, warm);
+    track_warm_anchors_body(blockIdx.x, keys, lists, cnt, F, B, C, scores, thres, m, warm, bk);
 }
 
 // ------------------------------------------------------------------------------------------------

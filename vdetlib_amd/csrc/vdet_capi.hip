@@ -16,6 +16,7 @@
 #include "../../include/vdet_hip.h"
 #include "nms_kernels.hpp"
 #include "binsort_kernels.hpp"
+#include "bucket_kernels.hpp"
 #include "temporal_kernels.hpp"
 #include "tubelet_kernels.hpp"
 #include "track_kernels.hpp"
@@ -159,6 +160,14 @@ struct vdet_ctx {
     DevBuf segtab;                // batched videos: per-frame {first, one past last} frame of its video
     std::vector<int2> h_seg;
     DevBuf sortctl;               // binsort_kernel's work counter + the list of problems it handed to the LSD kernel
+    // round 4: per-(frame, class) lists cut into score-ordered buckets instead of sorted (bucket_kernels.hpp)
+    int bucket_mode = 1;          // VDET_BUCKETS=0: always the LSD sort; 1 (default): volumes of more than 1024 boxes per frame whose
+                                  // regular frames take the packed walk; 2: every volume the kernel can take (tests)
+    bool lists_bucketed = false;  // the context's lists (c->order / c->ncand) are bucketed: c->ent / c->bst / c->nsb describe them
+    bool last_sort_bucketed = false;   // the last per-(frame, class) sort went through bucket_kernel (vdet_query 10 / 11)
+    const uint32_t *bk_raw = nullptr;  // what the buckets were cut from (keys or float scores), for the consumers' tie fallback
+    int bk_floats = 0;
+    DevBuf ent, bst, nsb;
     // second stream of the context: the memo warm-up runs on it, next to the NMS walk of the same video
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -558,6 +567,8 @@ struct SortWalkArgs {
     int use_thr;
     float thr;
     int topk = 0;
+    bool want_heads = false;      // bucketed lists: also write the exact head of every list (the tracking kernels read it)
+    bool no_buckets = false;      // the caller's kernels only take sorted rows
     int32_t *keep_idx;
     int32_t *keep_cnt;
     int64_t cap;
@@ -590,6 +601,10 @@ int launch_sort_walk(vdet_ctx *c, const SortWalkArgs &a, int nmax, int64_t order
         std::vector<const void *> fns;
         for (const Variant &v : variants) { fns.push_back(v.fn[0]); fns.push_back(v.fn[1]); fns.push_back(v.fn_list[0]); fns.push_back(v.fn_list[1]); }
         fns.push_back(reinterpret_cast<const void *>(walk_kernel));
+        for (const void *fn : {reinterpret_cast<const void *>(bucket_kernel<4, false>), reinterpret_cast<const void *>(bucket_kernel<4, true>),
+                               reinterpret_cast<const void *>(bucket_kernel<10, false>), reinterpret_cast<const void *>(bucket_kernel<10, true>),
+                               reinterpret_cast<const void *>(bucket_kernel<16, false>), reinterpret_cast<const void *>(bucket_kernel<16, true>)})
+            fns.push_back(fn);
         for (const void *fn : {reinterpret_cast<const void *>(binsort_kernel<8, false>), reinterpret_cast<const void *>(binsort_kernel<8, true>),
                                reinterpret_cast<const void *>(binsort_kernel<20, false>), reinterpret_cast<const void *>(binsort_kernel<20, true>),
                                reinterpret_cast<const void *>(binsort_kernel<36, false>), reinterpret_cast<const void *>(binsort_kernel<36, true>)})
@@ -642,6 +657,7 @@ int launch_sort_walk(vdet_ctx *c, const SortWalkArgs &a, int nmax, int64_t order
     sp.lds_base_off = (int)(keysB + 2 * idxB);
     const size_t lds = keysB + 2 * idxB + (size_t)4 * (nw * 256 + 256 + 4);
     const bool big = !var || lds > c->dyn_lds_max;
+    if (!a.walk_only && !a.order_out) c->lists_bucketed = false;      // (set again below if bucket_kernel cuts the context's lists)
     if (big && a.mode != 2)
         return fail(c, VDET_EINVAL, "a frame with %d boxes needs %zu B of LDS for the in-LDS sort; the limit is %zu B "
                                     "(about 18000 boxes per frame)", nmax, lds, c->dyn_lds_max);
@@ -672,9 +688,49 @@ int launch_sort_walk(vdet_ctx *c, const SortWalkArgs &a, int nmax, int64_t order
         const int bin_cpw = nmax <= 4096 ? 8 : nmax <= 10240 ? 20 : 36;      // keys per thread, 512 threads
         const bool use_bin = c->binsort && (sp.mode == 1 || sp.mode == 3) && a.topk == 0 && !a.use_thr && !a.excl && block == 1024 &&
                              nmax <= 512 * bin_cpw && bin_lds + 4096 <= c->dyn_lds_max && sp.npass == 4;
+        // round 4: cut the lists into score-ordered buckets instead of sorting them (bucket_kernels.hpp) wherever the packed
+        // walk of regular frames will consume them; what the kernel cannot take lands on the same fail list
+        const size_t bk_lds = bucket_lds_bytes(std::max(nmax, 1));
+        const bool packed_ok = c->sym_built && !c->walk_careful && c->walk_packed == 1 && c->wmeta_built;
+        const bool use_bk = c->bucket_mode > 0 && (sp.mode == 1 || sp.mode == 3) && a.topk == 0 && !a.excl && !a.order_out && !a.no_buckets &&
+                            (block == 1024 || c->bucket_mode >= 2) && nmax >= 2 && nmax <= kBkMaxB && bk_lds <= c->dyn_lds_max &&
+                            packed_ok && sp.npass == 4 && !(a.want_heads && c->no_lazy);
         StageTimer tm(c, ST_SORTK);
-        if (a.mode != 2) c->last_sort_binned = use_bin;
-        if (use_bin) {
+        if (a.mode != 2) c->last_sort_binned = use_bin && !use_bk;
+        if (a.mode != 2) c->last_sort_bucketed = use_bk;
+        if (!a.order_out) c->lists_bucketed = use_bk;
+        if (use_bk) {
+            const int nbs = bucket_nbs(a.B);
+            HIPCHK(c, c->sortctl.reserve(sizeof(BinSortCtl) + (size_t)a.P * 4));
+            HIPCHK(c, hipMemsetAsync(c->sortctl.p, 0, sizeof(BinSortCtl), c->stream));
+            HIPCHK(c, c->ent.reserve((size_t)a.P * a.B * 4));
+            HIPCHK(c, c->bst.reserve((size_t)a.P * nbs * 2));
+            HIPCHK(c, c->nsb.reserve((size_t)a.P * 4));
+            BucketParams bp{};
+            const bool floats = sp.keys == nullptr;
+            bp.raw = floats ? reinterpret_cast<const uint32_t *>(sp.scores) : sp.keys;
+            bp.P = a.P; bp.B = a.B; bp.C = a.C;
+            bp.use_thr = floats ? sp.use_thr : 0; bp.thr = sp.thr;
+            bp.groups = sp.groups;
+            bp.group_flags = c->gflags.as<uint32_t>();
+            bp.ent = c->ent.as<uint32_t>(); bp.bst = c->bst.as<uint16_t>(); bp.nbs = nbs;
+            bp.ncand = sp.ncand; bp.nsb = c->nsb.as<int32_t>();
+            bp.order = a.want_heads ? sp.order : nullptr;
+            bp.fail_list = reinterpret_cast<int32_t *>(c->sortctl.as<char>() + sizeof(BinSortCtl));
+            bp.nfail = &c->sortctl.as<BinSortCtl>()->nfail;
+            c->bk_raw = bp.raw; c->bk_floats = floats ? 1 : 0;
+#define VDET_BKK(KP) (floats ? reinterpret_cast<const void *>(bucket_kernel<KP, true>) : reinterpret_cast<const void *>(bucket_kernel<KP, false>))
+            const void *bfn = nmax <= 4096 ? VDET_BKK(4) : nmax <= 10240 ? VDET_BKK(10) : VDET_BKK(16);
+#undef VDET_BKK
+            void *bargs[] = {&bp};
+            HIPCHK(c, hipLaunchKernel(bfn, dim3((a.P + 7) & ~7), dim3(1024), bargs, bk_lds, c->stream));
+            const int32_t *fl = bp.fail_list;
+            const int *fc = bp.nfail;
+            void *largs[] = {&sp, (void *)&fl, (void *)&fc};
+            // (the LSD kernel for the failed lists; blocks of 256 threads take nmax <= 1024)
+            StageTimer tm2(c, ST_SORTFB);
+            HIPCHK(c, hipLaunchKernel(var->fn_list[c->atomic_rank ? 1 : 0], dim3(std::min(a.P, 2 * c->n_cu)), dim3(block), largs, lds, c->stream));
+        } else if (use_bin) {
             HIPCHK(c, c->sortctl.reserve(sizeof(BinSortCtl) + (size_t)a.P * 4));
             HIPCHK(c, hipMemsetAsync(c->sortctl.p, 0, sizeof(BinSortCtl), c->stream));
             BinSortParams bp{};
@@ -722,6 +778,15 @@ int launch_sort_walk(vdet_ctx *c, const SortWalkArgs &a, int nmax, int64_t order
     wp.wave_words = wp.mask_words + (wp.packed == 2 ? 8 * kPackRing2 : wp.packed ? 8 * kPackRing : 0);   // + the ring of alive candidates
     wp.wmeta = c->wmeta.as<WalkMeta>();
     wp.t32 = c->gt32;
+    if (c->lists_bucketed && !a.order_in && wp.packed == 1) {
+        wp.ent = c->ent.as<uint32_t>(); wp.bst = c->bst.as<uint16_t>(); wp.nsb = c->nsb.as<int32_t>();
+        wp.nbs = bucket_nbs(a.B);
+        wp.bk_raw = c->bk_raw; wp.bk_floats = c->bk_floats;
+        wp.bk_words = (wp.nbs / 2 + 3) & ~3;
+        wp.wave_words += wp.bk_words;
+    } else if (c->lists_bucketed && !a.order_in) {
+        return fail(c, VDET_EHIP, "internal: bucketed lists without the packed walk");
+    }
     {
         const int nblk = (((a.P + 3) / 4) + 7) & ~7;
         StageTimer tm(c, ST_WALK);
@@ -889,6 +954,7 @@ int vdet_create(vdet_ctx **out, int device)
     if (const char *e = getenv("VDET_RESCORE_ADJ")) c->rescore_adj = atoi(e) != 0;
     if (const char *e = getenv("VDET_LINK_MEMO")) c->link_memo = atoi(e) != 0;
     if (const char *e = getenv("VDET_BINSORT")) c->binsort = atoi(e) != 0;
+    if (const char *e = getenv("VDET_BUCKETS")) c->bucket_mode = atoi(e);
     if (const char *e = getenv("VDET_TRACK_LOOP")) c->track_loop = atoi(e) != 0;
     if (const char *e = getenv("VDET_LINK_WARM")) c->link_warm = atoi(e);
     if (const char *e = getenv("VDET_LINK_MAXB")) c->link_maxb = atoi(e) == 16 ? 16 : 8;
@@ -1023,6 +1089,13 @@ int vdet_query(vdet_ctx *c, int what)
     if (what == 8) return (int)std::min<long long>(c->n_host_syncs, 0x7FFFFFFF);
     if (what == 9) {   // problems the last volume sort's counting kernel handed to the LSD kernel (-1: it did not run)
         if (!c->last_sort_binned || !c->sortctl.p) return -1;
+        BinSortCtl h{};
+        if (hipMemcpyAsync(&h, c->sortctl.p, sizeof h, hipMemcpyDeviceToHost, c->stream) != hipSuccess || host_sync(c) != hipSuccess) return VDET_EHIP;
+        return h.nfail;
+    }
+    if (what == 10) return c->last_sort_bucketed ? 1 : 0;   // the last volume sort cut its lists into buckets (bucket_kernels.hpp)
+    if (what == 11) {  // ... and handed this many lists to the LSD kernel (-1: it did not run)
+        if (!c->last_sort_bucketed || !c->sortctl.p) return -1;
         BinSortCtl h{};
         if (hipMemcpyAsync(&h, c->sortctl.p, sizeof h, hipMemcpyDeviceToHost, c->stream) != hipSuccess || host_sync(c) != hipSuccess) return VDET_EHIP;
         return h.nfail;
@@ -1423,6 +1496,7 @@ int vdet_nms_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scor
         c->no_transpose = false;
         SortWalkArgs a{};
         a.sort_only = true;
+        a.want_heads = true;
         a.mode = 0; a.P = (int)(F * C); a.B = (int)B; a.C = (int)C;
         a.scores = d_scores;
         rc = launch_sort_walk(c, a, (int)B, F * C * B);
@@ -1437,6 +1511,8 @@ int vdet_nms_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scor
     const uint32_t *w_flags = regular_ok ? c->gflags.as<uint32_t>() : nullptr;
     FrameIndex w_ix{nullptr, nullptr, nullptr, nullptr};
     if (w_flags && c->index_valid && !c->no_index) w_ix = frame_index_of(c);
+    BucketLists bkl{nullptr, nullptr, nullptr, 0};     // how far the u16 rows of bucketed lists are materialised (track_kernels.hpp)
+    if (c->lists_bucketed) bkl = BucketLists{c->ent.as<uint32_t>(), c->bst.as<uint16_t>(), c->nsb.as<int32_t>(), bucket_nbs((int)B)};
     c->nodes_valid = false;
     HIPCHK(c, c->tracknode.reserve((size_t)std::max<int64_t>(C * max_tracks * F, 1) * 4));
     HIPCHK(c, hipMemsetAsync(c->tracknode.p, 0xFF, (size_t)std::max<int64_t>(C * max_tracks * F, 1) * 4, c->stream));
@@ -1469,7 +1545,7 @@ int vdet_nms_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scor
             StageTimer tm(c, ST_TLINK);
             hipLaunchKernelGGL(track_warm_anchors_kernel, dim3((unsigned)C), dim3(256), 0, ws, c->tkeys.as<uint32_t>(),
                                c->order.as<uint16_t>(), c->ncand.as<int32_t>(), (int)F, (int)B, (int)C, d_scores, thres, wm,
-                               c->linkwarm.as<int32_t>());
+                               c->linkwarm.as<int32_t>(), bkl);
             const int32_t *w_order = nullptr;
             if (c->link_lpt) {       // longest chains first
                 HIPCHK(c, c->linkorder.reserve((size_t)C * wm * 2 * 4));
@@ -1544,6 +1620,7 @@ int vdet_nms_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scor
     lz.boxes = sp.boxes; lz.tracks = d_tracks; lz.t32 = t32;
     lz.t1 = c->heads.as<int32_t>(); lz.head = lz.t1 + F * C; lz.nkp = lz.head + F * C; lz.pos = lz.nkp + F * C;
     lz.group_flags = sp.lazy ? sp.group_flags : nullptr;
+    lz.bk = bkl;
     // the eager track_det_nms kernel is only needed for the lists the pick does not maintain; when the
     // host does not know whether every frame is regular (asynchronous build) the kernel asks the device
     const bool need_suppress = !sp.lazy || !sp.group_flags || !c->all_regular;
@@ -1654,6 +1731,7 @@ int vdet_video_batch(vdet_ctx *c, const float *d_boxes, const float *d_scores, c
         c->no_transpose = false;
         SortWalkArgs a{};
         a.sort_only = true;
+        a.no_buckets = true;         // (the batch kernels read sorted rows; small frames are not worth cutting anyway)
         a.mode = 0; a.P = (int)(F * C); a.B = (int)B; a.C = (int)C;
         a.scores = d_scores;
         rc = launch_sort_walk(c, a, (int)B, F * C * B);
