@@ -445,8 +445,26 @@ def g15_exotic(R):
     np.savez_compressed(os.path.join(HERE, 'exotic_golden.npz'), **npz)
 
 
+def g16_mat(R):
+    """utils/protocol.py:528-555 on per-frame .mat files written by synth.write_mat_case (scipy.io.savemat of seeded
+    arrays): what load_frame_to_det / load_det_info of the reference return."""
+    with tempfile.TemporaryDirectory() as d:
+        vid = synth.write_mat_case(d)
+        ftd = R['P'].load_frame_to_det(vid, d)
+        info = R['P'].load_det_info(vid, d)
+    npz = {'frames': np.asarray(sorted(ftd), dtype=np.int64), 'det_info': np.asarray(info, dtype=np.float64)}
+    for f, (b, z) in ftd.items():
+        npz['boxes_%d' % f] = np.asarray(b)
+        npz['zs_%d' % f] = np.asarray(z)
+    np.savez_compressed(os.path.join(HERE, 'mat_golden.npz'), **npz)
+    print('  mat: frames %s, det_info %s %s' % (sorted(ftd), info.shape, info.dtype))
+
+
 def main():
     R = load_reference()
+    if '--mat-only' in sys.argv:
+        g16_mat(R)
+        return
     if '--link-only' in sys.argv:
         g14_link(R)
         return
@@ -467,6 +485,7 @@ def main():
         json.dump(out, f, separators=(',', ':'), sort_keys=True)
     g14_link(R)
     g15_exotic(R)
+    g16_mat(R)
     for fn in sorted(os.listdir(HERE)):
         print('%8d  %s' % (os.path.getsize(os.path.join(HERE, fn)), fn))
 

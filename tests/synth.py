@@ -348,3 +348,32 @@ def exotic_inputs(case):
     if case.get('nan_track'):
         tr[0, 2] = np.nan
     return (tr, d)
+
+
+# ---------------------------------------------------------------------------------------------
+# per-frame .mat detection files (utils/protocol.py:528-555: load_frame_to_det / load_det_info)
+# ---------------------------------------------------------------------------------------------
+MAT_CASE = dict(seed=1601, name='synth_vid_mat', F=7, C=5)
+
+
+def write_mat_case(det_dir):
+    """Writes the case's per-frame ``.mat`` files (``boxes [B,4]``, ``zs [B,C]``, both float64 as MATLAB saves them)
+    into det_dir and returns the vid_proto.  Frame 1..F: B = 6, 0 (empty arrays), 3, -- (no file), 9, 4, 1; frame 5's
+    file is named after the full frame path (``<path>.mat``, the loaders' second guess), the others after its stem."""
+    import os
+    import scipy.io as sio
+    c = MAT_CASE
+    rng = np.random.RandomState(c['seed'])
+    vid = make_vid_proto(c['name'], c['F'])
+    counts = [6, 0, 3, None, 9, 4, 1]
+    for frame, B in zip(vid['frames'], counts):
+        if B is None:
+            continue
+        boxes = boxes_1(rng, B, frac=True).astype(np.float64).reshape(B, 4)
+        zs = rng.randn(B, c['C'])
+        stem = os.path.splitext(frame['path'])[0]
+        name = (frame['path'] if frame['frame'] == 5 else stem) + '.mat'
+        path = os.path.join(det_dir, name)
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        sio.savemat(path, {'boxes': boxes, 'zs': zs})
+    return vid
