@@ -582,6 +582,9 @@ def main():
         torch.cuda.synchronize()
         single_video_ms = (time.perf_counter() - t6) / n1 * 1e3
         ctx.sync()
+        # how the per-(frame, class) lists of that last step were built (csrc/bucket_kernels.hpp: cut into score-ordered
+        # buckets; lists the bucket kernel handed to the LSD sort: crowded buckets / irregular frames)
+        lists = {"bucketed": ctx.query(10) == 1, "lsd_fallback_lists": ctx.query(11), "lists": F * C}
         # the same, on a context created with the library's latency options (graph batches pipelined over two streams, memo
         # warm-up next to the NMS walk): slower with several videos in flight, faster alone -- not the default
         single_video_latency_ms = None
@@ -685,6 +688,7 @@ def main():
             "value_other_scores": value_other,           # the same step on the other synthetic score distribution
             "hbm_traffic_per_video": hbm_total,          # sum of the PMC table (profiles/pmc_traffic.json), all kernels of one step
             "vid_shape": vid_shape,
+            "lists": lists,
             "inputs": "HBM-resident (the PCIe-fed rate is upload_pipeline.boxes_per_s, never `value`)",
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_allcores": cpu_all, "map_parity": map_par, "pcie": pcie,
             "upload_pipeline": upload,

@@ -237,6 +237,25 @@ int vdet_nms_volume_topk(vdet_ctx *ctx, const float *d_boxes, const float *d_sco
                          int64_t cap);
 
 /*
+ * The Fast R-CNN per-class flow on the device: fast_rcnn_det_vid's per-class loop (vdet/video_det.py:89-99) followed by
+ * apply_image_nms (vdet/image_det.py:117-123 -> utils/nms.pyx:17-68) for every frame and class, where -- unlike the
+ * vdet_nms_volume family -- every class suppresses ITS OWN regressed boxes (boxes[inds, 4j:4j+4], video_det.py:92).
+ *   d_boxes  [F,B,K,4] f32 (== the reference's [B, 4K] box array per frame), 16-byte aligned
+ *   d_scores [F,B,K]   f32;  classes j < class0 are skipped (class0 = 1: the background column)
+ *   candidates of (frame, j): score > score_thresh (use_score_thresh; float32 compare); more than topk (the
+ *   reference's max_per_image, <= 128) -> the topk best, argsort(-score)[:topk] (ties at the cut: lowest indices)
+ *   d_dets    [F,K,topk,5] f32 or NULL: the rows (x1,y1,x2,y2,score) in the REFERENCE's row order -- ascending box
+ *             index, or descending score when the cut applied (video_det.py:93-97)
+ *   d_sel_idx [F,K,topk] int32 or NULL: the box index of every row;  d_det_cnt [F,K] rows per (frame, class)
+ *   d_keep    [F,K,topk] int32: the kept ROW positions in descending score order (apply_image_nms's list),
+ *   d_keep_cnt [F,K].  Entries behind the counts are left untouched.
+ * A zero-union pair that the reference would evaluate latches VDET_EDIVZERO (reported by vdet_sync).
+ */
+int vdet_det_nms_volume(vdet_ctx *ctx, const float *d_boxes, const float *d_scores, int64_t F, int64_t B, int64_t K,
+                        int class0, int use_score_thresh, float score_thresh, int topk, double nms_thresh,
+                        float *d_dets, int32_t *d_sel_idx, int32_t *d_det_cnt, int32_t *d_keep, int32_t *d_keep_cnt);
+
+/*
  * vdet_nms_volume with the CALLER's order instead of the build's: d_order [F,C,B] uint16 lists every (frame, class)
  * column's candidates in the order the greedy loop of utils/nms.pyx:26-66 is to visit them (the first d_ncand[f,c]
  * entries; the rest is ignored), e.g. vdet_argsort_volume's lists with ties rearranged the way a particular machine's

@@ -60,7 +60,7 @@ def _isolated(boxes, f, rows):
 def test_bucketed_ties_the_entry_values_do_not_decide(oracle):
     """(a) exact duplicates of a score (equal ord, the index decides), (b) ALIVE neighbours of a thin histogram bin whose
     keys differ by one ulp (equal ord, different keys: the walk ranks them by the full keys) at the low end of the lists,
-    (c) the same at the top of a list (inside the head the tracking kernels read: the list goes to the LSD kernel)."""
+    (c) the same at the top of a list, inside the head whose exact order bucket_kernel writes for the tracking kernels."""
     boxes, scores = synth.video(4301, 2, 2200, 3, kind="perm")
     rng = np.random.RandomState(5)
     # (a) duplicates, spread over the list
@@ -77,7 +77,7 @@ def test_bucketed_ties_the_entry_values_do_not_decide(oracle):
     scores[1, rows, 0] = np.array(vals, np.float32)[rng.permutation(24)]
     nfail = _check_nms(oracle, boxes, scores, _ctx(), max_fail=0)
     assert nfail == 0
-    # (c) at the top: the head's exact order cannot come from the entry values
+    # (c) at the top: the head's exact order cannot come from the entry values alone
     boxes2, scores2 = synth.video(4302, 1, 1500, 2, kind="perm")
     rows = rng.permutation(1500)[:6]
     _isolated(boxes2, 0, rows)
@@ -90,7 +90,7 @@ def test_bucketed_ties_the_entry_values_do_not_decide(oracle):
     ctx = _ctx()
     tb, ts = torch.from_numpy(boxes2).cuda(), torch.from_numpy(scores2).cuda()
     ki, kc, tr, an, nt = ops.nms_track_volume(tb, ts, cap=1500, max_tracks=3, thres=0.0, ctx=ctx)
-    assert ctx.query(10) == 1 and ctx.query(11) >= 1            # the tied head went to the LSD kernel
+    assert ctx.query(10) == 1 and ctx.query(11) == 0            # (ties are settled by the full keys, not handed to the LSD kernel)
     widx, wcnt = oracle.nms_volume(boxes2, scores2, 0.3)
     assert np.array_equal(kc.cpu().numpy(), wcnt) and np.array_equal(ki.cpu().numpy(), widx)
     for c in range(2):

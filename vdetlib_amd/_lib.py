@@ -44,6 +44,7 @@ SYMBOLS = {
     "vdet_conv1d_f32": (_ci, [_vp, _vp, _ci, _ci, _vp, _vp, _ci, _ci, _ci, _vp]),
     "vdet_nms_volume": (_ci, [_vp, _vp, _vp, _ci, _i64, _i64, _i64, _f64, _ci, _f32, _vp, _vp, _i64]),
     "vdet_nms_volume_topk": (_ci, [_vp, _vp, _vp, _ci, _i64, _i64, _i64, _f64, _ci, _f32, _ci, _vp, _vp, _i64]),
+    "vdet_det_nms_volume": (_ci, [_vp, _vp, _vp, _i64, _i64, _i64, _ci, _ci, _f32, _ci, _f64, _vp, _vp, _vp, _vp, _vp]),
     "vdet_nms_volume_ordered": (_ci, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _f64, _vp, _vp, _i64]),
     "vdet_argsort_volume": (_ci, [_vp, _vp, _ci, _i64, _i64, _i64, _ci, _f32, _vp, _vp]),
     "vdet_video_batch": (_ci, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _f64, _f64, _ci, _f64, _ci, _vp, _vp, _vp, _i64, _vp, _vp,

@@ -88,7 +88,7 @@ __device__ __forceinline__ VidView vid_view(const BatchTrack &bt, const int v)
 __global__ __launch_bounds__(256) void batch_warm_anchors_kernel(const BatchTrack bt)
 {
     const VidView w = vid_view(bt, blockIdx.y);
-    track_warm_anchors_body(blockIdx.x, w.keys, w.lists, w.cnt, w.F, bt.B, bt.C, w.scores, bt.thres, bt.wm, w.warm, BucketLists{nullptr, nullptr, nullptr, 0});
+    track_warm_anchors_body(blockIdx.x, w.keys, w.lists, w.cnt, w.F, bt.B, bt.C, w.scores, bt.thres, bt.wm, w.warm, BucketLists{nullptr, nullptr});
 }
 
 // grid (C * wm, 2, V); MODE 1: memo warm-up, MODE 2: materialise the warm chains

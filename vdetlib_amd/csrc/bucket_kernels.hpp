@@ -6,30 +6,31 @@
 // bucket only the alive members have to be ranked, and that is a handful of lanes of the walking wave
 // (walk_list_bucketed, nms_kernels.hpp).  So this kernel does ONE counting pass per list:
 //
-//   1. histogram of the inverted sortable key's top 14 bits (sign, exponent, 5 mantissa bits: 32 bins per octave,
-//      so scores that crowd one exponent still spread over dozens of LDS addresses), u16 counters packed in pairs;
+//   1. histogram of the inverted sortable key's top 13 bits (sign, exponent, 4 mantissa bits: 16 bins per octave,
+//      so scores that crowd one exponent still spread over the LDS), u16 counters packed in pairs;
 //   2. exclusive scan -> cum[d] = candidates with a smaller digit (= better score);
 //   3. every key gets a RANK ESTIMATE by linear interpolation inside its bin, in 1/8192 rank units:
-//          fine = cum[d] * 2^13 + (m * count[d] >> 5),  m = the key's low 18 bits,
-//      monotone in the key (strictly, inside bins of >= 32 keys); bucket = fine >> 18 (32 estimated ranks each, so a
-//      bucket holds ~32 keys whatever the score distribution is -- the map is exact at every bin border and linear
-//      over 1/32 octave in between), ord = fine & 0x3FFFF;
+//          fine = cum[d] * 2^13 + (m * count[d] >> 5),  m = the next 18 bits of the key,
+//      monotone in the key; bucket = fine >> 16 (8 estimated ranks each, so a bucket holds ~8 keys whatever the score
+//      distribution is -- the map is exact at every bin border and linear over 1/16 octave in between), ord = fine & 0xFFFF;
 //   4. one returning LDS atomic per key on its bucket's counter = arrival slot inside the bucket; scan of the
-//      <= 512 bucket counters; entries {ord : 18 | 0x3FFF ^ index : 14} staged in LDS, copied out coalesced.
+//      <= 2 048 bucket counters; entries {ord : 16 | first-of-bucket : 1 | 0x3FFF ^ index : 14} staged in LDS;
+//   5. a bucket that straddles a 64-entry chunk border (one per chunk) is put in exact order by one wave (rank by lane
+//      broadcasts) and all its entries are flagged, i.e. become buckets of their own: the consumer reads the list in
+//      aligned chunks of 64 and every chunk holds whole buckets only.  Coalesced copy-out.
 //
-// Entries of one bucket are in arrival order.  Ascending entry value IS the list's order (descending score, ties by
-// descending index) except between two entries of a bucket with EQUAL ord (equal keys -- then the index bits already
-// say it -- or two keys of a thin bin within 32 / count of each other): consumers detect the equal ord and let the
-// full keys decide.  ~9 LDS operations per key and 8 barriers against ~20 and 22 of the LSD sort.
+// Entries of one bucket are in arrival order.  Ascending (ord, flag-less entry) IS the list's order (descending score,
+// ties by descending index) except between two entries of a bucket with EQUAL ord and different keys (two keys of a thin
+// bin within 32 / count of each other): whoever orders entries detects equal ords and lets the full keys decide.
+// ~8 LDS operations per key and 10 barriers against ~20 and 22 of the LSD sort.
 //
-// The first kBkHead buckets are also written to `order` in exact order (one wave each, rank by lane broadcasts) for
-// the tracking kernels, which read the head of every list (track_kernels.hpp: bucket_extend orders further buckets on
-// demand, one at a time).
+// The first kBkHead buckets are also written to `order` in exact order for the tracking kernels, which read the head of
+// every list (track_kernels.hpp: bucket_extend orders further buckets on demand, one at a time).
 //
-// A list whose buckets this map cannot keep within one wave (a bucket of more than 64 keys: heavily tied / quantised
-// scores), a list of an irregular frame (the eager track_det_nms walk reads whole lists) or a tie of ord inside the
-// head goes to a fail list and is sorted by the LSD kernel afterwards (sort_list_kernel); nsb[p] says which form a
-// list has.  Correctness never depends on the map: it only decides how evenly the buckets fill.
+// A list whose buckets this map cannot keep small (a bucket of more than 32 keys: heavily tied / quantised scores) or a
+// list of an irregular frame (the eager track_det_nms walk reads whole lists) goes to a fail list and is sorted by the
+// LSD kernel afterwards (sort_list_kernel); nsb[p] says which form a list has.  Correctness never depends on the map:
+// it only decides how evenly the buckets fill.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -40,18 +41,13 @@
 namespace vdet {
 
 constexpr int kBkMaxB = 16384;            // 14 index bits per entry
-constexpr int kBkMax = 64;                // keys per bucket the walk can take (one per lane)
-constexpr int kBkHead = 8;                // leading buckets ordered exactly for the tracking kernels
-constexpr int kBkHistWords = 8192 + 4;    // 16 384 u16 counters (+ cum[16384])
-constexpr int kBkCntWords = 512 + 4;      // bucket counters / starts (+ start[512])
+constexpr int kBkMax = 32;                // keys per bucket (a bucket and its neighbours fit one wave)
+constexpr int kBkHead = 32;               // leading buckets ordered exactly for the tracking kernels (two per wave)
+constexpr int kBkDigitBits = 13;
+constexpr int kBkHistWords = (1 << kBkDigitBits) / 2 + 4;    // u16 counters (+ cum[last + 1])
+constexpr int kBkCntWords = 2048 + 8;     // bucket counters / starts (+ start[2048])
 
 inline size_t bucket_lds_bytes(int n) { return (size_t)4 * (kBkHistWords + kBkCntWords + (size_t)((n + 3) & ~3)); }
-// u16 bucket starts per list in global memory: start[0 .. nbk] with nbk = ceil(ncand / 32) <= ceil(B / 32), padded to whole words
-inline int bucket_nbs(int B) { return ((((B + 31) >> 5) + 1) + 1) & ~1; }
-
-__device__ __forceinline__ int bucket_entry_index(uint32_t e) { return (int)(kBkIdxMask ^ (e & kBkIdxMask)); }
-// two entries of one bucket whose order the entry values do not decide: equal ord, different index
-__device__ __forceinline__ bool bucket_entries_tied(uint32_t a, uint32_t b) { return ((a ^ b) - 1u) < kBkIdxMask; }
 
 struct BucketParams {
     const uint32_t *raw;           // [P, B] rows of sortable keys (0 = not a candidate), or of float32 scores (FLOATS)
@@ -61,14 +57,43 @@ struct BucketParams {
     const GroupDesc *groups;       // one group per frame
     const uint32_t *group_flags;   // kFlagRegular per frame
     uint32_t *ent;                 // [P, B] bucketed entries
-    uint16_t *bst;                 // [P, nbs] bucket starts
-    int nbs;
     int32_t *ncand;                // [P]
-    int32_t *nsb;                  // [P]  -1: sorted list in `order` (LSD kernel);  else buckets (k << 16 | sorted prefix length)
+    int32_t *nsb;                  // [P]  -1: sorted list in `order` (LSD kernel);  else entries of `order` in exact order so far
     uint16_t *order;               // [P, B] exact head of every list (tracking), or null
     int32_t *fail_list;            // [P]
     int *nfail;
 };
+
+template <bool FLOATS>
+__device__ __forceinline__ uint32_t bucket_full_ikey(const uint32_t *__restrict__ src, int idx)
+{
+    const uint32_t r = src[idx];
+    return ~(FLOATS ? score_key(__uint_as_float(r)) : r);
+}
+
+// Exact rank of lane's entry among the member lanes [ls, le) of one wave (one bucket, <= 64 entries): by flag-less entry
+// value, and -- if two members share an ord without sharing an index -- by the full keys (global loads, rare).
+template <bool FLOATS>
+__device__ __forceinline__ uint32_t bucket_rank_members(uint32_t ekey, bool member, int ls, int le, const uint32_t *__restrict__ src)
+{
+    uint32_t rank = 0;
+    bool tie = false;
+    for (int l = ls; l < le; ++l) {
+        const uint32_t el = (uint32_t)__builtin_amdgcn_readlane((int)ekey, l);
+        rank += el < ekey ? 1u : 0u;
+        tie = tie || bucket_entries_tied(el, ekey);
+    }
+    if (__ballot(tie && member) != 0ull) {          // (wave-uniform)
+        const uint32_t kf = member ? bucket_full_ikey<FLOATS>(src, bucket_entry_index(ekey)) : 0u;
+        rank = 0;
+        for (int l = ls; l < le; ++l) {
+            const uint32_t il = (uint32_t)__builtin_amdgcn_readlane((int)kf, l);
+            const uint32_t el = (uint32_t)__builtin_amdgcn_readlane((int)ekey, l);
+            rank += (il < kf || (il == kf && el < ekey)) ? 1u : 0u;      // equal keys: the higher index first (its entry is smaller)
+        }
+    }
+    return rank;
+}
 
 // KPT = keys per thread (key v = tid + k * 1024)
 template <int KPT, bool FLOATS>
@@ -80,8 +105,11 @@ __global__ __launch_bounds__(1024, KPT <= 10 ? 8 : 4) void bucket_kernel(const B
     uint32_t *bcnt = hist + kBkHistWords;
     uint32_t *stage = bcnt + kBkCntWords;
     __shared__ uint32_t swt[16];
-    __shared__ uint32_t swb[8];
+    __shared__ uint32_t swb[16];
     __shared__ int sfail;
+    constexpr int kMBits = 32 - kBkDigitBits;            // low key bits interpolated inside a bin
+    constexpr int kHistW = (1 << kBkDigitBits) / 2;      // counter words
+    static_assert(kHistW == 4 * 1024, "one uint4 of counters per thread");
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int p = xcd_problem(blockIdx.x, gridDim.x);
@@ -114,29 +142,29 @@ __global__ __launch_bounds__(1024, KPT <= 10 ? 8 : 4) void bucket_kernel(const B
         ik[k] = ~kk;
     }
     {
-        uint4 *h4 = reinterpret_cast<uint4 *>(hist);
-        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-        h4[2 * tid] = z; h4[2 * tid + 1] = z;
-        if (tid < (kBkHistWords - 8192 + kBkCntWords)) hist[8192 + tid] = 0u;          // cum[16384], bucket counters
+        reinterpret_cast<uint4 *>(hist)[tid] = make_uint4(0u, 0u, 0u, 0u);
+        reinterpret_cast<uint2 *>(bcnt)[tid] = make_uint2(0u, 0u);
+        if (tid < 4) hist[kHistW + tid] = 0u;             // cum[last + 1] ...
+        if (tid < 8) bcnt[2048 + tid] = 0u;
         if (tid == 0) sfail = 0;
     }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < KPT; ++k)
         if (ik[k] != 0xFFFFFFFFu) {
-            const uint32_t d = ik[k] >> 18;
+            const uint32_t d = ik[k] >> kMBits;
             atomicAdd(&hist[d >> 1], (d & 1u) ? 0x10000u : 1u);
         }
     __syncthreads();
-    // exclusive scan of the 16 384 counters, in place: thread t owns digits [16 t, 16 t + 16)
-    uint32_t hw[8];
+    // exclusive scan of the counters, in place: thread t owns digits [8 t, 8 t + 8)
+    uint32_t hw[4];
     {
-        const uint4 a = reinterpret_cast<const uint4 *>(hist)[2 * tid], b = reinterpret_cast<const uint4 *>(hist)[2 * tid + 1];
-        hw[0] = a.x; hw[1] = a.y; hw[2] = a.z; hw[3] = a.w; hw[4] = b.x; hw[5] = b.y; hw[6] = b.z; hw[7] = b.w;
+        const uint4 a = reinterpret_cast<const uint4 *>(hist)[tid];
+        hw[0] = a.x; hw[1] = a.y; hw[2] = a.z; hw[3] = a.w;
     }
     uint32_t tot = 0;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) tot += (hw[j] & 0xFFFFu) + (hw[j] >> 16);
+    for (int j = 0; j < 4; ++j) tot += (hw[j] & 0xFFFFu) + (hw[j] >> 16);
     const uint32_t incl = wave_incl_scan_u32(tot);
     if (lane == 63) swt[w] = incl;
     __syncthreads();
@@ -151,15 +179,13 @@ __global__ __launch_bounds__(1024, KPT <= 10 ? 8 : 4) void bucket_kernel(const B
     const int ncand = (int)ncand_u;
     {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < 4; ++j) {
             const uint32_t lo = hw[j] & 0xFFFFu, hi = hw[j] >> 16;
-            hw[j] = run | ((run + lo) << 16);              // (cum < 16 384 wherever a key can look: no carry into the next field;
-            run += lo + hi;                                //  a full list's last fields hold 16 384 = 0x4000, still 16 bits)
+            hw[j] = run | ((run + lo) << 16);              // (cum <= 16 384: 16 bits, no carry into the next field)
+            run += lo + hi;
         }
-        uint4 *h4 = reinterpret_cast<uint4 *>(hist);
-        h4[2 * tid] = make_uint4(hw[0], hw[1], hw[2], hw[3]);
-        h4[2 * tid + 1] = make_uint4(hw[4], hw[5], hw[6], hw[7]);
-        if (tid == 1023) hist[8192] = run | (run << 16);   // cum[16384] = ncand
+        reinterpret_cast<uint4 *>(hist)[tid] = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+        if (tid == 1023) hist[kHistW] = run | (run << 16);   // cum[last + 1] = ncand
     }
     __syncthreads();
     // rank estimate -> bucket, slot inside the bucket
@@ -168,43 +194,60 @@ __global__ __launch_bounds__(1024, KPT <= 10 ? 8 : 4) void bucket_kernel(const B
     for (int k = 0; k < KPT; ++k) {
         br[k] = 0xFFFFFFFFu;
         if (ik[k] != 0xFFFFFFFFu) {
-            const uint32_t d = ik[k] >> 18, m = ik[k] & 0x3FFFFu;
+            const uint32_t d = ik[k] >> kMBits, m = (ik[k] & ((1u << kMBits) - 1u)) >> (kMBits - 18);   // 18 bits of the remainder
             const uint32_t c0 = cum16[d], c1 = cum16[d + 1];
             const uint32_t fine = (c0 << 13) + (__umul24(m, c1 - c0) >> 5);      // m < 2^18, count <= 2^14: the product fits
-            const uint32_t b = fine >> 18;
+            const uint32_t b = fine >> 16;
             const uint32_t r = atomicAdd(&bcnt[b], 1u);
-            ik[k] = ((fine & 0x3FFFFu) << 14) | (kBkIdxMask ^ (uint32_t)(tid + k * 1024));   // the entry
+            ik[k] = ((fine & 0xFFFFu) << 15) | (r == 0u ? kBkFlag : 0u) | (kBkIdxMask ^ (uint32_t)(tid + k * 1024));   // the entry
             br[k] = (b << 8) | (r < 255u ? r : 255u);
         }
     }
     __syncthreads();
-    // bucket starts (<= 512 buckets: waves 0..7)
-    uint32_t bn = 0, bincl = 0;
-    if (tid < 512) {
-        bn = bcnt[tid];
-        if (bn > (uint32_t)kBkMax) sfail = 1;
-        bincl = wave_incl_scan_u32(bn);
+    // bucket starts (<= 2 048 buckets, two per thread)
+    uint32_t bn0, bn1, bincl;
+    {
+        const uint2 a = reinterpret_cast<const uint2 *>(bcnt)[tid];
+        bn0 = a.x; bn1 = a.y;
+        if (bn0 > (uint32_t)kBkMax || bn1 > (uint32_t)kBkMax) sfail = 1;
+        bincl = wave_incl_scan_u32(bn0 + bn1);
         if (lane == 63) swb[w] = bincl;
     }
     __syncthreads();
-    if (sfail) {                                          // (block-uniform) a bucket one wave cannot take: the LSD kernel sorts this list
+    if (sfail) {                                          // (block-uniform) a crowded bucket: the LSD kernel sorts this list
         if (tid == 0) { prm.nsb[p] = -1; prm.fail_list[atomicAdd(prm.nfail, 1)] = p; }
         return;
     }
-    const int nbk = (ncand + 31) >> 5;                    // buckets in use (est. rank < ncand)
-    if (tid < 512) {
-        uint32_t st = bincl - bn;
+    const int nbk = (ncand + 7) >> 3;                     // buckets in use (est. rank < ncand)
+    {
+        uint32_t st = bincl - (bn0 + bn1);
         for (int k = 0; k < w; ++k) st += swb[k];
-        bcnt[tid] = st;
-        if (tid == 511) bcnt[512] = st + bn;
-        uint16_t *bs = prm.bst + (int64_t)p * prm.nbs;
-        if (tid <= nbk) bs[tid] = (uint16_t)st;           // start[nbk] = ncand (the counters behind the last bucket are zero)
-        if (tid == 511 && nbk == 512) bs[512] = (uint16_t)(st + bn);
+        reinterpret_cast<uint2 *>(bcnt)[tid] = make_uint2(st, st + bn0);
+        if (tid == 1023) bcnt[2048] = st + bn0 + bn1;
     }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < KPT; ++k)
         if (br[k] != 0xFFFFFFFFu) stage[bcnt[br[k] >> 8] + (br[k] & 255u)] = ik[k];
+    __syncthreads();
+    // the bucket across every 64-entry chunk border: exact order, every entry a bucket of its own
+    {
+        const int nchunk = (ncand + 63) >> 6;
+        for (int j = 1 + w; j < nchunk; j += 16) {
+            const int pos0 = 64 * j - 32, q = pos0 + lane;
+            const bool valid = q < ncand;
+            const uint32_t e = valid ? stage[q] : 0xFFFFFFFFu;
+            const unsigned long long fm = __ballot(!valid || (e & kBkFlag) != 0u);     // lanes where a bucket starts
+            if ((fm >> 32) & 1ull) continue;               // a bucket starts right at the border: nothing straddles
+            const unsigned long long low = fm & 0xFFFFFFFFull, high = fm >> 33;
+            const int ls = 63 - __builtin_clzll(low);      // (buckets hold <= 32 entries: the start is within reach)
+            const int le = high ? 33 + (__ffsll((unsigned long long)high) - 1) : 64;
+            const bool member = lane >= ls && lane < le;
+            const uint32_t ekey = e & ~kBkFlag;
+            const uint32_t rank = bucket_rank_members<FLOATS>(ekey, member, ls, le, src);
+            if (member) stage[pos0 + ls + (int)rank] = ekey | kBkFlag;
+        }
+    }
     __syncthreads();
     {
         uint32_t *out = prm.ent + (int64_t)p * prm.B;
@@ -219,28 +262,17 @@ __global__ __launch_bounds__(1024, KPT <= 10 ? 8 : 4) void bucket_kernel(const B
     int nhead = 0;
     if (prm.order) {
         nhead = nbk < kBkHead ? nbk : kBkHead;
-        if (w < nhead) {                                  // one wave per head bucket: exact order by lane broadcasts
-            const int s = (int)bcnt[w], n = (int)bcnt[w + 1] - s;
-            const uint32_t e = lane < n ? stage[s + lane] : 0xFFFFFFFFu;
-            uint32_t rank = 0;
-            bool tie = false;
-            for (int l = 0; l < n; ++l) {
-                const uint32_t el = (uint32_t)__builtin_amdgcn_readlane((int)e, l);
-                rank += el < e ? 1u : 0u;
-                tie = tie || bucket_entries_tied(el, e);
-            }
-            if (lane < n) prm.order[(int64_t)p * prm.B + s + (int)rank] = (uint16_t)bucket_entry_index(e);
-            if (__ballot(tie && lane < n) != 0ull && lane == 0) sfail = 1;
-        }
-        __syncthreads();
-        if (sfail) {
-            if (tid == 0) { prm.nsb[p] = -1; prm.fail_list[atomicAdd(prm.nfail, 1)] = p; }
-            return;
+        for (int b = w; b < nhead; b += 16) {             // exact order of the head buckets, one wave each
+            const int s = (int)bcnt[b], n = (int)bcnt[b + 1] - s;
+            const bool member = lane < n;
+            const uint32_t ekey = member ? (stage[s + lane] & ~kBkFlag) : 0xFFFFFFFFu;
+            const uint32_t rank = bucket_rank_members<FLOATS>(ekey, member, 0, n, src);
+            if (member) prm.order[(int64_t)p * prm.B + s + (int)rank] = (uint16_t)bucket_entry_index(ekey);
         }
     }
     if (tid == 0) {
         prm.ncand[p] = ncand;
-        prm.nsb[p] = (nhead << 16) | (int)bcnt[nhead];
+        prm.nsb[p] = (int)bcnt[nhead];
     }
 }
 

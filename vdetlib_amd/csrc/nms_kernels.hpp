@@ -77,7 +77,12 @@ struct TileDesc {      // one 256-row tile of one group
 
 constexpr int kRowsPerTile = 256;
 constexpr uint16_t kZTag = 0x8000;
-constexpr uint32_t kBkIdxMask = 0x3FFFu;   // index field of a bucketed list entry (bucket_kernels.hpp)
+// bucketed list entries (bucket_kernels.hpp): {ord : 16 | first of its bucket : 1 | 0x3FFF ^ box index : 14}
+constexpr uint32_t kBkIdxMask = 0x3FFFu;
+constexpr uint32_t kBkFlag = 0x4000u;
+__device__ __forceinline__ int bucket_entry_index(uint32_t e) { return (int)(kBkIdxMask ^ (e & kBkIdxMask)); }
+// two flag-less entries of one bucket whose order their values do not decide: equal ord, different index
+__device__ __forceinline__ bool bucket_entries_tied(uint32_t a, uint32_t b) { return ((a ^ b) - 1u) < kBkIdxMask; }
 
 // status bits latched by kernels into ctx->d_status
 constexpr int kStCap = 1;       // survivors > cap
@@ -968,6 +973,7 @@ struct SortParams {
     int lds_idxa_off, lds_idxb_off, lds_base_off;   // dynamic-LDS carve, multiples of 16
     int npass;                // 4 (debug knob VDET_SORT_PASSES: fewer passes = timing experiments only)
     int topk;                 // > 0: only the topk best candidates stay candidates (vdet/video_det.py:93-95)
+    int32_t *nover;           // [P] or null: candidates BEFORE the topk cut (vdet/video_det.py:93 tests len(cls_scores) > max_per_image)
 };
 
 struct ProblemRef { int g, N, rb; int64_t sbase, sstride, obase; };
@@ -1230,7 +1236,10 @@ __device__ __forceinline__ void lsd_sort_problem(const SortParams &prm, const in
     } else {
         for (int v = tid; v < N; v += BLOCK) out[v] = src[v];
     }
-    if (tid == 0) prm.ncand[p] = ncand_out;
+    if (tid == 0) {
+        prm.ncand[p] = ncand_out;
+        if (prm.nover) prm.nover[p] = ncand;
+    }
 }
 
 template <int BLOCK, int CPW, bool ARANK>
@@ -1340,13 +1349,10 @@ struct WalkParams {
     const WalkMeta *wmeta;    // per box: coordinates + list (adj_build_kernel), and the graph's threshold: the packed walk
     float t32;                // tests the members of a group against each other geometrically
     // bucketed lists (round 4, bucket_kernels.hpp); ent == null: every list is a sorted `order` row
-    const uint32_t *ent;      // [P,B] entries {ord : 18 | 0x3FFF ^ index : 14}, bucket by bucket
-    const uint16_t *bst;      // [P,nbs] bucket starts
+    const uint32_t *ent;      // [P,B] entries, bucket by bucket
     const int32_t *nsb;       // [P] < 0: this list is a sorted `order` row after all (LSD fallback)
-    int nbs;
     const uint32_t *bk_raw;   // [P,B] what the buckets were cut from: sortable keys, or float32 scores (bk_floats)
     int bk_floats;
-    int bk_words;             // u32 words of LDS per wave for the bucket starts
 };
 
 // LDS words through which the lanes of one wave talk to each other (the walks' dead masks): every
@@ -1611,74 +1617,62 @@ __device__ __forceinline__ void walk_list_packed(const WalkParams &prm, lds_mask
 }
 
 // ------------------------------------------------------------------------------------------------
-// The packed walk over a BUCKETED list (round 4; bucket_kernels.hpp): the list arrives cut into score-ordered buckets of
-// <= 64 entries {ord : 18 | 0x3FFF ^ index : 14} in arrival order.  One bucket per pass, one entry per lane: the lanes
-// whose box is still alive rank themselves among each other (ascending entry value = list order; a loop of lane
-// broadcasts over the alive lanes only -- ~1 400 of a list's 10 000 entries are ever ranked) and enter the ring of
-// alive candidates at head + rank instead of head + lane prefix.  Everything behind the ring is walk_list_packed's.
+// The packed walk over a BUCKETED list (round 4; bucket_kernels.hpp): the list arrives cut into score-ordered buckets of a
+// few entries {ord : 16 | first of its bucket : 1 | 0x3FFF ^ index : 14} in arrival order, laid out so that every aligned
+// chunk of 64 entries holds whole buckets.  Same passes over the same chunks as walk_list_packed; the lanes whose box is
+// still alive rank themselves by (bucket inside the chunk, ord) -- a loop of lane broadcasts over the alive lanes only:
+// ~1 400 of a list's 10 000 entries are ever ranked -- and enter the ring of alive candidates at head + rank instead of
+// head + lane prefix.  Everything behind the ring is walk_list_packed's.
 // Two alive entries of a bucket with equal ord (equal keys, or two keys of a thin histogram bin that interpolate to the
 // same 1/8192 rank) are not ordered by their entry values: the pass then ranks its alive lanes by the full keys.
-// Bucket starts live in LDS (one u16 each, behind the ring), read two buckets ahead.
 // ------------------------------------------------------------------------------------------------
-typedef volatile __attribute__((address_space(3))) uint16_t *lds_u16_t;
-
 __device__ __forceinline__ void walk_list_bucketed(const WalkParams &prm, lds_mask_t mask, const int lane, const int rb,
-                                                   const uint32_t *__restrict__ ent, const uint16_t *__restrict__ bst,
-                                                   const uint32_t *__restrict__ raw, const int ncand,
+                                                   const uint32_t *__restrict__ ent, const uint32_t *__restrict__ raw, const int ncand,
                                                    int32_t *__restrict__ out, const int64_t cap, int &nk_out)
 {
     lds_mask_t ring = mask + prm.mask_words;
-    lds_f4_t ringb = (lds_f4_t)ring;                              // slot s: words 8s .. 8s+3 = {index, list, length, entry}, float4 2s+1 = box
-    lds_mask_t bsw = ring + 8 * kPackRing;                        // bucket starts, two per word
-    lds_u16_t bs = (lds_u16_t)bsw;
+    lds_f4_t ringb = (lds_f4_t)ring;                              // slot s: words 8s .. 8s+3 = meta, float4 2s+1 = box
     const WalkMeta *__restrict__ wmeta = prm.wmeta + rb;
     const float t32 = prm.t32;
     int qh = 0, qn = 0, nk = 0;                                   // ring head, queued candidates, survivors (wave-uniform)
-    const int nbk = (ncand + 31) >> 5;                            // buckets in use; start[nbk] == ncand
-    {
-        const uint32_t *bstw = reinterpret_cast<const uint32_t *>(bst);   // (rows are whole words: bucket_nbs)
-        const int nw = (nbk + 2) >> 1;
-        for (int i = lane; i < nw; i += 64) bsw[i] = bstw[i];
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    }
     const int last = max(ncand - 1, 0);
-    int s0 = 0;
-    int s1 = __builtin_amdgcn_readfirstlane((int)bs[min(1, nbk)]);
-    int s2 = __builtin_amdgcn_readfirstlane((int)bs[min(2, nbk)]);
-    int s3 = __builtin_amdgcn_readfirstlane((int)bs[min(3, nbk)]);
-    uint32_t e_cur = ent[(uint32_t)min(s0 + lane, last)];
-    uint32_t e_nxt = ent[(uint32_t)min(s1 + lane, last)];
+    uint32_t e_cur = ent[(uint32_t)min(lane, last)];
+    uint32_t e_nxt = ent[(uint32_t)min(64 + lane, last)];
     uint2 m_cur = make_uint2(0u, 0u);
     float4 b_cur = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (lane < s1) {                                              // bucket 0: everything is alive
-        const WalkMeta *wm = wmeta + (uint32_t)(kBkIdxMask ^ (e_cur & kBkIdxMask));
+    if (lane < ncand) {                                           // chunk 0: everything is alive
+        const WalkMeta *wm = wmeta + (uint32_t)bucket_entry_index(e_cur);
         b_cur = wm->box; const uint4 rw = wm->row; m_cur = make_uint2(rw.x, rw.y);
     }
-    for (int b = 0; b < nbk; ++b) {
-        const int n0 = s1 - s0, n1 = s2 - s1;
-        const uint32_t s4v = bs[min(b + 4, nbk)];                 // (consumed at the bottom of the pass)
+    for (int q0 = 0; q0 < ncand; q0 += 64) {
         const uint32_t e = e_cur;
-        const int c = (int)(kBkIdxMask ^ (e & kBkIdxMask));
-        const uint32_t e_nn = ent[(uint32_t)min(s2 + lane, last)];
-        const int c_nxt = (int)(kBkIdxMask ^ (e_nxt & kBkIdxMask));
+        const int c = bucket_entry_index(e);
+        const uint32_t e_nn = ent[(uint32_t)min(q0 + 128 + lane, last)];
+        const int c_nxt = bucket_entry_index(e_nxt);
         uint2 m_nxt = make_uint2(0u, 0u);
         float4 b_nxt = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (lane < n1 && !((mask[c_nxt >> 5] >> (c_nxt & 31)) & 1u)) {
+        if ((q0 + 64 + lane) < ncand && !((mask[c_nxt >> 5] >> (c_nxt & 31)) & 1u)) {
             const WalkMeta *wm = wmeta + (uint32_t)c_nxt;
             b_nxt = wm->box; const uint4 rw = wm->row; m_nxt = make_uint2(rw.x, rw.y);
         }
-        const bool alive = lane < n0 && !((mask[c >> 5] >> (c & 31)) & 1u);
+        const bool valid = (q0 + lane) < ncand;
+        const bool alive = valid && !((mask[c >> 5] >> (c & 31)) & 1u);
         const unsigned long long am = __ballot(alive);
         const int na = __popcll(am);
         if (na) {                                                 // (scalar branch)
-            uint32_t rank = 0u;
+            uint32_t rank = 0u, key = 0u;
             if (na > 1) {
+                // rank key: buckets of a chunk in lane order, entries of a bucket by ord
+                const unsigned long long fm = __ballot(valid && (e & kBkFlag) != 0u);
+                const uint32_t bid = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u)) +
+                                     ((e & kBkFlag) ? 1u : 0u);
+                key = (bid << 16) | (e >> 15);
                 unsigned long long t = am;
                 while (t) {
                     const int l = __ffsll((unsigned long long)t) - 1;
                     t &= t - 1;
-                    const uint32_t el = (uint32_t)__builtin_amdgcn_readlane((int)e, l);
-                    rank += el < e ? 1u : 0u;
+                    const uint32_t kl = (uint32_t)__builtin_amdgcn_readlane((int)key, l);
+                    rank += kl < key ? 1u : 0u;
                 }
             }
             const int slot0 = qh + qn;
@@ -1687,18 +1681,14 @@ __device__ __forceinline__ void walk_list_bucketed(const WalkParams &prm, lds_ma
                 ring[8 * s] = (uint32_t)c;
                 ring[8 * s + 1] = m_cur.x;
                 ring[8 * s + 2] = m_cur.y;
-                ring[8 * s + 3] = e;
                 lds_f4v bv; bv.x = b_cur.x; bv.y = b_cur.y; bv.z = b_cur.z; bv.w = b_cur.w;
                 ringb[2 * s + 1] = bv;
             }
             if (na > 1) {
-                // neighbours in rank order with equal ord?  (the wave's LDS queue is in order: the slots above are written)
-                bool tie = false;
-                if (alive && rank > 0u) {
-                    const uint32_t ep = ring[8 * ring_wrap(slot0 + (int)rank - 1) + 3];
-                    tie = ((ep ^ e) >> 14) == 0u;
-                }
-                if (__ballot(tie) != 0ull) {                      // rare: rank the alive lanes by their full keys
+                // equal keys share a slot: does the slot hold what this lane wrote?  (the wave's LDS queue is in order)
+                const bool clash = alive && ring[8 * ring_wrap(slot0 + (int)rank)] != (uint32_t)c;
+                const unsigned long long cm = __ballot(clash);
+                if (cm != 0ull) {                                 // rare: rank the alive lanes by their full keys
                     uint32_t ikf = 0u;
                     if (alive) {
                         const uint32_t r = raw[(uint32_t)c];
@@ -1709,9 +1699,10 @@ __device__ __forceinline__ void walk_list_bucketed(const WalkParams &prm, lds_ma
                     while (t) {
                         const int l = __ffsll((unsigned long long)t) - 1;
                         t &= t - 1;
+                        const uint32_t kl = (uint32_t)__builtin_amdgcn_readlane((int)key, l);
                         const uint32_t il = (uint32_t)__builtin_amdgcn_readlane((int)ikf, l);
                         const int cl = __builtin_amdgcn_readlane(c, l);
-                        rank2 += (il < ikf || (il == ikf && cl > c)) ? 1u : 0u;
+                        rank2 += (kl < key || (kl == key && (il < ikf || (il == ikf && cl > c)))) ? 1u : 0u;
                     }
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     if (alive) {
@@ -1719,7 +1710,6 @@ __device__ __forceinline__ void walk_list_bucketed(const WalkParams &prm, lds_ma
                         ring[8 * s] = (uint32_t)c;
                         ring[8 * s + 1] = m_cur.x;
                         ring[8 * s + 2] = m_cur.y;
-                        ring[8 * s + 3] = e;
                         lds_f4v bv; bv.x = b_cur.x; bv.y = b_cur.y; bv.z = b_cur.z; bv.w = b_cur.w;
                         ringb[2 * s + 1] = bv;
                     }
@@ -1727,9 +1717,8 @@ __device__ __forceinline__ void walk_list_bucketed(const WalkParams &prm, lds_ma
             }
             qn += na;
         }
-        walk_ring_drain(prm, mask, ring, ringb, lane, t32, b + 1 >= nbk, qh, qn, nk, out, cap);
+        walk_ring_drain(prm, mask, ring, ringb, lane, t32, q0 + 64 >= ncand, qh, qn, nk, out, cap);
         e_cur = e_nxt; e_nxt = e_nn; m_cur = m_nxt; b_cur = b_nxt;
-        s0 = s1; s1 = s2; s2 = s3; s3 = __builtin_amdgcn_readfirstlane((int)s4v);
     }
     nk_out = nk;
 }
@@ -1919,7 +1908,7 @@ __global__ __launch_bounds__(256) void walk_kernel(const WalkParams prm)
     int bad = 0;
     if (regular && prm.packed && N >= 2) {     // (singleton groups have no graph: adj_build_kernel never saw them)
         if (prm.ent && prm.nsb[p] >= 0)
-            walk_list_bucketed(prm, mask, lane, rb, prm.ent + pr.obase, prm.bst + (int64_t)p * prm.nbs, prm.bk_raw + pr.obase, ncand, out, cap, nk);
+            walk_list_bucketed(prm, mask, lane, rb, prm.ent + pr.obase, prm.bk_raw + pr.obase, ncand, out, cap, nk);
         else if (prm.packed == 2) walk_list_packed2(prm, mask, lane, rb, order, ncand, out, cap, nk);
         else walk_list_packed(prm, mask, lane, rb, order, ncand, out, cap, nk);
         if (lane == 0) prm.keep_cnt[p] = nk;

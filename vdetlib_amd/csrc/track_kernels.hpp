@@ -48,17 +48,15 @@ __device__ __forceinline__ bool at_or_before(uint32_t k, int flat, uint32_t ka, 
 // (score desc, flat index asc) == the stable descending sort of vdet/track.py:200.
 // keys: [F*C, B] sortable keys (transpose_keys_kernel);  lists: [F*C, B] u16;  cnt: [F*C].
 // ------------------------------------------------------------------------------------------------
-// Bucketed lists (round 4, bucket_kernels.hpp): a (frame, class) list may arrive as score-ordered BUCKETS of <= 64
-// entries {ord : 18 | 0x3FFF ^ index : 14} instead of a sorted u16 row.  The tracking kernels only ever read the HEAD
-// of a list, one entry after the other, so the u16 row `lists[p]` is materialised lazily: bucket_kernel wrote its first
-// few buckets in exact order, nsb[p] = (buckets ordered so far) << 16 | (entries ordered so far), and whoever is about to
-// read position x >= that length orders the next bucket first (one thread per list -- lists are only ever touched by the
+// Bucketed lists (round 4, bucket_kernels.hpp): a (frame, class) list may arrive as score-ordered BUCKETS of a few
+// entries {ord : 16 | first of its bucket : 1 | 0x3FFF ^ index : 14} instead of a sorted u16 row.  The tracking kernels
+// only ever read the HEAD of a list, one entry after the other, so the u16 row `lists[p]` is materialised lazily:
+// bucket_kernel wrote its first buckets in exact order, nsb[p] = entries in exact order so far, and whoever is about to
+// read a position behind that orders the next bucket first (one thread per list -- lists are only ever touched by the
 // thread that owns their frame).  nsb[p] < 0: the row is a fully sorted list (LSD kernel).  ent == null: all rows are.
 struct BucketLists {
     const uint32_t *ent;        // [P,B]
-    const uint16_t *bst;        // [P,nbs] bucket starts
     int32_t *nsb;               // [P]
-    int nbs;
 };
 
 // entries of list p known to be in exact order in its u16 row (n = the list's length)
@@ -66,26 +64,26 @@ __device__ __forceinline__ int bucket_sorted_len(const BucketLists &bl, int p, i
 {
     if (!bl.ent) return n;
     const int st = bl.nsb[p];
-    return st < 0 ? n : (st & 0xFFFF);
+    return st < 0 ? n : st;
 }
 
-// order the next bucket of list p into its u16 row l; kk = the list's sortable keys (larger = earlier).  Returns the new
-// sorted length.  Rank by counting: the bucket's entries are two cache lines.
-__device__ __noinline__ int bucket_extend(const BucketLists &bl, int p, int B, uint16_t *l, const uint32_t *kk)
+// order the next bucket of list p (n entries) into its u16 row l; kk = the list's sortable keys (larger = earlier).
+// Returns the new sorted length.  Rank by counting: a bucket is at most 32 entries, one cache line.
+__device__ __noinline__ int bucket_extend(const BucketLists &bl, int p, int B, uint16_t *l, const uint32_t *kk, int n)
 {
-    const int k = bl.nsb[p] >> 16;
-    const uint16_t *bs = bl.bst + (int64_t)p * bl.nbs;
-    const int s = bs[k], n = (int)bs[k + 1] - s;
-    const uint32_t *e = bl.ent + (int64_t)p * B + s;
-    for (int i = 0; i < n; ++i) {
-        const uint32_t ei = e[i];
-        const int xi = (int)(kBkIdxMask ^ (ei & kBkIdxMask));
+    const int s = bl.nsb[p];
+    const uint32_t *e = bl.ent + (int64_t)p * B;
+    int t = s + 1;
+    while (t < n && !(e[t] & kBkFlag)) ++t;              // the bucket is [s, t)
+    for (int i = s; i < t; ++i) {
+        const uint32_t ei = e[i] & ~kBkFlag;
+        const int xi = bucket_entry_index(ei);
         int rank = 0;
-        for (int j = 0; j < n; ++j) {
-            const uint32_t ej = e[j];
+        for (int j = s; j < t; ++j) {
+            const uint32_t ej = e[j] & ~kBkFlag;
             bool before = ej < ei;
-            if (((ej ^ ei) - 1u) < kBkIdxMask) {          // equal ord, another entry: the full keys decide (ties: higher index first)
-                const int xj = (int)(kBkIdxMask ^ (ej & kBkIdxMask));
+            if (bucket_entries_tied(ej, ei)) {            // equal ord, another entry: the full keys decide (ties: higher index first)
+                const int xj = bucket_entry_index(ej);
                 const uint32_t ki = kk[xi], kj = kk[xj];
                 before = kj > ki || (kj == ki && xj > xi);
             }
@@ -93,14 +91,14 @@ __device__ __noinline__ int bucket_extend(const BucketLists &bl, int p, int B, u
         }
         l[s + rank] = (uint16_t)xi;
     }
-    bl.nsb[p] = ((k + 1) << 16) | (s + n);
-    return s + n;
+    bl.nsb[p] = t;
+    return t;
 }
 
 // make position x of list p readable (x < n)
 __device__ __forceinline__ void bucket_need(const BucketLists &bl, int p, int B, uint16_t *l, const uint32_t *kk, int n, int &upto, int x)
 {
-    while (x >= upto && upto < n) upto = bucket_extend(bl, p, B, l, kk);
+    while (x >= upto && upto < n) upto = bucket_extend(bl, p, B, l, kk, n);
 }
 
 // Lazy lists (regular frames: finite boxes with positive areas, so no union can be zero and skipping

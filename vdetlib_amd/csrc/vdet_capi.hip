@@ -17,6 +17,7 @@
 #include "nms_kernels.hpp"
 #include "binsort_kernels.hpp"
 #include "bucket_kernels.hpp"
+#include "detnms_kernels.hpp"
 #include "temporal_kernels.hpp"
 #include "tubelet_kernels.hpp"
 #include "track_kernels.hpp"
@@ -167,7 +168,8 @@ struct vdet_ctx {
     bool last_sort_bucketed = false;   // the last per-(frame, class) sort went through bucket_kernel (vdet_query 10 / 11)
     const uint32_t *bk_raw = nullptr;  // what the buckets were cut from (keys or float scores), for the consumers' tie fallback
     int bk_floats = 0;
-    DevBuf ent, bst, nsb;
+    DevBuf ent, nsb;
+    DevBuf nover;                 // vdet_det_nms_volume: candidates per list before the topk cut
     // second stream of the context: the memo warm-up runs on it, next to the NMS walk of the same video
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -567,6 +569,7 @@ struct SortWalkArgs {
     int use_thr;
     float thr;
     int topk = 0;
+    int32_t *nover_out = nullptr; // candidates of every list before the topk cut
     bool want_heads = false;      // bucketed lists: also write the exact head of every list (the tracking kernels read it)
     bool no_buckets = false;      // the caller's kernels only take sorted rows
     int32_t *keep_idx;
@@ -649,6 +652,7 @@ int launch_sort_walk(vdet_ctx *c, const SortWalkArgs &a, int nmax, int64_t order
     sp.ncand = a.order_out ? a.ncand_out : c->ncand.as<int32_t>();
     sp.npass = 4;
     sp.topk = a.topk;
+    sp.nover = a.nover_out;
     if (const char *e = getenv("VDET_SORT_PASSES")) sp.npass = atoi(e);
     const size_t keysB = r16((size_t)2 * std::max(nmax, 1));     // 16 key bits at a time (see sort_kernel)
     const size_t idxB = r16((size_t)2 * std::max(nmax, 1));
@@ -700,11 +704,9 @@ int launch_sort_walk(vdet_ctx *c, const SortWalkArgs &a, int nmax, int64_t order
         if (a.mode != 2) c->last_sort_bucketed = use_bk;
         if (!a.order_out) c->lists_bucketed = use_bk;
         if (use_bk) {
-            const int nbs = bucket_nbs(a.B);
             HIPCHK(c, c->sortctl.reserve(sizeof(BinSortCtl) + (size_t)a.P * 4));
             HIPCHK(c, hipMemsetAsync(c->sortctl.p, 0, sizeof(BinSortCtl), c->stream));
             HIPCHK(c, c->ent.reserve((size_t)a.P * a.B * 4));
-            HIPCHK(c, c->bst.reserve((size_t)a.P * nbs * 2));
             HIPCHK(c, c->nsb.reserve((size_t)a.P * 4));
             BucketParams bp{};
             const bool floats = sp.keys == nullptr;
@@ -713,7 +715,7 @@ int launch_sort_walk(vdet_ctx *c, const SortWalkArgs &a, int nmax, int64_t order
             bp.use_thr = floats ? sp.use_thr : 0; bp.thr = sp.thr;
             bp.groups = sp.groups;
             bp.group_flags = c->gflags.as<uint32_t>();
-            bp.ent = c->ent.as<uint32_t>(); bp.bst = c->bst.as<uint16_t>(); bp.nbs = nbs;
+            bp.ent = c->ent.as<uint32_t>();
             bp.ncand = sp.ncand; bp.nsb = c->nsb.as<int32_t>();
             bp.order = a.want_heads ? sp.order : nullptr;
             bp.fail_list = reinterpret_cast<int32_t *>(c->sortctl.as<char>() + sizeof(BinSortCtl));
@@ -779,11 +781,8 @@ int launch_sort_walk(vdet_ctx *c, const SortWalkArgs &a, int nmax, int64_t order
     wp.wmeta = c->wmeta.as<WalkMeta>();
     wp.t32 = c->gt32;
     if (c->lists_bucketed && !a.order_in && wp.packed == 1) {
-        wp.ent = c->ent.as<uint32_t>(); wp.bst = c->bst.as<uint16_t>(); wp.nsb = c->nsb.as<int32_t>();
-        wp.nbs = bucket_nbs(a.B);
+        wp.ent = c->ent.as<uint32_t>(); wp.nsb = c->nsb.as<int32_t>();
         wp.bk_raw = c->bk_raw; wp.bk_floats = c->bk_floats;
-        wp.bk_words = (wp.nbs / 2 + 3) & ~3;
-        wp.wave_words += wp.bk_words;
     } else if (c->lists_bucketed && !a.order_in) {
         return fail(c, VDET_EHIP, "internal: bucketed lists without the packed walk");
     }
@@ -1385,6 +1384,65 @@ int vdet_nms_volume_topk(vdet_ctx *c, const float *d_boxes, const float *d_score
 }
 
 // ---------------------------------------------------------------------------------------------
+// The Fast R-CNN per-class flow (vdet/video_det.py:89-99 + vdet/image_det.py:117-123): every class suppresses its OWN
+// regressed boxes.  Selection (score > thresh, best topk) = the LSD sort's threshold + top-k on the [F,B,K] score
+// volume; then one wave per (frame, class) on its <= 128 selected boxes (detnms_kernels.hpp).
+int vdet_det_nms_volume(vdet_ctx *c, const float *d_boxes, const float *d_scores, int64_t F, int64_t B, int64_t K, int class0,
+                        int use_score_thresh, float score_thresh, int topk, double nms_thresh, float *d_dets, int32_t *d_sel_idx,
+                        int32_t *d_det_cnt, int32_t *d_keep, int32_t *d_keep_cnt)
+{
+    if (!c) return VDET_EINVAL;
+    if (F < 0 || B < 0 || K < 0 || class0 < 0) return fail(c, VDET_EINVAL, "bad shape");
+    if (topk < 1 || topk > kDetMax) return fail(c, VDET_EINVAL, "topk = %d; the per-class NMS takes 1..%d boxes per (frame, class)", topk, kDetMax);
+    if (F == 0 || K == 0) return VDET_OK;
+    if (!d_det_cnt || !d_keep || !d_keep_cnt) return fail(c, VDET_EINVAL, "null output");
+    if (B > 32767) return fail(c, VDET_EINVAL, "B = %lld boxes per frame; the limit is 32767", (long long)B);
+    if (F * K > 0x7FFFFFF0ll || F * B > 0x7FFFFFF0ll) return fail(c, VDET_EINVAL, "volume too large");
+    HIPCHK(c, hipSetDevice(c->device));
+    timing_reset(c);
+    if (B == 0) {
+        HIPCHK(c, hipMemsetAsync(d_det_cnt, 0, (size_t)(F * K) * 4, c->stream));
+        HIPCHK(c, hipMemsetAsync(d_keep_cnt, 0, (size_t)(F * K) * 4, c->stream));
+        return VDET_OK;
+    }
+    if (!d_boxes || !d_scores) return fail(c, VDET_EINVAL, "null buffer");
+    if (((uintptr_t)d_boxes & 15) != 0) return fail(c, VDET_EINVAL, "d_boxes must be 16-byte aligned");
+    // only the group table (one group of B boxes per frame) is needed: no suppression graph is shared between classes here
+    NmsPlan &pl = volume_plan(c, F, B);
+    c->host_groups = &pl.groups;
+    HIPCHK(c, c->groups.reserve((size_t)F * sizeof(GroupDesc)));
+    if (!c->vplan_valid)
+        HIPCHK(c, hipMemcpyAsync(c->groups.p, pl.groups.data(), (size_t)F * sizeof(GroupDesc), hipMemcpyHostToDevice, c->stream));
+    c->lists_valid = false;          // (the context's lists become the selections)
+    HIPCHK(c, c->nover.reserve((size_t)(F * K) * 4));
+    SortWalkArgs a{};
+    a.sort_only = true;
+    a.no_buckets = true;             // the selection wants the k best in exact order
+    a.mode = 0; a.P = (int)(F * K); a.B = (int)B; a.C = (int)K;
+    a.scores = d_scores;
+    a.use_thr = use_score_thresh ? 1 : 0; a.thr = score_thresh; a.topk = topk;
+    a.nover_out = c->nover.as<int32_t>();
+    const bool saved = c->no_transpose;
+    c->no_transpose = false;
+    const int rc = launch_sort_walk(c, a, (int)B, F * K * B);
+    c->no_transpose = saved;
+    if (rc) return rc;
+    DetNmsParams dp{};
+    dp.boxes = reinterpret_cast<const float4 *>(d_boxes); dp.scores = d_scores;
+    dp.F = (int)F; dp.B = (int)B; dp.K = (int)K; dp.class0 = class0;
+    dp.order = c->order.as<uint16_t>(); dp.ncand = c->ncand.as<int32_t>(); dp.nover = c->nover.as<int32_t>();
+    dp.topk = topk; dp.t32 = thresh_to_f32(nms_thresh);
+    dp.dets = d_dets; dp.sel_idx = d_sel_idx; dp.det_cnt = d_det_cnt; dp.keep = d_keep; dp.keep_cnt = d_keep_cnt;
+    dp.status = &c->d_cnt->status;
+    {
+        StageTimer tm(c, ST_WALK);
+        hipLaunchKernelGGL(det_nms_kernel, dim3((unsigned)((F * K + 3) / 4)), dim3(256), 0, c->stream, dp);
+    }
+    HIPCHK(c, hipGetLastError());
+    return VDET_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 int vdet_nms_volume_ordered(vdet_ctx *c, const float *d_boxes, const uint16_t *d_order, const int32_t *d_ncand, int64_t F, int64_t B,
                             int64_t C, double thresh, int32_t *d_keep_idx, int32_t *d_keep_cnt, int64_t cap)
 {
@@ -1511,8 +1569,8 @@ int vdet_nms_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scor
     const uint32_t *w_flags = regular_ok ? c->gflags.as<uint32_t>() : nullptr;
     FrameIndex w_ix{nullptr, nullptr, nullptr, nullptr};
     if (w_flags && c->index_valid && !c->no_index) w_ix = frame_index_of(c);
-    BucketLists bkl{nullptr, nullptr, nullptr, 0};     // how far the u16 rows of bucketed lists are materialised (track_kernels.hpp)
-    if (c->lists_bucketed) bkl = BucketLists{c->ent.as<uint32_t>(), c->bst.as<uint16_t>(), c->nsb.as<int32_t>(), bucket_nbs((int)B)};
+    BucketLists bkl{nullptr, nullptr};     // how far the u16 rows of bucketed lists are materialised (track_kernels.hpp)
+    if (c->lists_bucketed) bkl = BucketLists{c->ent.as<uint32_t>(), c->nsb.as<int32_t>()};
     c->nodes_valid = false;
     HIPCHK(c, c->tracknode.reserve((size_t)std::max<int64_t>(C * max_tracks * F, 1) * 4));
     HIPCHK(c, hipMemsetAsync(c->tracknode.p, 0xFF, (size_t)std::max<int64_t>(C * max_tracks * F, 1) * 4, c->stream));

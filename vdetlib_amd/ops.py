@@ -88,6 +88,49 @@ def nms_volume(boxes, scores, thresh=0.3, score_thresh=None, cap=None, layout="F
     return keep_idx, keep_cnt
 
 
+def det_nms_volume(boxes, scores, score_thresh=0.05, topk=100, nms_thresh=0.3, first_class=1, sync=True, ctx=None,
+                   want_dets=True):
+    """The Fast R-CNN per-class flow of a whole video on the device: ``fast_rcnn_det_vid``'s per-class loop
+    (vdet/video_det.py:89-99: ``scores[:, j] > thresh``, the ``max_per_image`` best, rows ``boxes[inds, 4j:4j+4] | score``)
+    followed by ``apply_image_nms`` (vdet/image_det.py:117-123) for every frame and class -- every class suppresses its OWN
+    regressed boxes (``nms_volume`` is the class-agnostic-box form).
+
+    boxes [F,B,K,4] or [F,B,4K] f32 (the reference's per-frame ``[B, 4K]`` array), scores [F,B,K] f32; classes below
+    ``first_class`` (the background column) are skipped.  ``score_thresh=None``: every box is a candidate.  Returns
+      dets     [F,K,topk,5] f32 rows in the reference's row order (``all_boxes[j][i]`` = ``dets[i, j, :det_cnt[i, j]]``),
+      sel_idx  [F,K,topk] int32 box index of every row,  det_cnt [F,K] int32,
+      keep     [F,K,topk] int32 kept row positions, descending score (``apply_image_nms``'s list), keep_cnt [F,K] int32.
+    Entries behind the counts are -1 (dets: NaN)."""
+    if boxes.dtype != torch.float32 or scores.dtype != torch.float32:
+        raise ValueError("Buffer dtype mismatch, expected 'float32_t'")
+    scores = scores.contiguous()
+    if scores.dim() != 3:
+        raise ValueError("scores must be [F,B,K]")
+    F, B, K = scores.shape
+    boxes = boxes.contiguous()
+    if tuple(boxes.shape) not in ((F, B, K, 4), (F, B, 4 * K)):
+        raise ValueError("boxes must be [F,B,K,4] or [F,B,4K]")
+    topk = int(topk)
+    ctx = _ctx_for(boxes, ctx)
+    dev = boxes.device
+    dets = torch.full((F, K, topk, 5), float('nan'), dtype=torch.float32, device=dev) if want_dets else None
+    sel = torch.full((F, K, topk), -1, dtype=torch.int32, device=dev)
+    keep = torch.full((F, K, topk), -1, dtype=torch.int32, device=dev)
+    det_cnt = torch.zeros((F, K), dtype=torch.int32, device=dev)
+    keep_cnt = torch.zeros((F, K), dtype=torch.int32, device=dev)
+
+    def reset():
+        if dets is not None:
+            dets.fill_(float('nan'))
+        sel.fill_(-1); keep.fill_(-1)
+    _finish(ctx, lambda: ctx.check(ctx.lib.vdet_det_nms_volume(
+        ctx.h, boxes.data_ptr(), scores.data_ptr(), F, B, K, int(first_class), 0 if score_thresh is None else 1,
+        0.0 if score_thresh is None else float(score_thresh), topk, float(nms_thresh),
+        dets.data_ptr() if dets is not None else None, sel.data_ptr(), det_cnt.data_ptr(), keep.data_ptr(), keep_cnt.data_ptr())),
+        sync, reset=reset)
+    return dets, sel, det_cnt, keep, keep_cnt
+
+
 def nms_volume_ordered(boxes, order, ncand, thresh=0.3, cap=None, ctx=None, pad=True):
     """``nms_volume`` walking the CALLER's lists: order int16/uint16 [F,C,B] (box indices, e.g. ``argsort_volume``'s with
     ties rearranged as some machine's unstable ``scores.argsort()[::-1]`` left them, utils/nms.pyx:25), ncand int32 [F,C]
