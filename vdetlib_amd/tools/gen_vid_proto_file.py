@@ -14,8 +14,9 @@ import sys
 from ..utils.protocol import proto_dump, vid_proto_from_dir
 
 
-def generate(vid_name, root_dir, out_file, log=sys.stdout):
+def generate(vid_name, root_dir, out_file, log=None):
     """Returns True when the file was written, False when an existing file made the call a no-op."""
+    log = sys.stdout if log is None else log        # (looked up per call: stdout may have been redirected since import)
     if os.path.isfile(out_file):
         log.write("{} already exists.\n".format(out_file))
         return False
