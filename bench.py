@@ -219,6 +219,7 @@ def main():
         cx.set_cache(True)   # the volume pass, NMS and LINK of one step share keys, suppression graph and sorted lists
         cx.set_async(not args.sync_build)   # no host synchronisation inside a step once the first graph was built
     step_no = [0]
+    last_out = [None] * nstreams     # every stream's most recent step outputs (kept alive: compared after the timed region)
     heavy_done = [None]      # event: the previous step's heavy phase has left the GPU
     upload_src = [None]      # --with-upload leg: pinned host videos fed over PCIe at the head of every step
 
@@ -285,7 +286,8 @@ def main():
                 exch["events"].append((e0, e1))
                 exch["bytes"] = sum(t.numel() * t.element_size() for t in sent)
                 exch["last"] = (sent, gathered)
-        return keep_idx, keep_cnt, pooled, tub, conv
+        last_out[k] = (keep_idx, keep_cnt, pooled, tub, conv)
+        return last_out[k]
 
     def fence():
         if world > 1 or force_x:
@@ -353,6 +355,57 @@ def main():
                     "backend": dist.get_backend(), "world": dist.get_world_size(), "own_slot_matches": bool(mine),
                     "note": "HIP events on the step's stream around the two all_gather_into_tensor calls (tubelet boxes + pooled "
                             "scores, kept counts); the collectives run on RCCL's stream, ordered after the step's kernels"}
+
+    # ---- the TIMED configuration's own results: the last timed step of every stream (asynchronous builds, `--streams` videos
+    # in flight on their own streams and contexts) against a synchronous run of the same video on one fresh context, one
+    # video at a time on the default stream -- and, below (cpu_baseline.parity_checked_other_video), a video other than
+    # the first against the CPU oracle
+    timed_check = None
+    if rank == 0:
+        torch.cuda.synchronize()
+        timed = list(last_out)
+        ref_ctx = _lib.Context(local)
+        ref_ctx.set_cache(True)
+        taps_ref = None if (args.no_conv or args.window != len(TAPS)) else TAPS
+
+        def same(a, b):
+            if a is None or b is None:
+                return a is None and b is None
+            if a.is_floating_point():
+                return bool(torch.equal(a.nan_to_num(-7.0), b.nan_to_num(-7.0)))
+            return bool(torch.equal(a, b))
+        per_stream = []
+        for k in range(nstreams):
+            if timed[k] is None:
+                continue
+            vb, vs = vids[k]
+            ref_ctx.invalidate()
+            rp, rc = ops.volume_pass(vs, args.window, taps_ref, ctx=ref_ctx)
+            if rc is None and not args.no_conv:
+                rc = ops.temporal_conv(vs, TAPS, bias=0.0, pad=0.0, ctx=ref_ctx)
+            ki, kc, pooled_t, tub_t, conv_t = timed[k]
+            ok = same(pooled_t, rp) and same(conv_t, rc)
+            if args.no_link:
+                ri, rcnt = ops.nms_volume(vb, vs, args.thresh, cap=args.cap, ctx=ref_ctx, pad=False)
+            else:
+                ri, rcnt, rtr, ran, rnt = ops.nms_track_volume(vb, vs, nms_thres=args.thresh, thres=args.track_thres,
+                                                               max_tracks=args.max_tracks, link_thres=args.link_thres,
+                                                               max_frames=args.max_frames, cap=args.cap, ctx=ref_ctx, pad=False)
+                if tub_t is not None:
+                    rdet, rtp, rtb = ops.rescore_tracks(rtr, rnt, vb, vs, overlap_thres=args.pool_thres, window=args.window, ctx=ref_ctx)
+                    ok = ok and same(tub_t[0], rtr) and same(tub_t[1], rnt) and same(tub_t[2], rtp) and same(tub_t[3], rtb)
+                    del rdet, rtp, rtb
+                del rtr, ran, rnt
+            live = torch.arange(ki.shape[2], device=dev)[None, None, :] < kc[:, :, None]     # (pad=False: the tail is uninitialised)
+            ok = ok and same(kc, rcnt) and bool(torch.equal(torch.where(live, ki, -1), torch.where(live, ri, -1)))
+            per_stream.append(bool(ok))
+            del ri, rcnt, rp, rc, live
+        timed_check = {"timed_outputs_identical": bool(per_stream) and all(per_stream), "streams_checked": len(per_stream),
+                       "against": "one fresh synchronous context, one video at a time on the default stream (every output tensor "
+                                  "of the step: kept indices + counts, both temporal volumes, tubelets, re-scored tubelets)"}
+        ref_ctx.sync()
+        del ref_ctx, timed
+        torch.cuda.empty_cache()
 
     # ---- per-kernel timing (HIP events on the kernels' stream), outside the timed region
     result = None
@@ -689,6 +742,7 @@ def main():
             "hbm_traffic_per_video": hbm_total,          # sum of the PMC table (profiles/pmc_traffic.json), all kernels of one step
             "vid_shape": vid_shape,
             "lists": lists,
+            "timed_check": timed_check,
             "inputs": "HBM-resident (the PCIe-fed rate is upload_pipeline.boxes_per_s, never `value`)",
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_allcores": cpu_all, "map_parity": map_par, "pcie": pcie,
             "upload_pipeline": upload,

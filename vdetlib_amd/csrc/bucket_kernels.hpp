@@ -95,184 +95,291 @@ __device__ __forceinline__ uint32_t bucket_rank_members(uint32_t ekey, bool memb
     return rank;
 }
 
-// KPT = keys per thread (key v = tid + k * 1024)
-template <int KPT, bool FLOATS>
-__global__ __launch_bounds__(1024, KPT <= 10 ? 8 : 4) void bucket_kernel(const BucketParams prm)
+// workgroup barrier that orders LDS traffic only: the next list's keys stay in flight across it (a plain __syncthreads()
+// waits for every outstanding global load on gfx9: one counter for loads and stores)
+__device__ __forceinline__ void bucket_lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+constexpr uint32_t kBkNeedsRank = 0x80000000u;   // bucket start word: its entries are put in exact order (chunk border / head)
+constexpr uint32_t kBkTied = 0x40000000u;        // ... and two of them share an ord: the full keys decide (bucket_rank_members)
+constexpr uint32_t kBkStartMask = 0x0000FFFFu;
+constexpr int kBkWorkMax = 2048;                 // entries ranked per list (two per thread)
+
+// BLOCK threads, KPT = keys per thread (key v = tid + k * BLOCK).  Persistent workgroups: a workgroup walks its share of the
+// lists and requests the next list's keys before it starts on the current one.  512 threads x 20 keys at B = 10 000: the LDS
+// (65 KB) admits two workgroups per CU whatever their size, and 8 waves each leave 128 VGPRs per lane -- 1 024 threads x 10
+// keys under the 64-register cap spill the prefetched keys.
+template <int BLOCK, int KPT, bool FLOATS>
+__global__ __launch_bounds__(BLOCK, (BLOCK == 1024 && KPT <= 10) ? 8 : 4) void bucket_kernel(const BucketParams prm)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *hist = reinterpret_cast<uint32_t *>(smem);
     const uint16_t *cum16 = reinterpret_cast<const uint16_t *>(smem);
+    uint32_t *work = hist;                                // (the histogram is dead once every key has its bucket)
     uint32_t *bcnt = hist + kBkHistWords;
     uint32_t *stage = bcnt + kBkCntWords;
-    __shared__ uint32_t swt[16];
-    __shared__ uint32_t swb[16];
+    constexpr int NW = BLOCK / 64;                        // waves
+    constexpr int HPT = (1 << kBkDigitBits) / 2 / BLOCK;  // histogram words per thread (4 or 8)
+    constexpr int CPT = 2048 / BLOCK;                     // bucket counters per thread (2 or 4)
+    constexpr int WPT = kBkWorkMax / BLOCK;               // ranked entries per thread
+    __shared__ uint32_t swt[NW];
+    __shared__ uint32_t swb[NW];
     __shared__ int sfail;
+    __shared__ uint32_t nwork, ntied;
+    __shared__ uint32_t tied[64];
     constexpr int kMBits = 32 - kBkDigitBits;            // low key bits interpolated inside a bin
     constexpr int kHistW = (1 << kBkDigitBits) / 2;      // counter words
-    static_assert(kHistW == 4 * 1024, "one uint4 of counters per thread");
+    static_assert(HPT * BLOCK == kHistW && (HPT == 4 || HPT == 8) && CPT * BLOCK == 2048, "whole vectors of counters per thread");
+    static_assert(kBkWorkMax <= kHistW, "the work list lives in the histogram");
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int p = xcd_problem(blockIdx.x, gridDim.x);
-    if (p >= prm.P) return;
-    const int g = p / prm.C;
-    const int N = prm.groups[g].nbox;
-    const bool doable = N >= 2 && N <= kBkMaxB && N <= 1024 * KPT && (prm.group_flags[g] & kFlagRegular);
-    if (!doable) {                                       // (block-uniform)
-        if (tid == 0) { prm.nsb[p] = -1; prm.fail_list[atomicAdd(prm.nfail, 1)] = p; }
-        return;
-    }
-    const uint32_t *src = prm.raw + (int64_t)p * prm.B;
+    // XCD-contiguous shares (block b runs on XCD b % 8): the lists of one frame meet in one L2
+    const int per = (prm.P + 7) >> 3;
+    const int p_end = min(prm.P, ((int)(blockIdx.x & 7) + 1) * per);
+    const int stride = (int)gridDim.x >> 3;
+    int pn = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
 
-    // the keys, inverted: ascending = the list's order; 0xFFFFFFFF = not a candidate (real inverted keys are <= 0xFF800000)
-    uint32_t ik[KPT];
+    uint32_t nxt[KPT];
+    int n_nxt = 0;                                        // boxes of the requested list; 0: the kernel does not take it
+    auto request = [&](int q) {
+        n_nxt = 0;
+        if (q >= p_end) return;
+        const int g = q / prm.C;
+        const int N = prm.groups[g].nbox;
+        if (!(N >= 2 && N <= kBkMaxB && N <= BLOCK * KPT && (prm.group_flags[g] & kFlagRegular))) return;
+        n_nxt = N;
+        const uint32_t *src = prm.raw + (int64_t)q * prm.B;
 #pragma unroll
-    for (int k = 0; k < KPT; ++k) {
-        const int v = tid + k * 1024;
-        uint32_t kk = 0u;
-        if (v < N) {
-            const uint32_t r = src[v];
-            if (FLOATS) {
-                const float sc = __uint_as_float(r);
-                kk = score_key(sc);
-                if (prm.use_thr && !(sc > prm.thr)) kk = 0u;
-            } else {
-                kk = r;
+        for (int k = 0; k < KPT; ++k) {
+            const int v = tid + k * BLOCK;
+            nxt[k] = v < N ? src[v] : 0u;
+        }
+    };
+    request(pn);
+    while (pn < p_end) {
+        const int p = pn, N = n_nxt;
+        // the keys, inverted: ascending = the list's order; 0xFFFFFFFF = not a candidate (real inverted keys are <= 0xFF800000)
+        uint32_t ik[KPT];
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) {
+            const int v = tid + k * BLOCK;
+            uint32_t kk = 0u;
+            if (v < N) {
+                if (FLOATS) {
+                    const float sc = __uint_as_float(nxt[k]);
+                    kk = score_key(sc);
+                    if (prm.use_thr && !(sc > prm.thr)) kk = 0u;
+                } else {
+                    kk = nxt[k];
+                }
+            }
+            ik[k] = ~kk;
+        }
+        pn += stride;
+        request(pn);                                      // in flight while this list is cut
+        if (N == 0) {                                     // (block-uniform) irregular frame / size: the LSD kernel sorts this list
+            if (tid == 0) { prm.nsb[p] = -1; prm.fail_list[atomicAdd(prm.nfail, 1)] = p; }
+            continue;
+        }
+        const uint32_t *src = prm.raw + (int64_t)p * prm.B;
+        {
+#pragma unroll
+            for (int j = 0; j < HPT / 4; ++j) reinterpret_cast<uint4 *>(hist)[tid * (HPT / 4) + j] = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+            for (int j = 0; j < CPT / 2; ++j) reinterpret_cast<uint2 *>(bcnt)[tid * (CPT / 2) + j] = make_uint2(0u, 0u);
+            if (tid < 4) hist[kHistW + tid] = 0u;         // cum[last + 1] ...
+            if (tid < 8) bcnt[2048 + tid] = 0u;
+            if (tid == 0) { sfail = 0; nwork = 0u; ntied = 0u; }
+        }
+        bucket_lds_barrier();
+#pragma unroll
+        for (int k = 0; k < KPT; ++k)
+            if (ik[k] != 0xFFFFFFFFu) {
+                const uint32_t d = ik[k] >> kMBits;
+                atomicAdd(&hist[d >> 1], (d & 1u) ? 0x10000u : 1u);
+            }
+        bucket_lds_barrier();
+        // exclusive scan of the counters, in place: thread t owns digits [2 HPT t, 2 HPT (t + 1))
+        uint32_t hw[HPT];
+#pragma unroll
+        for (int j = 0; j < HPT / 4; ++j) {
+            const uint4 a = reinterpret_cast<const uint4 *>(hist)[tid * (HPT / 4) + j];
+            hw[4 * j] = a.x; hw[4 * j + 1] = a.y; hw[4 * j + 2] = a.z; hw[4 * j + 3] = a.w;
+        }
+        uint32_t tot = 0;
+#pragma unroll
+        for (int j = 0; j < HPT; ++j) tot += (hw[j] & 0xFFFFu) + (hw[j] >> 16);
+        const uint32_t incl = wave_incl_scan_u32(tot);
+        if (lane == 63) swt[w] = incl;
+        bucket_lds_barrier();
+        uint32_t run = incl - tot;
+        uint32_t ncand_u = 0;
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            const uint32_t s = swt[k];
+            run += k < w ? s : 0u;
+            ncand_u += s;
+        }
+        const int ncand = (int)ncand_u;
+        {
+#pragma unroll
+            for (int j = 0; j < HPT; ++j) {
+                const uint32_t lo = hw[j] & 0xFFFFu, hi = hw[j] >> 16;
+                hw[j] = run | ((run + lo) << 16);          // (cum <= 16 384: 16 bits, no carry into the next field)
+                run += lo + hi;
+            }
+#pragma unroll
+            for (int j = 0; j < HPT / 4; ++j)
+                reinterpret_cast<uint4 *>(hist)[tid * (HPT / 4) + j] = make_uint4(hw[4 * j], hw[4 * j + 1], hw[4 * j + 2], hw[4 * j + 3]);
+            if (tid == BLOCK - 1) hist[kHistW] = run | (run << 16);   // cum[last + 1] = ncand
+        }
+        bucket_lds_barrier();
+        // rank estimate -> bucket, slot inside the bucket
+        uint32_t br[KPT];
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) {
+            br[k] = 0xFFFFFFFFu;
+            if (ik[k] != 0xFFFFFFFFu) {
+                const uint32_t d = ik[k] >> kMBits, m = (ik[k] & ((1u << kMBits) - 1u)) >> (kMBits - 18);   // 18 bits of the remainder
+                const uint32_t c0 = cum16[d], c1 = cum16[d + 1];
+                const uint32_t fine = (c0 << 13) + (__umul24(m, c1 - c0) >> 5);      // m < 2^18, count <= 2^14: the product fits
+                const uint32_t b = fine >> 16;
+                const uint32_t r = atomicAdd(&bcnt[b], 1u);
+                ik[k] = ((fine & 0xFFFFu) << 15) | (r == 0u ? kBkFlag : 0u) | (kBkIdxMask ^ (uint32_t)(tid + k * BLOCK));   // the entry
+                br[k] = (b << 8) | (r < 255u ? r : 255u);
             }
         }
-        ik[k] = ~kk;
-    }
-    {
-        reinterpret_cast<uint4 *>(hist)[tid] = make_uint4(0u, 0u, 0u, 0u);
-        reinterpret_cast<uint2 *>(bcnt)[tid] = make_uint2(0u, 0u);
-        if (tid < 4) hist[kHistW + tid] = 0u;             // cum[last + 1] ...
-        if (tid < 8) bcnt[2048 + tid] = 0u;
-        if (tid == 0) sfail = 0;
-    }
-    __syncthreads();
+        bucket_lds_barrier();
+        // bucket starts (<= 2 048 buckets, CPT per thread)
+        uint32_t bn[CPT], bsum = 0, bincl;
+        {
 #pragma unroll
-    for (int k = 0; k < KPT; ++k)
-        if (ik[k] != 0xFFFFFFFFu) {
-            const uint32_t d = ik[k] >> kMBits;
-            atomicAdd(&hist[d >> 1], (d & 1u) ? 0x10000u : 1u);
-        }
-    __syncthreads();
-    // exclusive scan of the counters, in place: thread t owns digits [8 t, 8 t + 8)
-    uint32_t hw[4];
-    {
-        const uint4 a = reinterpret_cast<const uint4 *>(hist)[tid];
-        hw[0] = a.x; hw[1] = a.y; hw[2] = a.z; hw[3] = a.w;
-    }
-    uint32_t tot = 0;
+            for (int j = 0; j < CPT / 2; ++j) {
+                const uint2 a = reinterpret_cast<const uint2 *>(bcnt)[tid * (CPT / 2) + j];
+                bn[2 * j] = a.x; bn[2 * j + 1] = a.y;
+            }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) tot += (hw[j] & 0xFFFFu) + (hw[j] >> 16);
-    const uint32_t incl = wave_incl_scan_u32(tot);
-    if (lane == 63) swt[w] = incl;
-    __syncthreads();
-    uint32_t run = incl - tot;
-    uint32_t ncand_u = 0;
+            for (int j = 0; j < CPT; ++j) {
+                if (bn[j] > (uint32_t)kBkMax) sfail = 1;
+                bsum += bn[j];
+            }
+            bincl = wave_incl_scan_u32(bsum);
+            if (lane == 63) swb[w] = bincl;
+        }
+        bucket_lds_barrier();
+        if (sfail) {                                      // (block-uniform) a crowded bucket: the LSD kernel sorts this list
+            if (tid == 0) { prm.nsb[p] = -1; prm.fail_list[atomicAdd(prm.nfail, 1)] = p; }
+            bucket_lds_barrier();                         // (every wave has read sfail before the next list clears it)
+            continue;
+        }
+        const int nbk = (ncand + 7) >> 3;                 // buckets in use (est. rank < ncand)
+        const int nhead = prm.order ? (nbk < kBkHead ? nbk : kBkHead) : 0;
+        {
+            // a bucket across a 64-entry chunk border, or one of the head the tracking kernels read, is put in exact order
+            uint32_t st = bincl - bsum;
+            for (int k = 0; k < w; ++k) st += swb[k];
+            uint32_t sw[CPT];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const uint32_t s = swt[k];
-        run += k < w ? s : 0u;
-        ncand_u += s;
-    }
-    const int ncand = (int)ncand_u;
-    {
+            for (int j = 0; j < CPT; ++j) {
+                const bool need = bn[j] && ((CPT * tid + j < nhead) || (bn[j] > 1u && (st >> 6) != ((st + bn[j] - 1u) >> 6)));
+                sw[j] = st | (need ? kBkNeedsRank : 0u);
+                st += bn[j];
+            }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint32_t lo = hw[j] & 0xFFFFu, hi = hw[j] >> 16;
-            hw[j] = run | ((run + lo) << 16);              // (cum <= 16 384: 16 bits, no carry into the next field)
-            run += lo + hi;
+            for (int j = 0; j < CPT / 2; ++j) reinterpret_cast<uint2 *>(bcnt)[tid * (CPT / 2) + j] = make_uint2(sw[2 * j], sw[2 * j + 1]);
+            if (tid == BLOCK - 1) bcnt[2048] = st;
         }
-        reinterpret_cast<uint4 *>(hist)[tid] = make_uint4(hw[0], hw[1], hw[2], hw[3]);
-        if (tid == 1023) hist[kHistW] = run | (run << 16);   // cum[last + 1] = ncand
-    }
-    __syncthreads();
-    // rank estimate -> bucket, slot inside the bucket
-    uint32_t br[KPT];
+        bucket_lds_barrier();
 #pragma unroll
-    for (int k = 0; k < KPT; ++k) {
-        br[k] = 0xFFFFFFFFu;
-        if (ik[k] != 0xFFFFFFFFu) {
-            const uint32_t d = ik[k] >> kMBits, m = (ik[k] & ((1u << kMBits) - 1u)) >> (kMBits - 18);   // 18 bits of the remainder
-            const uint32_t c0 = cum16[d], c1 = cum16[d + 1];
-            const uint32_t fine = (c0 << 13) + (__umul24(m, c1 - c0) >> 5);      // m < 2^18, count <= 2^14: the product fits
-            const uint32_t b = fine >> 16;
-            const uint32_t r = atomicAdd(&bcnt[b], 1u);
-            ik[k] = ((fine & 0xFFFFu) << 15) | (r == 0u ? kBkFlag : 0u) | (kBkIdxMask ^ (uint32_t)(tid + k * 1024));   // the entry
-            br[k] = (b << 8) | (r < 255u ? r : 255u);
+        for (int k = 0; k < KPT; ++k)
+            if (br[k] != 0xFFFFFFFFu) {
+                const uint32_t b = br[k] >> 8, sw = bcnt[b];
+                const uint32_t pos = (sw & kBkStartMask) + (br[k] & 255u);
+                stage[pos] = ik[k];
+                if (sw & kBkNeedsRank) {
+                    const uint32_t slot = atomicAdd(&nwork, 1u);
+                    if (slot < (uint32_t)kBkWorkMax) work[slot] = pos | (b << 14);
+                }
+            }
+        bucket_lds_barrier();
+        const int nw = (int)nwork;
+        if (nw > kBkWorkMax) {                            // (block-uniform; does not happen with buckets of ~8)
+            if (tid == 0) { prm.nsb[p] = -1; prm.fail_list[atomicAdd(prm.nfail, 1)] = p; }
+            bucket_lds_barrier();
+            continue;
         }
-    }
-    __syncthreads();
-    // bucket starts (<= 2 048 buckets, two per thread)
-    uint32_t bn0, bn1, bincl;
-    {
-        const uint2 a = reinterpret_cast<const uint2 *>(bcnt)[tid];
-        bn0 = a.x; bn1 = a.y;
-        if (bn0 > (uint32_t)kBkMax || bn1 > (uint32_t)kBkMax) sfail = 1;
-        bincl = wave_incl_scan_u32(bn0 + bn1);
-        if (lane == 63) swb[w] = bincl;
-    }
-    __syncthreads();
-    if (sfail) {                                          // (block-uniform) a crowded bucket: the LSD kernel sorts this list
-        if (tid == 0) { prm.nsb[p] = -1; prm.fail_list[atomicAdd(prm.nfail, 1)] = p; }
-        return;
-    }
-    const int nbk = (ncand + 7) >> 3;                     // buckets in use (est. rank < ncand)
-    {
-        uint32_t st = bincl - (bn0 + bn1);
-        for (int k = 0; k < w; ++k) st += swb[k];
-        reinterpret_cast<uint2 *>(bcnt)[tid] = make_uint2(st, st + bn0);
-        if (tid == 1023) bcnt[2048] = st + bn0 + bn1;
-    }
-    __syncthreads();
+        // exact rank of the listed entries inside their buckets (rank by counting; the bucket is <= 32 entries)
+        uint32_t we[WPT], ws[WPT], wr[WPT];
 #pragma unroll
-    for (int k = 0; k < KPT; ++k)
-        if (br[k] != 0xFFFFFFFFu) stage[bcnt[br[k] >> 8] + (br[k] & 255u)] = ik[k];
-    __syncthreads();
-    // the bucket across every 64-entry chunk border: exact order, every entry a bucket of its own
-    {
-        const int nchunk = (ncand + 63) >> 6;
-        for (int j = 1 + w; j < nchunk; j += 16) {
-            const int pos0 = 64 * j - 32, q = pos0 + lane;
-            const bool valid = q < ncand;
-            const uint32_t e = valid ? stage[q] : 0xFFFFFFFFu;
-            const unsigned long long fm = __ballot(!valid || (e & kBkFlag) != 0u);     // lanes where a bucket starts
-            if ((fm >> 32) & 1ull) continue;               // a bucket starts right at the border: nothing straddles
-            const unsigned long long low = fm & 0xFFFFFFFFull, high = fm >> 33;
-            const int ls = 63 - __builtin_clzll(low);      // (buckets hold <= 32 entries: the start is within reach)
-            const int le = high ? 33 + (__ffsll((unsigned long long)high) - 1) : 64;
-            const bool member = lane >= ls && lane < le;
-            const uint32_t ekey = e & ~kBkFlag;
-            const uint32_t rank = bucket_rank_members<FLOATS>(ekey, member, ls, le, src);
-            if (member) stage[pos0 + ls + (int)rank] = ekey | kBkFlag;
+        for (int h = 0; h < WPT; ++h) {
+            const int i = tid + BLOCK * h;
+            we[h] = 0xFFFFFFFFu; ws[h] = 0u; wr[h] = 0u;
+            if (i < nw) {
+                const uint32_t it = work[i], b = it >> 14;
+                const uint32_t s = bcnt[b] & kBkStartMask, n = (bcnt[b + 1] & kBkStartMask) - s;
+                const uint32_t e = stage[it & 0x3FFFu] & ~kBkFlag;
+                uint32_t rank = 0u, eq = 0u;
+                for (uint32_t j = 0; j < n; ++j) {
+                    const uint32_t ej = stage[s + j] & ~kBkFlag;
+                    rank += ej < e ? 1u : 0u;
+                    eq += ((ej ^ e) >> 15) == 0u ? 1u : 0u;
+                }
+                if (eq > 1u && !(atomicOr(&bcnt[b], kBkTied) & kBkTied)) {      // same ord as another entry: this bucket by full keys
+                    const uint32_t t = atomicAdd(&ntied, 1u);
+                    if (t < 64u) tied[t] = b; else sfail = 1;
+                }
+                we[h] = e; ws[h] = s | (b << 16); wr[h] = rank;
+            }
         }
-    }
-    __syncthreads();
-    {
-        uint32_t *out = prm.ent + (int64_t)p * prm.B;
-        if ((((int64_t)p * prm.B) & 3) == 0) {
-            const int nv = ncand >> 2;
-            for (int i = tid; i < nv; i += 1024) reinterpret_cast<uint4 *>(out)[i] = reinterpret_cast<const uint4 *>(stage)[i];
-            for (int i = (nv << 2) + tid; i < ncand; i += 1024) out[i] = stage[i];
-        } else {
-            for (int i = tid; i < ncand; i += 1024) out[i] = stage[i];
+        bucket_lds_barrier();                             // every rank is counted before an entry moves
+        if (sfail) {
+            if (tid == 0) { prm.nsb[p] = -1; prm.fail_list[atomicAdd(prm.nfail, 1)] = p; }
+            bucket_lds_barrier();
+            continue;
         }
-    }
-    int nhead = 0;
-    if (prm.order) {
-        nhead = nbk < kBkHead ? nbk : kBkHead;
-        for (int b = w; b < nhead; b += 16) {             // exact order of the head buckets, one wave each
-            const int s = (int)bcnt[b], n = (int)bcnt[b + 1] - s;
-            const bool member = lane < n;
-            const uint32_t ekey = member ? (stage[s + lane] & ~kBkFlag) : 0xFFFFFFFFu;
-            const uint32_t rank = bucket_rank_members<FLOATS>(ekey, member, 0, n, src);
-            if (member) prm.order[(int64_t)p * prm.B + s + (int)rank] = (uint16_t)bucket_entry_index(ekey);
+        uint16_t *head = prm.order ? prm.order + (int64_t)p * prm.B : nullptr;
+#pragma unroll
+        for (int h = 0; h < WPT; ++h)
+            if (we[h] != 0xFFFFFFFFu) {
+                const uint32_t b = ws[h] >> 16, s = ws[h] & 0xFFFFu;
+                if (!(bcnt[b] & kBkTied)) {
+                    stage[s + wr[h]] = we[h] | kBkFlag;   // (every entry of an ordered bucket is a bucket of its own)
+                    if ((int)b < nhead) head[s + wr[h]] = (uint16_t)bucket_entry_index(we[h]);
+                }
+            }
+        {
+            const int nt = (int)ntied;                    // rare: buckets in which the entry values do not decide
+            for (int i = w; i < nt; i += NW) {
+                const uint32_t b = tied[i];
+                const int s = (int)(bcnt[b] & kBkStartMask), n = (int)(bcnt[b + 1] & kBkStartMask) - s;
+                const bool member = lane < n;
+                const uint32_t ekey = member ? (stage[s + lane] & ~kBkFlag) : 0xFFFFFFFFu;
+                const uint32_t rank = bucket_rank_members<FLOATS>(ekey, member, 0, n, src);
+                if (member) {
+                    stage[s + (int)rank] = ekey | kBkFlag;
+                    if ((int)b < nhead) head[s + (int)rank] = (uint16_t)bucket_entry_index(ekey);
+                }
+            }
         }
-    }
-    if (tid == 0) {
-        prm.ncand[p] = ncand;
-        prm.nsb[p] = (int)bcnt[nhead];
+        if (tid == 0) {
+            prm.ncand[p] = ncand;
+            prm.nsb[p] = (int)(bcnt[nhead] & kBkStartMask);
+        }
+        bucket_lds_barrier();
+        {
+            uint32_t *out = prm.ent + (int64_t)p * prm.B;
+            if ((((int64_t)p * prm.B) & 3) == 0) {
+                const int nv = ncand >> 2;
+                for (int i = tid; i < nv; i += BLOCK) reinterpret_cast<uint4 *>(out)[i] = reinterpret_cast<const uint4 *>(stage)[i];
+                for (int i = (nv << 2) + tid; i < ncand; i += BLOCK) out[i] = stage[i];
+            } else {
+                for (int i = tid; i < ncand; i += BLOCK) out[i] = stage[i];
+            }
+        }
     }
 }
 

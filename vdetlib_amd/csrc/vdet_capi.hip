@@ -164,6 +164,7 @@ struct vdet_ctx {
     // round 4: per-(frame, class) lists cut into score-ordered buckets instead of sorted (bucket_kernels.hpp)
     int bucket_mode = 1;          // VDET_BUCKETS=0: always the LSD sort; 1 (default): volumes of more than 1024 boxes per frame whose
                                   // regular frames take the packed walk; 2: every volume the kernel can take (tests)
+    int bucket_block = 512;       // VDET_BUCKET_BLOCK=1024: 1 024 threads x 10 keys per list at B <= 10 240 (A-B knob)
     bool lists_bucketed = false;  // the context's lists (c->order / c->ncand) are bucketed: c->ent / c->bst / c->nsb describe them
     bool last_sort_bucketed = false;   // the last per-(frame, class) sort went through bucket_kernel (vdet_query 10 / 11)
     const uint32_t *bk_raw = nullptr;  // what the buckets were cut from (keys or float scores), for the consumers' tie fallback
@@ -604,9 +605,10 @@ int launch_sort_walk(vdet_ctx *c, const SortWalkArgs &a, int nmax, int64_t order
         std::vector<const void *> fns;
         for (const Variant &v : variants) { fns.push_back(v.fn[0]); fns.push_back(v.fn[1]); fns.push_back(v.fn_list[0]); fns.push_back(v.fn_list[1]); }
         fns.push_back(reinterpret_cast<const void *>(walk_kernel));
-        for (const void *fn : {reinterpret_cast<const void *>(bucket_kernel<4, false>), reinterpret_cast<const void *>(bucket_kernel<4, true>),
-                               reinterpret_cast<const void *>(bucket_kernel<10, false>), reinterpret_cast<const void *>(bucket_kernel<10, true>),
-                               reinterpret_cast<const void *>(bucket_kernel<16, false>), reinterpret_cast<const void *>(bucket_kernel<16, true>)})
+        for (const void *fn : {reinterpret_cast<const void *>(bucket_kernel<512, 8, false>), reinterpret_cast<const void *>(bucket_kernel<512, 8, true>),
+                               reinterpret_cast<const void *>(bucket_kernel<512, 20, false>), reinterpret_cast<const void *>(bucket_kernel<512, 20, true>),
+                               reinterpret_cast<const void *>(bucket_kernel<1024, 16, false>), reinterpret_cast<const void *>(bucket_kernel<1024, 16, true>),
+                               reinterpret_cast<const void *>(bucket_kernel<1024, 10, false>), reinterpret_cast<const void *>(bucket_kernel<1024, 10, true>)})
             fns.push_back(fn);
         for (const void *fn : {reinterpret_cast<const void *>(binsort_kernel<8, false>), reinterpret_cast<const void *>(binsort_kernel<8, true>),
                                reinterpret_cast<const void *>(binsort_kernel<20, false>), reinterpret_cast<const void *>(binsort_kernel<20, true>),
@@ -721,11 +723,16 @@ int launch_sort_walk(vdet_ctx *c, const SortWalkArgs &a, int nmax, int64_t order
             bp.fail_list = reinterpret_cast<int32_t *>(c->sortctl.as<char>() + sizeof(BinSortCtl));
             bp.nfail = &c->sortctl.as<BinSortCtl>()->nfail;
             c->bk_raw = bp.raw; c->bk_floats = floats ? 1 : 0;
-#define VDET_BKK(KP) (floats ? reinterpret_cast<const void *>(bucket_kernel<KP, true>) : reinterpret_cast<const void *>(bucket_kernel<KP, false>))
-            const void *bfn = nmax <= 4096 ? VDET_BKK(4) : nmax <= 10240 ? VDET_BKK(10) : VDET_BKK(16);
+#define VDET_BKK(BL, KP) (floats ? reinterpret_cast<const void *>(bucket_kernel<BL, KP, true>) : reinterpret_cast<const void *>(bucket_kernel<BL, KP, false>))
+            const bool wide = c->bucket_block == 1024 && nmax > 4096 && nmax <= 10240;     // VDET_BUCKET_BLOCK=1024 (A-B knob)
+            const void *bfn = wide ? VDET_BKK(1024, 10) : nmax <= 4096 ? VDET_BKK(512, 8) : nmax <= 10240 ? VDET_BKK(512, 20) : VDET_BKK(1024, 16);
+            const int bblock = (wide || nmax > 10240) ? 1024 : 512;
 #undef VDET_BKK
             void *bargs[] = {&bp};
-            HIPCHK(c, hipLaunchKernel(bfn, dim3((a.P + 7) & ~7), dim3(1024), bargs, bk_lds, c->stream));
+            // persistent workgroups (the next list's keys are requested while the current one is cut): as many as are resident
+            const int per_cu = 2 * (bk_lds + 512) <= c->max_lds ? 2 : 1;
+            const int bgrid = std::max(8, (per_cu * c->n_cu) & ~7);
+            HIPCHK(c, hipLaunchKernel(bfn, dim3(bgrid), dim3(bblock), bargs, bk_lds, c->stream));
             const int32_t *fl = bp.fail_list;
             const int *fc = bp.nfail;
             void *largs[] = {&sp, (void *)&fl, (void *)&fc};
@@ -954,6 +961,7 @@ int vdet_create(vdet_ctx **out, int device)
     if (const char *e = getenv("VDET_LINK_MEMO")) c->link_memo = atoi(e) != 0;
     if (const char *e = getenv("VDET_BINSORT")) c->binsort = atoi(e) != 0;
     if (const char *e = getenv("VDET_BUCKETS")) c->bucket_mode = atoi(e);
+    if (const char *e = getenv("VDET_BUCKET_BLOCK")) c->bucket_block = atoi(e);
     if (const char *e = getenv("VDET_TRACK_LOOP")) c->track_loop = atoi(e) != 0;
     if (const char *e = getenv("VDET_LINK_WARM")) c->link_warm = atoi(e);
     if (const char *e = getenv("VDET_LINK_MAXB")) c->link_maxb = atoi(e) == 16 ? 16 : 8;
