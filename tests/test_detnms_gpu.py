@@ -115,7 +115,7 @@ def test_det_nms_config2_size(oracle):
     h = 10 + torch.rand(F, B, 1, generator=g, device="cuda") * 290
     BX = torch.empty(F, B, K, 4, device="cuda")
     for i, t in enumerate((x1, y1, x1 + w, y1 + h)):                                              # per-class regression deltas
-        BX[..., i] = t + (torch.rand(F, B, K, generator=g, device="cuda") - 0.5) * 24
+        BX[..., i] = t + (torch.rand(F, B, K, generator=g, device="cuda") - 0.5) * 8       # (w, h >= 10: no box collapses)
     del x1, y1, w, h
     BX.round_()
     S = torch.rand(F, B, K, generator=g, device="cuda")

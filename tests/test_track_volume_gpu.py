@@ -432,12 +432,20 @@ def test_pipelined_graph_build(monkeypatch, oracle, irregular):
 
 def test_link_memo_shares_steps_across_chains(oracle):
     """Coherent proposals, several classes: chains of different classes / tracks run through the same nodes, so the
-    link memo serves a large share of the steps (vdet_query 4 / 5) -- with tubelets identical to the oracle's."""
+    link memo serves a large share of the steps (vdet_query 4 / 5) -- with tubelets identical to the oracle's.  Frames
+    this small get their whole link table up front (link_fill_kernel): then NO step is ever scanned; VDET_LINK_FILL=0
+    keeps the warm-up + scan-on-miss scheme of large frames."""
+    import os
     import torch
     from vdetlib_amd import ops, _lib
     boxes, scores = synth.coherent_video(77, 40, 300, 6)
-    cx = _lib.Context(torch.cuda.current_device())
-    tr, an, nt = ops.track_volume(torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda(), thres=0.0, max_tracks=8, ctx=cx)
+    tb, ts = torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda()
+    os.environ["VDET_LINK_FILL"] = "0"
+    try:
+        cx = _lib.Context(torch.cuda.current_device())
+    finally:
+        del os.environ["VDET_LINK_FILL"]
+    tr, an, nt = ops.track_volume(tb, ts, thres=0.0, max_tracks=8, ctx=cx)
     # steps found in the memo / scanned, by the tracking loop (4, 5) and by the warm-up of the predicted anchors (6, 7);
     # tubelets of predicted anchors are copied from the materialised warm chains, so the loop may have nothing left to do
     hits, misses = cx.query(4) + cx.query(6), cx.query(5) + cx.query(7)
@@ -447,3 +455,40 @@ def test_link_memo_shares_steps_across_chains(oracle):
         wt, wa, wn = oracle.greedy_track_volume(boxes, scores[:, :, c], 0.3, 0.0, 8, 0.5, 0)
         assert int(nt[c]) == wn and np.array_equal(tr[c, :wn].cpu().numpy(), wt[:wn], equal_nan=True)
     cx.close()
+    cf = _lib.Context(torch.cuda.current_device())          # default: the whole table first
+    tr2, an2, nt2 = ops.track_volume(tb, ts, thres=0.0, max_tracks=8, ctx=cf)
+    assert cf.query(5) + cf.query(7) == 0                    # nothing was scanned by a chain
+    assert torch.equal(nt, nt2) and torch.equal(an, an2) and torch.equal(tr.nan_to_num(-7.0), tr2.nan_to_num(-7.0))
+    cf.close()
+
+
+@pytest.mark.parametrize("case", ["frac", "irregular", "max_frames"])
+def test_link_table_up_front_equals_scanning_on_demand(case):
+    """link_fill_kernel (every node's next() at once) against the chains' own window scans on fractional boxes (the int
+    truncation of the current box matters), on a video with irregular frames (plain arg-max over all boxes) and with a
+    tubelet length limit"""
+    import os
+    import torch
+    from vdetlib_amd import ops, _lib
+    boxes, scores = synth.coherent_video(91, 24, 260, 4, jitter=4, frac=(case == "frac"))
+    if case == "irregular":
+        boxes[5, 7, 0] = np.nan
+        boxes[11, 3] = np.array([50, 60, 49, 90], np.float32)        # zero width
+    kw = dict(thres=0.2, max_tracks=6, link_thres=0.45, max_frames=7 if case == "max_frames" else 0)
+    tb, ts = torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda()
+    res = []
+    for fill in ("0", "1024"):
+        os.environ["VDET_LINK_FILL"] = fill
+        try:
+            cx = _lib.Context(torch.cuda.current_device())
+        finally:
+            del os.environ["VDET_LINK_FILL"]
+        try:
+            res.append(ops.track_volume(tb, ts, ctx=cx, **kw))
+        except ZeroDivisionError:
+            res.append(None)
+        cx.close()
+    assert (res[0] is None) == (res[1] is None)
+    if res[0] is not None:
+        for a, b in zip(*res):
+            assert torch.equal(a.nan_to_num(-7.0), b.nan_to_num(-7.0))

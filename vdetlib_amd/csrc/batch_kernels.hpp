@@ -91,6 +91,17 @@ __global__ __launch_bounds__(256) void batch_warm_anchors_kernel(const BatchTrac
     track_warm_anchors_body(blockIdx.x, w.keys, w.lists, w.cnt, w.F, bt.B, bt.C, w.scores, bt.thres, bt.wm, w.warm, BucketLists{nullptr, nullptr});
 }
 
+// grid (ceil(Fmax * B / 256), 2, V): the whole link table of every video (link_fill_node)
+__global__ __launch_bounds__(256) void batch_link_fill_kernel(const BatchTrack bt)
+{
+    const VidView w = vid_view(bt, blockIdx.z);
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= (int64_t)w.F * bt.B) return;
+    const int f = (int)(n / bt.B);
+    link_fill_node(f, (int)(n - (int64_t)f * bt.B), blockIdx.y == 0 ? 1 : -1, w.boxes, w.F, bt.B, bt.link_t32, w.group_flags, w.ix,
+                   bt.link_thres, w.memo);
+}
+
 // grid (C * wm, 2, V); MODE 1: memo warm-up, MODE 2: materialise the warm chains
 template <int LT, int MODE>
 __global__ __launch_bounds__(LT, (MODE == 1 && LT == 256) ? 5 : 1) void batch_link_kernel(const BatchTrack bt)

@@ -62,6 +62,7 @@ struct BucketParams {
     uint16_t *order;               // [P, B] exact head of every list (tracking), or null
     int32_t *fail_list;            // [P]
     int *nfail;
+    int dbg;                       // VDET_BK_DBG (timing experiments only; results invalid): 1 no exact-order phase, 2 no copy-out, 4 stop after the scan, 8 stop after the load
 };
 
 template <bool FLOATS>
@@ -181,6 +182,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 && KPT <= 10) ? 8 : 4) void b
         }
         pn += stride;
         request(pn);                                      // in flight while this list is cut
+        if (prm.dbg & 8) { if (ik[0] == 0x12345u) prm.ncand[p] = 1; continue; }
         if (N == 0) {                                     // (block-uniform) irregular frame / size: the LSD kernel sorts this list
             if (tid == 0) { prm.nsb[p] = -1; prm.fail_list[atomicAdd(prm.nfail, 1)] = p; }
             continue;
@@ -238,6 +240,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 && KPT <= 10) ? 8 : 4) void b
             if (tid == BLOCK - 1) hist[kHistW] = run | (run << 16);   // cum[last + 1] = ncand
         }
         bucket_lds_barrier();
+        if (prm.dbg & 4) { if (tid == 0) prm.ncand[p] = ncand; continue; }
         // rank estimate -> bucket, slot inside the bucket
         uint32_t br[KPT];
 #pragma unroll
@@ -306,7 +309,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 && KPT <= 10) ? 8 : 4) void b
                 }
             }
         bucket_lds_barrier();
-        const int nw = (int)nwork;
+        const int nw = (prm.dbg & 1) ? 0 : (int)nwork;
         if (nw > kBkWorkMax) {                            // (block-uniform; does not happen with buckets of ~8)
             if (tid == 0) { prm.nsb[p] = -1; prm.fail_list[atomicAdd(prm.nfail, 1)] = p; }
             bucket_lds_barrier();
@@ -370,7 +373,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 && KPT <= 10) ? 8 : 4) void b
             prm.nsb[p] = (int)(bcnt[nhead] & kBkStartMask);
         }
         bucket_lds_barrier();
-        {
+        if (!(prm.dbg & 2)) {
             uint32_t *out = prm.ent + (int64_t)p * prm.B;
             if ((((int64_t)p * prm.B) & 3) == 0) {
                 const int nv = ncand >> 2;

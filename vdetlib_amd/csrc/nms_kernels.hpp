@@ -1353,6 +1353,7 @@ struct WalkParams {
     const int32_t *nsb;       // [P] < 0: this list is a sorted `order` row after all (LSD fallback)
     const uint32_t *bk_raw;   // [P,B] what the buckets were cut from: sortable keys, or float32 scores (bk_floats)
     int bk_floats;
+    int dbg;                  // VDET_WALK_DBG (timing experiments only; results invalid): 1 no ranking of the alive lanes, 2 no equal-key check
 };
 
 // LDS words through which the lanes of one wave talk to each other (the walks' dead masks): every
@@ -1661,7 +1662,9 @@ __device__ __forceinline__ void walk_list_bucketed(const WalkParams &prm, lds_ma
         const int na = __popcll(am);
         if (na) {                                                 // (scalar branch)
             uint32_t rank = 0u, key = 0u;
-            if (na > 1) {
+            if (prm.dbg & 1) {
+                rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));
+            } else if (na > 1) {
                 // rank key: buckets of a chunk in lane order, entries of a bucket by ord
                 const unsigned long long fm = __ballot(valid && (e & kBkFlag) != 0u);
                 const uint32_t bid = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u)) +
@@ -1684,7 +1687,7 @@ __device__ __forceinline__ void walk_list_bucketed(const WalkParams &prm, lds_ma
                 lds_f4v bv; bv.x = b_cur.x; bv.y = b_cur.y; bv.z = b_cur.z; bv.w = b_cur.w;
                 ringb[2 * s + 1] = bv;
             }
-            if (na > 1) {
+            if (na > 1 && !(prm.dbg & 3)) {
                 // equal keys share a slot: does the slot hold what this lane wrote?  (the wave's LDS queue is in order)
                 const bool clash = alive && ring[8 * ring_wrap(slot0 + (int)rank)] != (uint32_t)c;
                 const unsigned long long cm = __ballot(clash);

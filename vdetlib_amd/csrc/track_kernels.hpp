@@ -929,6 +929,76 @@ __global__ __launch_bounds__(1024) void warm_order_kernel(const int32_t *__restr
 }
 
 // ------------------------------------------------------------------------------------------------
+// The WHOLE link table at once (round 4), for frames of up to a few hundred proposals (VID shape): one thread per node
+// (frame, proposal) and direction evaluates next(f, j, dir) -- the same window scan, screen and arg-max rule as an
+// unknown step of track_link_memo_body, serially over the node's window (tens of candidates) -- and writes the memo
+// word.  ~2 F B windows per video: microseconds of chip-filling work, after which EVERY chain of the video is pointer
+// chasing (0.38 us per step) whatever its anchor is -- no anchor prediction, no warm-up launch, no serial window scans
+// inside the tracking loop (on coherent videos the warm-up predicted one chain per class and the loop scanned the rest).
+// The values are the ones a scan would publish, so the memo-driven kernels are unchanged.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void link_fill_node(const int f, const int j, const int dir, const float4 *__restrict__ boxes, int F, int B,
+                                               float link_t32, const uint32_t *__restrict__ group_flags, const FrameIndex &ix,
+                                               double link_thres, unsigned long long *memo)
+{
+    const int f2 = f + dir;
+    if (f2 < 0 || f2 >= F) return;                    // (a chain stops at the video's border before it asks)
+    const float4 cur = trunc4(boxes[(int64_t)f * B + j]);
+    const float carea = box_area(cur);
+    const uint32_t fflags = group_flags ? group_flags[f2] : 0u;
+    const bool fast = ix.xbox && (fflags & kFlagRegular) && link_t32 > 1e-30f && carea > 0.0f && carea < __uint_as_float(0x7F800000u);
+    float bv = -1.0f;
+    int bi = -1;
+    if (fast) {
+        const float omt = (float)(1.0 - link_thres) * 1.002f + 1.0e-6f;
+        const float inv_t = (float)(1.002 / fmax(link_thres, 1.0e-6));
+        const float t32e = link_t32 * 4.76837158203125e-7f;
+        const float xmin = ix.info[f2 * 4], scale = ix.info[f2 * 4 + 1], wmax = ix.info[f2 * 4 + 2];
+        const float wc = (cur.z - cur.x) + 1.0f;
+        const float lo = cur.x - omt * fminf(wmax, wc * inv_t) - 2.0f;
+        const float hi = cur.x + omt * wc + 2.0f;
+        const uint32_t *cum = ix.cum + (int64_t)f2 * 257;
+        const int r0 = (int)cum[xbucket(fmaxf(lo, -3.0e38f), xmin, scale)];
+        const int r1 = (int)cum[xbucket(fminf(hi, 3.0e38f), xmin, scale) + 1];
+        const float4 *xb = ix.xbox + (int64_t)f2 * B;
+        const uint16_t *xo = ix.xord + (int64_t)f2 * B;
+        for (int r = r0; r < r1; ++r) {
+            const float4 x = xb[r];
+            bool border;
+            const bool pass = pred_regular(cur, carea, x, box_area(x), link_t32, t32e, border);
+            if (pass || border) {
+                const float v = link_iou(cur, carea, x);
+                const int b = (int)xo[r];
+                if (v >= link_t32 && (v > bv || (v == bv && b < bi))) { bv = v; bi = b; }
+            }
+        }
+    } else {
+        // irregular frame / no index / degenerate current box: the plain arg-max (NaN never wins, lowest index on ties)
+        const float4 *fb = boxes + (int64_t)f2 * B;
+        for (int b = 0; b < B; ++b) {
+            const float v = link_iou(cur, carea, fb[b]);
+            if (v > bv) { bv = v; bi = b; }
+        }
+    }
+    const bool linked = bi >= 0 && bv >= link_t32;
+    unsigned long long *mm = memo + (int64_t)(dir > 0 ? 0 : 1) * F * B;
+    __hip_atomic_store(&mm[(int64_t)f * B + j],
+                       kMemoValid | ((unsigned long long)(linked ? bi + 1 : 0) << 32) | (linked ? __float_as_uint(bv) : 0u),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// grid (ceil(F * B / 256), 2)
+__global__ __launch_bounds__(256) void link_fill_kernel(const float4 *__restrict__ boxes, int F, int B, float link_t32,
+                                                        const uint32_t *__restrict__ group_flags, const FrameIndex ix, double link_thres,
+                                                        unsigned long long *memo)
+{
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= (int64_t)F * B) return;
+    const int f = (int)(n / B);
+    link_fill_node(f, (int)(n - (int64_t)f * B), blockIdx.y == 0 ? 1 : -1, boxes, F, B, link_t32, group_flags, ix, link_thres, memo);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Likely anchors of a class, for warming the link memo: the best `m` detections of the class in the
 // global order of vdet/track.py:200 (score descending, flat index ascending) that score >= thres --
 // taken from the first two entries of every (frame, class) sorted list.  The tracking loop's real

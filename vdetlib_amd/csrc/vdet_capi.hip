@@ -160,10 +160,12 @@ struct vdet_ctx {
     std::vector<VidDesc> h_vids;
     DevBuf segtab;                // batched videos: per-frame {first, one past last} frame of its video
     std::vector<int2> h_seg;
+    std::vector<int64_t> h_seg_off;   // the offsets h_seg / segtab were built from
     DevBuf sortctl;               // binsort_kernel's work counter + the list of problems it handed to the LSD kernel
     // round 4: per-(frame, class) lists cut into score-ordered buckets instead of sorted (bucket_kernels.hpp)
     int bucket_mode = 1;          // VDET_BUCKETS=0: always the LSD sort; 1 (default): volumes of more than 1024 boxes per frame whose
                                   // regular frames take the packed walk; 2: every volume the kernel can take (tests)
+    int bk_dbg = 0, walk_dbg = 0; // VDET_BK_DBG / VDET_WALK_DBG: timing experiments (results invalid)
     int bucket_block = 512;       // VDET_BUCKET_BLOCK=1024: 1 024 threads x 10 keys per list at B <= 10 240 (A-B knob)
     bool lists_bucketed = false;  // the context's lists (c->order / c->ncand) are bucketed: c->ent / c->bst / c->nsb describe them
     bool last_sort_bucketed = false;   // the last per-(frame, class) sort went through bucket_kernel (vdet_query 10 / 11)
@@ -183,6 +185,8 @@ struct vdet_ctx {
     bool link_lpt = true;         // VDET_LINK_LPT=0: the warm-up's chains in launch order instead of longest first (A-B knob)
     bool link_u16 = true;         // VDET_LINK_U16=0: the LINK window scans read the float4 index on every frame (A-B knob)
     int link_maxb = 8;            // VDET_LINK_MAXB=8|16: boxes per thread and batch in the warm-up's window scans (A-B knob)
+    int link_fill = 1024;         // VDET_LINK_FILL=b: frames of up to b proposals get their WHOLE link table computed up front (link_fill_kernel:
+                                  // every chain is pointer chasing afterwards, no anchor prediction, no warm-up scans); 0: never (A-B knob / tests)
     int link_warm = -1;           // VDET_LINK_WARM=m: chains warmed per class (-1: max_tracks + 2; 0: none)
     DevBuf linkmemo, linkstats, linkwarm, linkorder, linkchains, linknodes, tracknode, rtodo;
     // which proposal every row of the last tracking call's tracks is (written by the link kernels; vdet_rescore_tracks
@@ -722,6 +726,7 @@ int launch_sort_walk(vdet_ctx *c, const SortWalkArgs &a, int nmax, int64_t order
             bp.order = a.want_heads ? sp.order : nullptr;
             bp.fail_list = reinterpret_cast<int32_t *>(c->sortctl.as<char>() + sizeof(BinSortCtl));
             bp.nfail = &c->sortctl.as<BinSortCtl>()->nfail;
+            bp.dbg = c->bk_dbg;
             c->bk_raw = bp.raw; c->bk_floats = floats ? 1 : 0;
 #define VDET_BKK(BL, KP) (floats ? reinterpret_cast<const void *>(bucket_kernel<BL, KP, true>) : reinterpret_cast<const void *>(bucket_kernel<BL, KP, false>))
             const bool wide = c->bucket_block == 1024 && nmax > 4096 && nmax <= 10240;     // VDET_BUCKET_BLOCK=1024 (A-B knob)
@@ -790,6 +795,7 @@ int launch_sort_walk(vdet_ctx *c, const SortWalkArgs &a, int nmax, int64_t order
     if (c->lists_bucketed && !a.order_in && wp.packed == 1) {
         wp.ent = c->ent.as<uint32_t>(); wp.nsb = c->nsb.as<int32_t>();
         wp.bk_raw = c->bk_raw; wp.bk_floats = c->bk_floats;
+        wp.dbg = c->walk_dbg;
     } else if (c->lists_bucketed && !a.order_in) {
         return fail(c, VDET_EHIP, "internal: bucketed lists without the packed walk");
     }
@@ -961,7 +967,10 @@ int vdet_create(vdet_ctx **out, int device)
     if (const char *e = getenv("VDET_LINK_MEMO")) c->link_memo = atoi(e) != 0;
     if (const char *e = getenv("VDET_BINSORT")) c->binsort = atoi(e) != 0;
     if (const char *e = getenv("VDET_BUCKETS")) c->bucket_mode = atoi(e);
+    if (const char *e = getenv("VDET_LINK_FILL")) c->link_fill = atoi(e);
     if (const char *e = getenv("VDET_BUCKET_BLOCK")) c->bucket_block = atoi(e);
+    if (const char *e = getenv("VDET_BK_DBG")) c->bk_dbg = atoi(e);
+    if (const char *e = getenv("VDET_WALK_DBG")) c->walk_dbg = atoi(e);
     if (const char *e = getenv("VDET_TRACK_LOOP")) c->track_loop = atoi(e) != 0;
     if (const char *e = getenv("VDET_LINK_WARM")) c->link_warm = atoi(e);
     if (const char *e = getenv("VDET_LINK_MAXB")) c->link_maxb = atoi(e) == 16 ? 16 : 8;
@@ -1606,6 +1615,14 @@ int vdet_nms_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scor
         }
         HIPCHK(c, hipMemsetAsync(c->linkmemo.p, 0, (size_t)2 * F * B * 8, ws));
         HIPCHK(c, hipMemsetAsync(c->linkstats.p, 0, 16, ws));
+        // small frames: the whole link table up front (every node's window scan, chip-filling) -- then no step of any chain
+        // is ever scanned again, whatever the anchors turn out to be
+        const bool filled = c->link_fill > 0 && B <= c->link_fill && w_ix.xbox != nullptr && max_tracks > 0;
+        if (filled) {
+            StageTimer tm(c, ST_TLINK);
+            hipLaunchKernelGGL(link_fill_kernel, dim3((unsigned)((F * B + 255) / 256), 2), dim3(256), 0, ws, reinterpret_cast<const float4 *>(d_boxes),
+                               (int)F, (int)B, link_t32, w_flags, w_ix, link_thres, c->linkmemo.as<unsigned long long>());
+        }
         if (wm > 0 && max_tracks > 0) {
             HIPCHK(c, c->linkwarm.reserve((size_t)C * wm * 4));
             StageTimer tm(c, ST_TLINK);
@@ -1613,7 +1630,7 @@ int vdet_nms_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scor
                                c->order.as<uint16_t>(), c->ncand.as<int32_t>(), (int)F, (int)B, (int)C, d_scores, thres, wm,
                                c->linkwarm.as<int32_t>(), bkl);
             const int32_t *w_order = nullptr;
-            if (c->link_lpt) {       // longest chains first
+            if (c->link_lpt && !filled) {       // longest chains first
                 HIPCHK(c, c->linkorder.reserve((size_t)C * wm * 2 * 4));
                 hipLaunchKernelGGL(warm_order_kernel, dim3(1), dim3(1024), 0, ws, c->linkwarm.as<int32_t>(), (int)(C * wm), (int)F, (int)B,
                                    reach, c->linkorder.as<int32_t>());
@@ -1624,7 +1641,8 @@ int vdet_nms_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scor
                                (const TrackState *)nullptr, (float *)nullptr, w_flags, w_ix, link_thres, \
                                c->linkmemo.as<unsigned long long>(), c->linkstats.as<unsigned int>(), c->linkwarm.as<int32_t>(), \
                                (int32_t *)nullptr, w_order)
-            if (c->link_maxb == 16) VDET_WARM(16); else VDET_WARM(8);
+            if (filled) {}                   // (every step is known already)
+            else if (c->link_maxb == 16) VDET_WARM(16); else VDET_WARM(8);
 #undef VDET_WARM
             if (c->link_materialize) {
                 // every step of the warm chains is known now: write each predicted anchor's tubelet ONCE (one wave walks
@@ -1782,6 +1800,8 @@ int vdet_video_batch(vdet_ctx *c, const float *d_boxes, const float *d_scores, c
     }
     const int64_t F = h_frame_off[V];
     if (F * C > 0x7FFFFFF0ll || F * B > 0x7FFFFFF0ll || V * C > 0x7FFFFFF0ll) return fail(c, VDET_EINVAL, "volume too large");
+    if (want_rescore && max_tracks > 0 && Fmax > kSeriesWaveMaxF)      // (checked before anything is enqueued; only the re-scoring's series kernel has the limit)
+        return fail(c, VDET_EINVAL, "a video of %lld frames: the batched call re-scores at most %d per video", (long long)Fmax, kSeriesWaveMaxF);
     HIPCHK(c, hipSetDevice(c->device));
     timing_reset(c);
     const float t32 = thresh_to_f32(nms_thres);
@@ -1842,12 +1862,20 @@ int vdet_video_batch(vdet_ctx *c, const float *d_boxes, const float *d_scores, c
     const bool need_suppress = c->no_lazy || !g_flags || !c->all_regular;
     const int mask_words = (int)((((size_t)4 * ((B + 31) / 32) + 15) & ~(size_t)15) / 4);
     // ---- all videos side by side: one launch per stage, the video is a grid dimension (batch_kernels.hpp)
-    if (Fmax > kSeriesWaveMaxF) return fail(c, VDET_EINVAL, "a video of %lld frames: the batched call takes at most %d per video", (long long)Fmax, kSeriesWaveMaxF);
-    (void)host_sync(c);      // (an earlier copy from the host table may be in flight)
-    c->h_vids.resize((size_t)V);
-    for (int64_t v = 0; v < V; ++v) c->h_vids[(size_t)v] = VidDesc{(int32_t)h_frame_off[v], (int32_t)(h_frame_off[v + 1] - h_frame_off[v])};
-    HIPCHK(c, c->vidtab.reserve((size_t)V * sizeof(VidDesc)));
-    HIPCHK(c, hipMemcpyAsync(c->vidtab.p, c->h_vids.data(), (size_t)V * sizeof(VidDesc), hipMemcpyHostToDevice, c->stream));
+    {
+        // the {first frame, frames} table: uploaded only when it differs from the resident one (the host copy must not be
+        // rewritten under a copy in flight, so a change waits for the stream once; the same offsets again cost nothing)
+        bool same_tab = c->vidtab.p != nullptr && c->h_vids.size() == (size_t)V;
+        for (int64_t v = 0; same_tab && v < V; ++v)
+            same_tab = c->h_vids[(size_t)v].f0 == (int32_t)h_frame_off[v] && c->h_vids[(size_t)v].F == (int32_t)(h_frame_off[v + 1] - h_frame_off[v]);
+        if (!same_tab) {
+            (void)host_sync(c);
+            c->h_vids.resize((size_t)V);
+            for (int64_t v = 0; v < V; ++v) c->h_vids[(size_t)v] = VidDesc{(int32_t)h_frame_off[v], (int32_t)(h_frame_off[v + 1] - h_frame_off[v])};
+            HIPCHK(c, c->vidtab.reserve((size_t)V * sizeof(VidDesc)));
+            HIPCHK(c, hipMemcpyAsync(c->vidtab.p, c->h_vids.data(), (size_t)V * sizeof(VidDesc), hipMemcpyHostToDevice, c->stream));
+        }
+    }
     BatchTrack bt{};
     bt.vids = c->vidtab.as<VidDesc>();
     bt.Ftot = (int)F; bt.B = (int)B; bt.C = (int)C; bt.T = T; bt.wm = wm;
@@ -1871,7 +1899,10 @@ int vdet_video_batch(vdet_ctx *c, const float *d_boxes, const float *d_scores, c
     {
         StageTimer tm(c, ST_TLINK);
         hipLaunchKernelGGL(batch_warm_anchors_kernel, dim3((unsigned)C, (unsigned)V), dim3(256), 0, c->stream, bt);
-        hipLaunchKernelGGL((batch_link_kernel<256, 1>), dim3((unsigned)(C * wm), 2, (unsigned)V), dim3(256), 0, c->stream, bt);
+        if (c->link_fill > 0 && B <= c->link_fill && have_ix)       // the whole link table of every video: no chain ever scans
+            hipLaunchKernelGGL(batch_link_fill_kernel, dim3((unsigned)((Fmax * B + 255) / 256), 2, (unsigned)V), dim3(256), 0, c->stream, bt);
+        else
+            hipLaunchKernelGGL((batch_link_kernel<256, 1>), dim3((unsigned)(C * wm), 2, (unsigned)V), dim3(256), 0, c->stream, bt);
         hipLaunchKernelGGL((batch_link_kernel<64, 2>), dim3((unsigned)(C * wm), 2, (unsigned)V), dim3(64), 0, c->stream, bt);
     }
     {
@@ -2320,13 +2351,16 @@ static int upload_segments(vdet_ctx *c, const int64_t *h_frame_off, int64_t V, i
         if (h_frame_off[v + 1] < h_frame_off[v]) return fail(c, VDET_EINVAL, "frame offsets must not decrease");
     const int64_t F = h_frame_off[V];
     if (F > 0x7FFFFFF0ll) return fail(c, VDET_EINVAL, "too many frames");
+    *Ftot = F;
+    // the per-frame {first, one past last} table: rebuilt and uploaded only when the offsets differ from the resident ones
+    if (c->segtab.p && c->h_seg_off.size() == (size_t)V + 1 && std::equal(c->h_seg_off.begin(), c->h_seg_off.end(), h_frame_off)) return VDET_OK;
     (void)host_sync(c);      // (an earlier copy from the host table may be in flight)
+    c->h_seg_off.assign(h_frame_off, h_frame_off + V + 1);
     c->h_seg.resize((size_t)std::max<int64_t>(F, 1));
     for (int64_t v = 0; v < V; ++v)
         for (int64_t f = h_frame_off[v]; f < h_frame_off[v + 1]; ++f) c->h_seg[(size_t)f] = make_int2((int)h_frame_off[v], (int)h_frame_off[v + 1]);
     HIPCHK(c, c->segtab.reserve(c->h_seg.size() * sizeof(int2)));
     if (F) HIPCHK(c, hipMemcpyAsync(c->segtab.p, c->h_seg.data(), (size_t)F * sizeof(int2), hipMemcpyHostToDevice, c->stream));
-    *Ftot = F;
     return VDET_OK;
 }
 
