@@ -29,6 +29,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK = 8.0e12          # B/s, MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md)
+METRIC = "boxes/sec whole-node (NMS+temporal-conv+link), 300f\u00d710k-box synth; mAP parity"   # BASELINE.json
 
 
 def synth_video_cuda(torch, seed, F, B, C, device, kind="rand"):
@@ -71,6 +72,174 @@ def synth_vid_batch(torch, dev, V=64, B=300, C=30, seed=777):
     scores = torch.where(padm[..., None], torch.full_like(scores, float("-inf")), scores).contiguous()
     return boxes, scores, off
 
+
+
+def kept_dets_to_det_proto(video_name, kept_idx, kept_cnt, boxes, scores, class_names, topk):
+    """One video's gathered NMS results -> a det_proto (utils/protocol.py:307-320 dict layout): a detection per kept
+    (frame, box) with the scores of the classes it was kept for.  kept_idx [F,C,topk] / kept_cnt [F,C] numpy, boxes
+    [F,B,4] / scores [F,B,C] numpy (the box protos a host has anyway)."""
+    import hashlib
+    dets = {}
+    F, C = kept_cnt.shape
+    for f in range(F):
+        for c in range(C):
+            for b in kept_idx[f, c, :min(int(kept_cnt[f, c]), topk)].tolist():
+                d = dets.get((f, b))
+                if d is None:
+                    bb = [int(v) for v in boxes[f, b]]
+                    d = dets[(f, b)] = {"frame": f + 1, "bbox": bb, "scores": [],
+                                        "hash": hashlib.md5('{}_{}_{}_{}_{}_{}'.format(video_name, f + 1, *bb).encode()).hexdigest()}
+                d["scores"].append({"class": class_names[c], "class_index": c + 1, "score": float(scores[f, b, c])})
+    return {"video": video_name, "detections": [dets[k] for k in sorted(dets)]}
+
+
+def run_sharded(args):
+    """BASELINE configs[3]: `--videos` videos sharded over the ranks (LPT by frames x boxes), `--streams` of them in flight
+    per rank, and ONE exchange step per pass: ragged RCCL all-gathers of every video's results (tubelets with their
+    re-scored boxes and pooled scores, the top-k kept detections per (frame, class) + counts).  A "step" = one pass over
+    all the videos.  Rank 0 turns one gathered video into det_proto / track_proto dicts."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from vdetlib_amd import ops, _lib, dist as vdist
+    world, rank, local = vdist.env_world()
+    one_gpu = os.environ.get("VDET_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local = 0
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    force_x = args.force_exchange
+    vdist.init(backend=("gloo" if one_gpu else "nccl") if (world > 1 or force_x) else None, device=dev, force=force_x)
+    V, B, C, T, TOPK = args.videos, args.boxes, args.classes, args.max_tracks, min(100, args.cap)
+    TAPS = [0.25, 0.5, 0.25]
+    rs = np.random.RandomState(3000)
+    frames = [max(3, int(round(args.frames * (0.75 + 0.5 * u)))) for u in rs.rand(V)]      # videos differ in length
+    owned = vdist.shard_lpt([f * B for f in frames], world)
+    mine = owned[rank]
+    vids = {v: synth_video_cuda(torch, 3000 + v, frames[v], B, C, dev, args.scores) for v in mine}
+    nstreams = max(1, min(args.streams, max(len(mine), 1)))
+    ctxs = [_lib.Context(local) for _ in range(nstreams)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
+    for cx in ctxs:
+        cx.set_cache(True); cx.set_async(True)
+
+    def process(v, k):
+        vb, vs = vids[v]
+        cx = ctxs[k]
+        with torch.cuda.stream(streams[k]):
+            cx.invalidate()
+            pooled, conv = ops.volume_pass(vs, args.window, TAPS, ctx=cx)
+            ki, kc, tr, an, nt = ops.nms_track_volume(vb, vs, nms_thres=args.thresh, thres=args.track_thres, max_tracks=T,
+                                                      link_thres=args.link_thres, cap=args.cap, sync=False, ctx=cx, pad=False)
+            det, tp, tb = ops.rescore_tracks(tr, nt, vb, vs, overlap_thres=args.pool_thres, window=args.window, sync=False, ctx=cx)
+            Fv = frames[v]
+            # the video's result records: tubelet rows (x1 y1 x2 y2 link-score | re-scored box | pooled score) and the top-k kept
+            tub = torch.cat([tr.reshape(C * T * Fv, 5), tb.reshape(C * T * Fv, 4), tp.to(torch.float32).reshape(C * T * Fv, 1)], 1)
+            kept = ki[:, :, :TOPK].reshape(Fv * C, TOPK)
+            return {"v": v, "tub": tub, "anchors": an.reshape(C * T, 3), "ntracks": nt, "kept": kept, "kcnt": kc.reshape(Fv * C)}
+
+    exch_ms = []
+
+    def one_pass(exchange=True):
+        res = [process(v, i % nstreams) for i, v in enumerate(mine)]
+        for s_ in streams:
+            torch.cuda.current_stream().wait_stream(s_)
+        out = None
+        if exchange and (world > 1 or force_x):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            cat = (lambda key, shape: torch.cat([r[key] for r in res], 0) if res else torch.zeros(shape, device=dev))
+            meta = torch.tensor([[r["v"], frames[r["v"]]] for r in res], dtype=torch.int64, device=dev).reshape(-1, 2)
+            out = {"meta": vdist.all_gather_ragged(meta, force=force_x),
+                   "tub": vdist.all_gather_ragged(cat("tub", (0, 10)), force=force_x),
+                   "anchors": vdist.all_gather_ragged(cat("anchors", (0, 3)), force=force_x),
+                   "ntracks": vdist.all_gather_ragged(cat("ntracks", (0,)).to(torch.int32), force=force_x),
+                   "kept": vdist.all_gather_ragged(cat("kept", (0, TOPK)), force=force_x),
+                   "kcnt": vdist.all_gather_ragged(cat("kcnt", (0,)), force=force_x)}
+            e1.record()
+            exch_ms.append((e0, e1))
+            out["bytes"] = sum(r[k].numel() * r[k].element_size() for r in res for k in ("tub", "anchors", "ntracks", "kept", "kcnt"))
+        return res, out
+
+    def fence():
+        if world > 1 or force_x:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 2)):
+        one_pass()
+        for cx in ctxs:
+            try:
+                cx.sync()
+            except _lib.RetryError:
+                pass
+    fence()
+    del exch_ms[:]
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res, gathered = one_pass()
+    fence()
+    dt = time.perf_counter() - t0
+    for cx in ctxs:
+        cx.sync()
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if one_gpu else dev)
+    by_rank = [dt]
+    if world > 1:
+        allt = torch.empty(world, dtype=torch.float64, device=tmax.device)
+        dist.all_gather_into_tensor(allt, tmax)
+        by_rank = [float(x) for x in allt.tolist()]
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    total_boxes = sum(frames) * B
+    result = None
+    if rank == 0:
+        xinfo, protos = None, None
+        if gathered is not None:
+            xms = [a.elapsed_time(b) for a, b in exch_ms]
+            got = sorted(int(m[0]) for part in gathered["meta"] for m in part.tolist())
+            xinfo = {"exchange_ms": sum(xms) / len(xms), "exchange_ms_max": max(xms), "payload_bytes_per_rank": gathered["bytes"],
+                     "backend": dist.get_backend(), "world": dist.get_world_size(), "videos_gathered": len(got),
+                     "all_videos_present": got == list(range(V))}
+            # one video of the LAST rank's shard -> protocol dicts on rank 0 (boxes / scores of a remote video: regenerated
+            # from its seed here; a deployment has the box protos on the host)
+            r_ = len(gathered["meta"]) - 1
+            while r_ > 0 and gathered["meta"][r_].shape[0] == 0:
+                r_ -= 1
+            metas = gathered["meta"][r_].tolist()
+            v, Fv = int(metas[0][0]), int(metas[0][1])
+            tub = gathered["tub"][r_][:C * T * Fv].reshape(C, T, Fv, 10)
+            anc = gathered["anchors"][r_][:C * T].reshape(C, T, 3)
+            ntr = gathered["ntracks"][r_][:C]
+            kept = gathered["kept"][r_][:Fv * C].reshape(Fv, C, TOPK).cpu().numpy()
+            kcnt = gathered["kcnt"][r_][:Fv * C].reshape(Fv, C).cpu().numpy()
+            c_best = int(torch.argmax(ntr).item())
+            tp = ops.tracks_to_proto("synth_%d" % v, tub[c_best, :, :, :5].contiguous(), anc[c_best], int(ntr[c_best]))
+            hb, hs = [t.cpu().numpy() for t in (vids[v] if v in vids else synth_video_cuda(torch, 3000 + v, Fv, B, C, dev, args.scores))]
+            dp = kept_dets_to_det_proto("synth_%d" % v, kept[:min(Fv, 3)], kcnt[:min(Fv, 3)], hb, hs, ["c%d" % (c + 1) for c in range(C)], TOPK)
+            protos = {"video": v, "from_rank": r_, "track_proto_class": c_best + 1, "tracks": len(tp["tracks"]),
+                      "track_boxes": sum(len(t) for t in tp["tracks"]), "det_proto_frames": min(Fv, 3), "detections": len(dp["detections"])}
+        bpb = 16 * C + 16
+        result = {
+            "metric": METRIC, "value": total_boxes * args.steps / dt, "unit": "boxes/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[3]: %d videos (%d..%d frames x %d boxes x %d classes) sharded over %d rank(s) by LPT, %d in flight per "
+                                   "rank; per video NMS + temporal pass + %d tubelets/class + re-scoring; one ragged all-gather of all results "
+                                   "per pass (a step = one pass over all videos)" % (V, min(frames), max(frames), B, C, world, nstreams, T),
+                       "videos": V, "frames": frames, "boxes": B, "classes": C, "shards": owned, "parallelism": "video-sharded x%d" % world},
+            "exchange": xinfo, "protocol_dicts": protos,
+            "per_rank": {"seconds": by_rank, "boxes": [sum(frames[v] for v in o) * B for o in owned],
+                         "hbm_frac_algorithmic": [sum(frames[v] for v in o) * B * args.steps / max(t, 1e-9) * bpb / HBM_PEAK for o, t in zip(owned, by_rank)]},
+            "roofline": {"bound": "hbm", "kernel": "whole path", "achieved": total_boxes * args.steps / dt * bpb / 1e9, "peak": world * HBM_PEAK / 1e9,
+                         "unit": "GB/s", "frac": total_boxes * args.steps / dt * bpb / (world * HBM_PEAK), "traffic": None,
+                         "algorithmic_bytes_per_box": bpb},
+            "cpu_baseline": None,
+        }
+    if world > 1 or force_x:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
 
 def vid_shape_leg(torch, ops, _lib, dev, taps, V=64, B=300, C=30, T=4):
     """64 VID-shaped synthetic videos (400-600 frames, 200-300 proposals per frame padded to 300 with far-away boxes and
@@ -173,6 +342,9 @@ def main():
                          "previous ones run underneath; none: streams run free")
     ap.add_argument("--max-frames", type=int, default=0, help="(ablation) tubelet length limit of the tracker (0 = the whole video)")
     ap.add_argument("--no-rescore", action="store_true", help="(ablation) tubelets without the spatial / temporal re-scoring")
+    ap.add_argument("--videos", type=int, default=0, help="configs[3]: this many videos sharded over the ranks (LPT), one ragged exchange per pass; "
+                    "0 (default): the headline step, one video per rank and step")
+    ap.add_argument("--no-coherent", action="store_true", help="skip the coherent-video leg (reported next to value, never part of it)")
     ap.add_argument("--no-upload", action="store_true", help="skip the PCIe-fed pipeline leg (reported next to value, never part of it)")
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the N > 1 exchange step -- process group, RCCL communicator, all-gather of device tensors from "
@@ -180,7 +352,8 @@ def main():
     args = ap.parse_args()
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
         args.no_cpu = True       # the CPU baseline / mAP-parity / PCIe legs are reported at N = 1 only
-    METRIC = "boxes/sec whole-node (NMS+temporal-conv+link), 300f\u00d710k-box synth; mAP parity"   # BASELINE.json
+    if args.videos > 0:          # BASELINE configs[3]: many videos sharded over the ranks
+        return run_sharded(args)
 
     import numpy as np
     import torch
@@ -693,6 +866,55 @@ def main():
             for cx in ctxs:
                 cx.sync()
             value_other = {"scores": other, "value": F * B * no / odt, "ms_per_step": odt / no * 1e3, "steps": no}
+        # A COHERENT video of the same size (what real proposals look like: utils/protocol.py:358-369 box protos of consecutive
+        # frames): every proposal persists from frame to frame with a few pixels of jitter and keeps most of its score, so the
+        # best detections of a class are the same few objects in every frame and the tubelets of a class are DISTINCT chains
+        # through all frames (on independent frames the chains of all classes merge into a few).  Never part of `value`.
+        value_coherent = None
+        if not args.no_coherent:
+            g = torch.Generator(device=dev).manual_seed(977)
+            for vb_, vs_ in vids:
+                base = torch.rand(B, 4, generator=g, device=dev)
+                x1, y1 = base[:, 0] * 1230, base[:, 1] * 670
+                bb = torch.stack([x1, y1, torch.clamp(x1 + 10 + base[:, 2] * 290, max=1279), torch.clamp(y1 + 10 + base[:, 3] * 290, max=719)], -1)
+                vb_.copy_((bb[None] + torch.randint(-3, 4, (F, B, 4), generator=g, device=dev)).round())
+                vb_[..., 2:] = torch.maximum(vb_[..., 2:], vb_[..., :2] + 4)
+                vs_.uniform_(generator=g).mul_(0.2).add_(0.8 * torch.rand(B, C, generator=g, device=dev)[None])
+                del base, bb
+            step_no[0] = 0
+            for _ in range(2 * nstreams):
+                step(exchange=False)
+            for cx in ctxs:
+                try:
+                    cx.sync()
+                except _lib.RetryError:
+                    pass
+            torch.cuda.synchronize()
+            no = max(args.steps // 2, 2 * nstreams)
+            t8 = time.perf_counter()
+            for _ in range(no):
+                step(exchange=False)
+            torch.cuda.synchronize()
+            cdt = time.perf_counter() - t8
+            for cx in ctxs:
+                cx.sync()
+            ctx.set_timing(2)
+            for _ in range(2):
+                step_no[0] = 0
+                step(exchange=False)
+                torch.cuda.synchronize()
+            ctx.sync()
+            cst = {k: round(ms / 2, 3) for k, (ms, n) in ctx.last_timing().items() if n}
+            ctx.set_timing(0)
+            t9 = time.perf_counter()
+            for _ in range(4):
+                step_no[0] = 0
+                step(exchange=False)
+            torch.cuda.synchronize()
+            value_coherent = {"value": F * B * no / cdt, "ms_per_step": cdt / no * 1e3, "steps": no,
+                              "single_video_ms": (time.perf_counter() - t9) / 4 * 1e3, "stage_ms_one_video": cst,
+                              "link_steps_memo_scanned": [ctx.query(4) + ctx.query(6), ctx.query(5) + ctx.query(7)],
+                              "video": "proposals persist over the frames (jitter +-3 px), scores 0.8 * per-proposal + 0.2 * per-frame noise"}
         vid_shape = None
         if not args.no_cpu and world == 1:
             # BASELINE configs[4]'s SHAPE (ILSVRC-VID val: hundreds of frames x <= 300 ragged proposals x 30 classes; the
@@ -739,6 +961,7 @@ def main():
             "single_video_ms": single_video_ms,          # one video at a time (no videos in flight): the latency of one step
             "single_video_latency_mode_ms": single_video_latency_ms,   # ... with VDET_GRAPH_PIPE=1 VDET_AUX_STREAM=1 (not the default)
             "value_other_scores": value_other,           # the same step on the other synthetic score distribution
+            "value_coherent": value_coherent,            # ... on a coherent video (proposals persist from frame to frame)
             "hbm_traffic_per_video": hbm_total,          # sum of the PMC table (profiles/pmc_traffic.json), all kernels of one step
             "vid_shape": vid_shape,
             "lists": lists,

@@ -196,3 +196,26 @@ def test_volume_nms_with_a_recorded_tie_order(oracle):
             want = oracle.nms(d, 0.3, order=rec[f, c])
             n = int(kc[f, c])
             assert n == len(want) and ki[f, c, :n].cpu().numpy().tolist() == want
+
+
+def test_volume_nms_rejects_lists_out_of_range(oracle):
+    """caller-supplied lists are checked before they are walked: a count above B or a box index >= B is a ValueError
+    (VDET_EINVAL), never an out-of-bounds access; the other lists' results are still those of their own walks"""
+    import synth
+    F, B, C = 2, 600, 3
+    boxes, scores = synth.video(37, F, B, C)
+    tb, ts = torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda()
+    order, ncand = ops.argsort_volume(ts)
+    ki, kc = ops.nms_volume_ordered(tb, order, ncand, 0.3)                # sane lists: fine
+    widx, wcnt = oracle.nms_volume(boxes, scores, 0.3)
+    assert np.array_equal(kc.cpu().numpy(), wcnt)
+    bad = order.clone()
+    bad[1, 2, 17] = 20000                                                   # an index >= B (as uint16)
+    with pytest.raises(ValueError):
+        ops.nms_volume_ordered(tb, bad, ncand, 0.3)
+    badn = ncand.clone()
+    badn[0, 1] = B + 5
+    with pytest.raises(ValueError):
+        ops.nms_volume_ordered(tb, order, badn, 0.3)
+    ki2, kc2 = ops.nms_volume_ordered(tb, order, ncand, 0.3)              # the context is usable afterwards
+    assert torch.equal(kc, kc2)

@@ -160,3 +160,40 @@ def test_eight_virtual_ranks_reproduce_the_serial_result():
     loads = [sum(shapes[v][0] * shapes[v][1] for v in o) for o in lpt]
     rr = [sum(shapes[v][0] * shapes[v][1] for v in vd.shard_round_robin(len(vids), r, world)) for r in range(world)]
     assert max(loads) <= max(rr)
+
+
+def _run_sharded(nproc, port, extra, env_extra=None):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **(env_extra or {}))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", "2", "--warmup", "2",
+           "--videos", "5", "--frames", "10", "--boxes", "1500", "--classes", "6", "--max-tracks", "3", "--streams", "2", "--cap", "512",
+           "--no-cpu"] + extra
+    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_sharded_videos_world_of_one_rccl():
+    """bench.py --videos (BASELINE configs[3] as written: LPT shard, videos in flight, ONE ragged exchange of all results per
+    pass, one gathered video turned into protocol dicts on rank 0) over RCCL in a world of one rank"""
+    r = _run_sharded(1, 29551, ["--force-exchange"])
+    assert r["n_gpus"] == 1 and r["config"]["videos"] == 5 and r["config"]["shards"] == [[0, 1, 2, 3, 4]]
+    x = r["exchange"]
+    assert x["backend"] == "nccl" and x["world"] == 1 and x["all_videos_present"] is True and x["payload_bytes_per_rank"] > 0
+    assert r["protocol_dicts"]["tracks"] > 0 and r["protocol_dicts"]["detections"] > 0
+    assert abs(r["value"] - sum(r["config"]["frames"]) * 1500 * 2 / (r["ms_per_step"] * 2e-3)) / r["value"] < 1e-6
+    assert 0 < r["roofline"]["frac"] < 1 and len(r["per_rank"]["hbm_frac_algorithmic"]) == 1
+
+
+def test_sharded_videos_two_ranks_dry_run():
+    """the same with two ranks on one GPU (gloo): every video is processed by exactly one rank (LPT), all of them arrive"""
+    r = _run_sharded(2, 29553, [], {"VDET_BENCH_ONE_GPU": "1"})
+    sh = r["config"]["shards"]
+    assert r["n_gpus"] == 2 and sorted(sh[0] + sh[1]) == [0, 1, 2, 3, 4] and sh[0] and sh[1]
+    fr = r["config"]["frames"]
+    assert abs(sum(fr[v] for v in sh[0]) - sum(fr[v] for v in sh[1])) <= max(fr)            # LPT balances the frames
+    assert r["exchange"]["world"] == 2 and r["exchange"]["all_videos_present"] is True
+    assert r["protocol_dicts"]["from_rank"] == 1 and r["protocol_dicts"]["tracks"] > 0
+    assert len(r["per_rank"]["seconds"]) == 2 and r["scaling"] == "strong"

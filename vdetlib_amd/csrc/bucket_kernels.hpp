@@ -14,7 +14,7 @@
 //      monotone in the key; bucket = fine >> 16 (8 estimated ranks each, so a bucket holds ~8 keys whatever the score
 //      distribution is -- the map is exact at every bin border and linear over 1/16 octave in between), ord = fine & 0xFFFF;
 //   4. one returning LDS atomic per key on its bucket's counter = arrival slot inside the bucket; scan of the
-//      <= 2 048 bucket counters; entries {ord : 16 | first-of-bucket : 1 | 0x3FFF ^ index : 14} staged in LDS;
+//      <= 2 048 bucket counters; entries {ord : 16 | 0x3FFF ^ index : 14 | first-of-bucket : 1} staged in LDS;
 //   5. a bucket that straddles a 64-entry chunk border (one per chunk) is put in exact order by one wave (rank by lane
 //      broadcasts) and all its entries are flagged, i.e. become buckets of their own: the consumer reads the list in
 //      aligned chunks of 64 and every chunk holds whole buckets only.  Coalesced copy-out.
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 && KPT <= 10) ? 8 : 4) void b
                 const uint32_t fine = (c0 << 13) + (__umul24(m, c1 - c0) >> 5);      // m < 2^18, count <= 2^14: the product fits
                 const uint32_t b = fine >> 16;
                 const uint32_t r = atomicAdd(&bcnt[b], 1u);
-                ik[k] = ((fine & 0xFFFFu) << 15) | (r == 0u ? kBkFlag : 0u) | (kBkIdxMask ^ (uint32_t)(tid + k * BLOCK));   // the entry
+                ik[k] = ((fine & 0xFFFFu) << 15) | ((kBkIdxMask ^ (uint32_t)(tid + k * BLOCK)) << 1) | (r == 0u ? kBkFlag : 0u);   // the entry
                 br[k] = (b << 8) | (r < 255u ? r : 255u);
             }
         }
@@ -315,7 +315,8 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 && KPT <= 10) ? 8 : 4) void b
             bucket_lds_barrier();
             continue;
         }
-        // exact rank of the listed entries inside their buckets (rank by counting; the bucket is <= 32 entries)
+        // exact rank of the listed entries inside their buckets: rank by counting over the bucket (<= 32 entries); the flag is the
+        // entries' lowest bit, so whole entries compare like (ord, index)
         uint32_t we[WPT], ws[WPT], wr[WPT];
 #pragma unroll
         for (int h = 0; h < WPT; ++h) {
@@ -324,38 +325,40 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 && KPT <= 10) ? 8 : 4) void b
             if (i < nw) {
                 const uint32_t it = work[i], b = it >> 14;
                 const uint32_t s = bcnt[b] & kBkStartMask, n = (bcnt[b + 1] & kBkStartMask) - s;
-                const uint32_t e = stage[it & 0x3FFFu] & ~kBkFlag;
-                uint32_t rank = 0u, eq = 0u;
-                for (uint32_t j = 0; j < n; ++j) {
-                    const uint32_t ej = stage[s + j] & ~kBkFlag;
-                    rank += ej < e ? 1u : 0u;
-                    eq += ((ej ^ e) >> 15) == 0u ? 1u : 0u;
-                }
-                if (eq > 1u && !(atomicOr(&bcnt[b], kBkTied) & kBkTied)) {      // same ord as another entry: this bucket by full keys
-                    const uint32_t t = atomicAdd(&ntied, 1u);
-                    if (t < 64u) tied[t] = b; else sfail = 1;
-                }
-                we[h] = e; ws[h] = s | (b << 16); wr[h] = rank;
+                const uint32_t e = stage[it & 0x3FFFu];
+                uint32_t rank = 0u;
+                for (uint32_t j = 0; j < n; ++j) rank += stage[s + j] < e ? 1u : 0u;
+                we[h] = e; ws[h] = s | (n << 15) | (b << 21); wr[h] = rank;
             }
         }
         bucket_lds_barrier();                             // every rank is counted before an entry moves
+        uint16_t *head = prm.order ? prm.order + (int64_t)p * prm.B : nullptr;
+#pragma unroll
+        for (int h = 0; h < WPT; ++h)
+            if (we[h] != 0xFFFFFFFFu) {
+                const uint32_t b = ws[h] >> 21, s = ws[h] & 0x7FFFu;
+                stage[s + wr[h]] = we[h] | kBkFlag;       // (every entry of an ordered bucket is a bucket of its own)
+                if ((int)b < nhead) head[s + wr[h]] = (uint16_t)bucket_entry_index(we[h]);
+            }
+        bucket_lds_barrier();
+        // two neighbours with the same ord?  then the entry values did not decide their order: that bucket again, by full keys
+#pragma unroll
+        for (int h = 0; h < WPT; ++h)
+            if (we[h] != 0xFFFFFFFFu) {
+                const uint32_t b = ws[h] >> 21, s = ws[h] & 0x7FFFu, n = (ws[h] >> 15) & 63u;
+                if (wr[h] + 1u < n && ((stage[s + wr[h] + 1u] ^ we[h]) >> 15) == 0u && !(atomicOr(&bcnt[b], kBkTied) & kBkTied)) {
+                    const uint32_t t = atomicAdd(&ntied, 1u);
+                    if (t < 64u) tied[t] = b; else sfail = 1;
+                }
+            }
+        bucket_lds_barrier();
         if (sfail) {
             if (tid == 0) { prm.nsb[p] = -1; prm.fail_list[atomicAdd(prm.nfail, 1)] = p; }
             bucket_lds_barrier();
             continue;
         }
-        uint16_t *head = prm.order ? prm.order + (int64_t)p * prm.B : nullptr;
-#pragma unroll
-        for (int h = 0; h < WPT; ++h)
-            if (we[h] != 0xFFFFFFFFu) {
-                const uint32_t b = ws[h] >> 16, s = ws[h] & 0xFFFFu;
-                if (!(bcnt[b] & kBkTied)) {
-                    stage[s + wr[h]] = we[h] | kBkFlag;   // (every entry of an ordered bucket is a bucket of its own)
-                    if ((int)b < nhead) head[s + wr[h]] = (uint16_t)bucket_entry_index(we[h]);
-                }
-            }
-        {
-            const int nt = (int)ntied;                    // rare: buckets in which the entry values do not decide
+        const int nt = (int)ntied;                        // (block-uniform) rare
+        if (nt) {
             for (int i = w; i < nt; i += NW) {
                 const uint32_t b = tied[i];
                 const int s = (int)(bcnt[b] & kBkStartMask), n = (int)(bcnt[b + 1] & kBkStartMask) - s;
@@ -367,12 +370,12 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 && KPT <= 10) ? 8 : 4) void b
                     if ((int)b < nhead) head[s + (int)rank] = (uint16_t)bucket_entry_index(ekey);
                 }
             }
+            bucket_lds_barrier();
         }
         if (tid == 0) {
             prm.ncand[p] = ncand;
             prm.nsb[p] = (int)(bcnt[nhead] & kBkStartMask);
         }
-        bucket_lds_barrier();
         if (!(prm.dbg & 2)) {
             uint32_t *out = prm.ent + (int64_t)p * prm.B;
             if ((((int64_t)p * prm.B) & 3) == 0) {

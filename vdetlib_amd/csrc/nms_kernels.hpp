@@ -77,18 +77,20 @@ struct TileDesc {      // one 256-row tile of one group
 
 constexpr int kRowsPerTile = 256;
 constexpr uint16_t kZTag = 0x8000;
-// bucketed list entries (bucket_kernels.hpp): {ord : 16 | first of its bucket : 1 | 0x3FFF ^ box index : 14}
+// bucketed list entries (bucket_kernels.hpp): {ord : 16 | 0x3FFF ^ box index : 14 | first of its bucket : 1} -- the flag sits
+// below the index, so comparing two entries as integers never looks at it (two entries differ in ord or index)
 constexpr uint32_t kBkIdxMask = 0x3FFFu;
-constexpr uint32_t kBkFlag = 0x4000u;
-__device__ __forceinline__ int bucket_entry_index(uint32_t e) { return (int)(kBkIdxMask ^ (e & kBkIdxMask)); }
-// two flag-less entries of one bucket whose order their values do not decide: equal ord, different index
-__device__ __forceinline__ bool bucket_entries_tied(uint32_t a, uint32_t b) { return ((a ^ b) - 1u) < kBkIdxMask; }
+constexpr uint32_t kBkFlag = 1u;
+__device__ __forceinline__ int bucket_entry_index(uint32_t e) { return (int)(kBkIdxMask ^ ((e >> 1) & kBkIdxMask)); }
+// two DIFFERENT entries of one bucket whose order their values do not decide: equal ord
+__device__ __forceinline__ bool bucket_entries_tied(uint32_t a, uint32_t b) { return ((a ^ b) >> 15) == 0u && ((a ^ b) >> 1) != 0u; }
 
 // status bits latched by kernels into ctx->d_status
 constexpr int kStCap = 1;       // survivors > cap
 constexpr int kStDivZero = 2;   // evaluated zero-union pair
 constexpr int kStPool = 4;      // adjacency pool too small (internal, retried by the host)
 constexpr int kStPoolAsync = 8; // ... in an asynchronous build (no retry possible: reported by vdet_sync)
+constexpr int kStBadOrder = 16; // a caller-supplied candidate list holds a count or an index out of range (vdet_nms_volume_ordered)
 constexpr uint32_t kFlagRegular = 1u;   // group_flags bit: see frame_flags_kernel
 constexpr uint32_t kFlagU16 = 2u;       // group_flags bit: every coordinate of the frame is an integer in [0, 65535] (and not -0.0)
 
@@ -1619,7 +1621,7 @@ __device__ __forceinline__ void walk_list_packed(const WalkParams &prm, lds_mask
 
 // ------------------------------------------------------------------------------------------------
 // The packed walk over a BUCKETED list (round 4; bucket_kernels.hpp): the list arrives cut into score-ordered buckets of a
-// few entries {ord : 16 | first of its bucket : 1 | 0x3FFF ^ index : 14} in arrival order, laid out so that every aligned
+// few entries {ord : 16 | 0x3FFF ^ index : 14 | first of its bucket : 1} in arrival order, laid out so that every aligned
 // chunk of 64 entries holds whole buckets.  Same passes over the same chunks as walk_list_packed; the lanes whose box is
 // still alive rank themselves by (bucket inside the chunk, ord) -- a loop of lane broadcasts over the alive lanes only:
 // ~1 400 of a list's 10 000 entries are ever ranked -- and enter the ring of alive candidates at head + rank instead of
@@ -1671,11 +1673,17 @@ __device__ __forceinline__ void walk_list_bucketed(const WalkParams &prm, lds_ma
                                      ((e & kBkFlag) ? 1u : 0u);
                 key = (bid << 16) | (e >> 15);
                 unsigned long long t = am;
-                while (t) {
-                    const int l = __ffsll((unsigned long long)t) - 1;
+                while (t) {                                       // two alive lanes per turn
+                    const int l0 = __ffsll((unsigned long long)t) - 1;
                     t &= t - 1;
-                    const uint32_t kl = (uint32_t)__builtin_amdgcn_readlane((int)key, l);
-                    rank += kl < key ? 1u : 0u;
+                    const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)key, l0);
+                    uint32_t k1 = 0xFFFFFFFFu;
+                    if (t) {
+                        const int l1 = __ffsll((unsigned long long)t) - 1;
+                        t &= t - 1;
+                        k1 = (uint32_t)__builtin_amdgcn_readlane((int)key, l1);
+                    }
+                    rank += (k0 < key ? 1u : 0u) + (k1 < key ? 1u : 0u);
                 }
             }
             const int slot0 = qh + qn;
@@ -1983,6 +1991,26 @@ __global__ __launch_bounds__(256) void walk_kernel(const WalkParams prm)
     if (lane == 0) prm.keep_cnt[p] = nk;
     if ((int64_t)nk > cap && lane == 0) atomicOr(prm.status, kStCap);
     if (__ballot(bad != 0) && lane == 0) atomicOr(prm.status, kStDivZero);
+}
+
+// Caller-supplied candidate lists (vdet_nms_volume_ordered) are walked as they come: a count above B or an index >= B would
+// index the walks' LDS dead mask and the adjacency tables out of bounds.  One wave per list checks it first: a bad list
+// latches kStBadOrder and is walked as EMPTY (ncand_out = 0), a good one keeps its count.
+__global__ __launch_bounds__(256) void check_order_kernel(const uint16_t *__restrict__ order, const int32_t *__restrict__ ncand_in, int P, int B,
+                                                          int32_t *__restrict__ ncand_out, int *__restrict__ status)
+{
+    const int lane = threadIdx.x & 63;
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= P) return;
+    const int n = ncand_in[p];
+    bool bad = n < 0 || n > B;
+    if (!bad)
+        for (int q = lane; q < n; q += 64) bad = bad || (int)order[(int64_t)p * B + q] >= B;
+    const bool any = __ballot(bad) != 0ull;
+    if (lane == 0) {
+        ncand_out[p] = any ? 0 : n;
+        if (any) atomicOr(status, kStBadOrder);
+    }
 }
 
 // mode-2 merge helper: survivors of every group -> composites key << 32 | original index

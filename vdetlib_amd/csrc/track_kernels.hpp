@@ -49,7 +49,7 @@ __device__ __forceinline__ bool at_or_before(uint32_t k, int flat, uint32_t ka, 
 // keys: [F*C, B] sortable keys (transpose_keys_kernel);  lists: [F*C, B] u16;  cnt: [F*C].
 // ------------------------------------------------------------------------------------------------
 // Bucketed lists (round 4, bucket_kernels.hpp): a (frame, class) list may arrive as score-ordered BUCKETS of a few
-// entries {ord : 16 | first of its bucket : 1 | 0x3FFF ^ index : 14} instead of a sorted u16 row.  The tracking kernels
+// entries {ord : 16 | 0x3FFF ^ index : 14 | first of its bucket : 1} instead of a sorted u16 row.  The tracking kernels
 // only ever read the HEAD of a list, one entry after the other, so the u16 row `lists[p]` is materialised lazily:
 // bucket_kernel wrote its first buckets in exact order, nsb[p] = entries in exact order so far, and whoever is about to
 // read a position behind that orders the next bucket first (one thread per list -- lists are only ever touched by the
@@ -76,12 +76,12 @@ __device__ __noinline__ int bucket_extend(const BucketLists &bl, int p, int B, u
     int t = s + 1;
     while (t < n && !(e[t] & kBkFlag)) ++t;              // the bucket is [s, t)
     for (int i = s; i < t; ++i) {
-        const uint32_t ei = e[i] & ~kBkFlag;
+        const uint32_t ei = e[i];
         const int xi = bucket_entry_index(ei);
         int rank = 0;
         for (int j = s; j < t; ++j) {
-            const uint32_t ej = e[j] & ~kBkFlag;
-            bool before = ej < ei;
+            const uint32_t ej = e[j];
+            bool before = (ej >> 1) < (ei >> 1);          // (the flag bit does not take part)
             if (bucket_entries_tied(ej, ei)) {            // equal ord, another entry: the full keys decide (ties: higher index first)
                 const int xj = bucket_entry_index(ej);
                 const uint32_t ki = kk[xi], kj = kk[xj];

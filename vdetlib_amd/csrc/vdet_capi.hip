@@ -173,6 +173,7 @@ struct vdet_ctx {
     int bk_floats = 0;
     DevBuf ent, nsb;
     DevBuf nover;                 // vdet_det_nms_volume: candidates per list before the topk cut
+    DevBuf ordncand;              // vdet_nms_volume_ordered: the caller's counts after check_order_kernel
     // second stream of the context: the memo warm-up runs on it, next to the NMS walk of the same video
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -268,6 +269,7 @@ uint32_t pow2ceil(uint32_t x)
 int translate_status(vdet_ctx *c, int st)
 {
     if (st & kStPoolAsync) return fail(c, VDET_EAGAIN, "adjacency pool overflow in an asynchronous graph build: run the calls again");
+    if (st & kStBadOrder) return fail(c, VDET_EINVAL, "a caller-supplied candidate list holds a count or a box index out of range");
     if (st & kStDivZero) return fail(c, VDET_EDIVZERO, "float division (zero union)");
     if (st & kStCap) return fail(c, VDET_ECAP, "more survivors than the output capacity");
     if (st & kStPool) return fail(c, VDET_EHIP, "internal: adjacency pool overflow");
@@ -1050,7 +1052,7 @@ int vdet_destroy(vdet_ctx *c)
                       &c->rowz, &c->rowmeta, &c->groupz, &c->adj, &c->comp, &c->origidx, &c->out64,
                       &c->trk_frames, &c->trk_boxes, &c->b1, &c->b2, &c->iou_out, &c->order, &c->ncand, &c->keepidx,
                       &c->keepcnt, &c->gflags, &c->pairs, &c->tkeys, &c->tstate, &c->visited, &c->heads, &c->xkeys, &c->xord, &c->xncand, &c->linkmemo, &c->linkstats, &c->linkwarm, &c->linkorder, &c->linkchains, &c->linknodes, &c->tracknode, &c->rtodo,
-                      &c->xbox, &c->xbox16, &c->xord16, &c->xcum, &c->xinfo, &c->wmeta, &c->reachtab, &c->sortctl, &c->segtab, &c->vidtab};
+                      &c->xbox, &c->xbox16, &c->xord16, &c->xcum, &c->xinfo, &c->wmeta, &c->reachtab, &c->sortctl, &c->segtab, &c->vidtab, &c->ent, &c->nsb, &c->nover, &c->ordncand};
     for (DevBuf *b : bufs) b->release();
     for (DevBuf &b : c->tmp) b.release();
     for (auto &e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -1487,10 +1489,14 @@ int vdet_nms_volume_ordered(vdet_ctx *c, const float *d_boxes, const uint16_t *d
         c->prep.boxes = d_boxes; c->prep.F = F; c->prep.B = B; c->prep.t32 = t32;
         c->graph_valid = true;
     }
+    // the lists are the caller's: counts / indices out of range latch VDET_EINVAL (vdet_sync) and the list is walked as empty
+    HIPCHK(c, c->ordncand.reserve((size_t)(F * C) * 4));
+    hipLaunchKernelGGL(check_order_kernel, dim3((unsigned)((F * C + 3) / 4)), dim3(256), 0, c->stream, d_order, d_ncand, (int)(F * C), (int)B,
+                       c->ordncand.as<int32_t>(), &c->d_cnt->status);
     SortWalkArgs a{};
     a.walk_only = true;
     a.mode = 1; a.P = (int)(F * C); a.B = (int)B; a.C = (int)C;
-    a.order_in = d_order; a.ncand_in = d_ncand;
+    a.order_in = d_order; a.ncand_in = c->ordncand.as<int32_t>();
     a.keep_idx = d_keep_idx; a.keep_cnt = d_keep_cnt; a.cap = cap;
     return launch_sort_walk(c, a, (int)B, F * C * B);
 }
