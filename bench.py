@@ -925,6 +925,40 @@ def main():
                 vid_shape = vid_shape_leg(torch, ops, _lib, dev, TAPS)
             except Exception as e:       # (report, do not fail the headline)
                 vid_shape = {"error": repr(e)[:300]}
+        # BASELINE configs[0]'s reference flow with per-class regressed boxes (fast_rcnn_det_vid's per-class loop + apply_image_nms
+        # per (frame, class): vdet/video_det.py:89-99, vdet/image_det.py:117-123) on the device: vdet_det_nms_volume at c1 shape
+        # (30 frames x 300 proposals x 30 classes + background, top-100) and at c2 shape.  Never part of `value`.
+        c1_flow = None
+        if not args.no_cpu and world == 1:
+            try:
+                def flow(Ff, Bf, Kf, reps):
+                    g = torch.Generator(device=dev).manual_seed(31)
+                    bx = torch.rand(Ff, Bf, 1, 4, generator=g, device=dev)
+                    x1, y1 = bx[..., 0] * 1230, bx[..., 1] * 670
+                    base = torch.stack([x1, y1, x1 + 10 + bx[..., 2] * 290, y1 + 10 + bx[..., 3] * 290], -1)
+                    BX = (base + (torch.rand(Ff, Bf, Kf, 4, generator=g, device=dev) - 0.5) * 8).round().contiguous()
+                    S = torch.rand(Ff, Bf, Kf, generator=g, device=dev)
+                    fc = _lib.Context(local)
+                    for _ in range(2):
+                        ops.det_nms_volume(BX, S, score_thresh=0.05, topk=100, nms_thresh=args.thresh, ctx=fc, want_dets=True)
+                    torch.cuda.synchronize()
+                    t = time.perf_counter()
+                    for _ in range(reps):
+                        out_ = ops.det_nms_volume(BX, S, score_thresh=0.05, topk=100, nms_thresh=args.thresh, ctx=fc, want_dets=True, sync=False)
+                    fc.sync(); torch.cuda.synchronize()
+                    ms = (time.perf_counter() - t) / reps * 1e3
+                    fc.close()
+                    return ms, int(out_[4].sum().item())
+                ms1, kept1 = flow(30, 300, 31, 20)
+                ms2, kept2 = flow(F, B, C + 1, 3)
+                c1_flow = {"c1_ms": ms1, "c1_kept": kept1, "c1_problems": 30 * 30,
+                           "reference_cpu_s": {"fast_rcnn_det_vid_threshold_topk": 0.06, "apply_image_nms_x900_top100": 0.19,
+                                               "where": "BASELINE.md section 2: the reference's own code, 1 core of the build container "
+                                                        "(not the GPU box's host)"},
+                           "c2_ms": ms2, "c2_kept": kept2, "c2_problems": F * C,
+                           "what": "threshold 0.05 -> best 100 -> per-class NMS of each class's OWN regressed boxes [F,B,K,4], rows + kept lists out"}
+            except Exception as e:
+                c1_flow = {"error": repr(e)[:300]}
         hbm_total = None
         pj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.isfile(pj):
@@ -965,6 +999,7 @@ def main():
             "hbm_traffic_per_video": hbm_total,          # sum of the PMC table (profiles/pmc_traffic.json), all kernels of one step
             "vid_shape": vid_shape,
             "lists": lists,
+            "c1_reference_flow": c1_flow,
             "timed_check": timed_check,
             "inputs": "HBM-resident (the PCIe-fed rate is upload_pipeline.boxes_per_s, never `value`)",
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_allcores": cpu_all, "map_parity": map_par, "pcie": pcie,

@@ -169,3 +169,64 @@ def test_full_volume_fast_paths_equal_the_plain_ones(full_run, monkeypatch):
                        ("tpool", tpool, r['tpool']), ("tboxes", tboxes, r['tboxes'])):
         assert torch.equal(a.nan_to_num(-7.0), b.nan_to_num(-7.0)), name
     cx.close()
+
+
+def _variant_video(torch, kind, dev):
+    """the c2 volume with other inputs than the benchmarked ones: fractional boxes (K1s's quotient fallback band, the int
+    truncation of tracked boxes), N(0,1) scores (both signs, many exponents: other histogram bins / radix digits), a
+    COHERENT video (every proposal persists with +-3 px of jitter and keeps 80 % of its score: distinct tubelets per class)"""
+    g = torch.Generator(device=dev).manual_seed({"frac": 411, "randn": 412, "coherent": 413}[kind])
+    if kind == "coherent":
+        base = torch.rand(B, 4, generator=g, device=dev)
+        x1, y1 = base[:, 0] * 1230, base[:, 1] * 670
+        bb = torch.stack([x1, y1, torch.clamp(x1 + 10 + base[:, 2] * 290, max=1279), torch.clamp(y1 + 10 + base[:, 3] * 290, max=719)], -1)
+        boxes = (bb[None] + torch.randint(-3, 4, (F, B, 4), generator=g, device=dev)).round()
+        boxes[..., 2:] = torch.maximum(boxes[..., 2:], boxes[..., :2] + 4)
+        scores = torch.rand(F, B, C, generator=g, device=dev).mul_(0.2).add_(0.8 * torch.rand(B, C, generator=g, device=dev)[None])
+        return boxes.contiguous(), scores.contiguous(), 0.9
+    x1 = torch.rand(F, B, generator=g, device=dev) * 1230
+    y1 = torch.rand(F, B, generator=g, device=dev) * 670
+    w = 10 + torch.rand(F, B, generator=g, device=dev) * 290
+    h = 10 + torch.rand(F, B, generator=g, device=dev) * 290
+    boxes = torch.stack([x1, y1, torch.clamp(x1 + w, max=1279), torch.clamp(y1 + h, max=719)], -1)
+    boxes = boxes.contiguous() if kind == "frac" else boxes.round().contiguous()
+    if kind == "randn":
+        return boxes, torch.randn(F, B, C, generator=g, device=dev), 2.5
+    return boxes, torch.rand(F, B, C, generator=g, device=dev), 0.9
+
+
+@pytest.mark.parametrize("kind", ["frac", "randn", "coherent"])
+def test_full_volume_other_inputs(kind, oracle, tmp_path):
+    """at FULL size the oracle had only met U(0,1) scores on integer boxes.  Per variant: the NMS
+    survivors of 9 frames x all 200 classes, and all ten tubelets + re-scoring of two classes."""
+    import torch
+    import oracle_pool
+    from vdetlib_amd import ops, _lib
+    dev = torch.device("cuda", torch.cuda.current_device())
+    boxes, scores, thres = _variant_video(torch, kind, dev)
+    cx = _lib.Context(dev.index)
+    cx.set_cache(True)
+    keep_idx, keep_cnt, tracks, anchors, ntracks = ops.nms_track_volume(
+        boxes, scores, nms_thres=0.3, thres=thres, max_tracks=10, link_thres=0.5, cap=2048, ctx=cx)
+    det, tpool, tboxes = ops.rescore_tracks(tracks, ntracks, boxes, scores, overlap_thres=0.7, window=3, ctx=cx)
+    frames = [0, 1, 84, 85, 149, 170, 171, 298, 299]
+    hb = boxes[frames].cpu().numpy()
+    hs = scores[frames].contiguous().cpu().numpy()
+    widx, wcnt = oracle.nms_volume(hb, hs, 0.3, cap=2048, threads=max(1, len(os.sched_getaffinity(0))))
+    assert np.array_equal(keep_cnt[frames].cpu().numpy(), wcnt)
+    assert np.array_equal(keep_idx[frames].cpu().numpy(), widx)
+    classes = [7, 150]
+    hball = boxes.cpu().numpy()
+    cols = {c: scores[:, :, c].contiguous().cpu().numpy() for c in classes}
+    want = oracle_pool.rescored_tubelets_per_class(hball, cols, dict(nms_thres=0.3, thres=thres, max_tracks=10, link_thres=0.5,
+                                                                     pool_thres=0.7, window=3), tmp_path)
+    for c in classes:
+        wt, wn, wpool, wbx, wdet = want[c]
+        assert int(ntracks[c]) == wn, (kind, c, int(ntracks[c]), wn)
+        assert np.array_equal(tracks[c, :wn].cpu().numpy(), wt[:wn], equal_nan=True), (kind, c)
+        has = ~np.isnan(wt[:wn, :, 0])
+        gd, gp, gb = det[c, :wn].cpu().numpy(), tpool[c, :wn].cpu().numpy(), tboxes[c, :wn].cpu().numpy()
+        np.testing.assert_allclose(gd[has], wdet[:wn][has], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(gp[has], wpool[:wn][has], rtol=0, atol=1e-9)
+        assert np.array_equal(gb[has], wbx[:wn][has])
+    cx.close()

@@ -184,6 +184,17 @@ def test_overlap_anchor_and_conv_cls(case, proto_golden):
     assert out[0]['gt'] == 1
     track_proto = proto_golden['greedy_track']['plain_det_c1']
     _close(_py(T.anchor_propagate(case['vid'], copy.deepcopy(track_proto), case['det'], 2)), g['anchor_propagate'])
+    # the reference only reads the detections of the ANCHOR frames (vdet/tubelet_cls.py:366-374): a det_proto whose other
+    # detections carry short score lists gives the same result
+    anchor_frames = {b['frame'] for t in track_proto['tracks'] for b in t if b['anchor'] == 0}
+    short = copy.deepcopy(case['det'])
+    cut = 0
+    for d in short['detections']:
+        if d['frame'] not in anchor_frames:
+            d['scores'] = d['scores'][:1]
+            cut += 1
+    assert cut > 0
+    _close(_py(T.anchor_propagate(case['vid'], copy.deepcopy(track_proto), short, 2)), g['anchor_propagate'])
     # score_conv_cls: blob assembly contract pinned with the recording fake net
     sc = proto_golden['score_conv_cls']
     net = synth.FakeTCN()

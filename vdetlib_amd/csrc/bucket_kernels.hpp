@@ -15,17 +15,21 @@
 //      distribution is -- the map is exact at every bin border and linear over 1/16 octave in between), ord = fine & 0xFFFF;
 //   4. one returning LDS atomic per key on its bucket's counter = arrival slot inside the bucket; scan of the
 //      <= 2 048 bucket counters; entries {ord : 16 | 0x3FFF ^ index : 14 | first-of-bucket : 1} staged in LDS;
-//   5. a bucket that straddles a 64-entry chunk border (one per chunk) is put in exact order by one wave (rank by lane
-//      broadcasts) and all its entries are flagged, i.e. become buckets of their own: the consumer reads the list in
-//      aligned chunks of 64 and every chunk holds whole buckets only.  Coalesced copy-out.
+//   5. a bucket that straddles a 64-entry chunk border (one per chunk) is put in exact order (its entries go on a work list;
+//      every thread ranks a few of them by counting over the bucket in LDS) and all its entries are flagged, i.e. become
+//      buckets of their own: the consumer reads the list in aligned chunks of 64 and every chunk holds whole buckets only.
+//      Coalesced copy-out.
 //
 // Entries of one bucket are in arrival order.  Ascending (ord, flag-less entry) IS the list's order (descending score,
 // ties by descending index) except between two entries of a bucket with EQUAL ord and different keys (two keys of a thin
 // bin within 32 / count of each other): whoever orders entries detects equal ords and lets the full keys decide.
 // ~8 LDS operations per key and 10 barriers against ~20 and 22 of the LSD sort.
 //
-// The first kBkHead buckets are also written to `order` in exact order for the tracking kernels, which read the head of
-// every list (track_kernels.hpp: bucket_extend orders further buckets on demand, one at a time).
+// The first kBkHead buckets (~1 500 entries) are put in exact order as well: nearly all of them are still alive when the
+// walk reaches them, so ranking them there (a lane-broadcast loop per alive lane in the issue-bound walk) costs more
+// than counting ranks here (LDS reads in a kernel with instruction slots to spare); a chunk of one-entry buckets is
+// taken in lane order by the walk.  With `order` given they are also written there as plain indices for the tracking
+// kernels, which read the head of every list (track_kernels.hpp: bucket_extend orders further buckets on demand).
 //
 // A list whose buckets this map cannot keep small (a bucket of more than 32 keys: heavily tied / quantised scores) or a
 // list of an irregular frame (the eager track_det_nms walk reads whole lists) goes to a fail list and is sorted by the
@@ -42,7 +46,8 @@ namespace vdet {
 
 constexpr int kBkMaxB = 16384;            // 14 index bits per entry
 constexpr int kBkMax = 32;                // keys per bucket (a bucket and its neighbours fit one wave)
-constexpr int kBkHead = 32;               // leading buckets ordered exactly for the tracking kernels (two per wave)
+constexpr int kBkHead = 192;              // leading buckets (~1 500 entries) put in exact order: nearly every one of them is still alive when
+                                          // the walk gets there (ranking them there costs more than here), and the tracking kernels read them
 constexpr int kBkDigitBits = 13;
 constexpr int kBkHistWords = (1 << kBkDigitBits) / 2 + 4;    // u16 counters (+ cum[last + 1])
 constexpr int kBkCntWords = 2048 + 8;     // bucket counters / starts (+ start[2048])
@@ -106,9 +111,8 @@ __device__ __forceinline__ void bucket_lds_barrier()
 }
 
 constexpr uint32_t kBkNeedsRank = 0x80000000u;   // bucket start word: its entries are put in exact order (chunk border / head)
-constexpr uint32_t kBkTied = 0x40000000u;        // ... and two of them share an ord: the full keys decide (bucket_rank_members)
 constexpr uint32_t kBkStartMask = 0x0000FFFFu;
-constexpr int kBkWorkMax = 2048;                 // entries ranked per list (two per thread)
+constexpr int kBkWorkMax = 4096;                 // entries ranked per list
 
 // BLOCK threads, KPT = keys per thread (key v = tid + k * BLOCK).  Persistent workgroups: a workgroup walks its share of the
 // lists and requests the next list's keys before it starts on the current one.  512 threads x 20 keys at B = 10 000: the LDS
@@ -280,7 +284,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 && KPT <= 10) ? 8 : 4) void b
             continue;
         }
         const int nbk = (ncand + 7) >> 3;                 // buckets in use (est. rank < ncand)
-        const int nhead = prm.order ? (nbk < kBkHead ? nbk : kBkHead) : 0;
+        const int nhead = nbk < kBkHead ? nbk : kBkHead;
         {
             // a bucket across a 64-entry chunk border, or one of the head the tracking kernels read, is put in exact order
             uint32_t st = bincl - bsum;
@@ -298,16 +302,27 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 && KPT <= 10) ? 8 : 4) void b
         }
         bucket_lds_barrier();
 #pragma unroll
-        for (int k = 0; k < KPT; ++k)
+        for (int k = 0; k < KPT; ++k) {
+            bool needs = false;
+            uint32_t item = 0u;
             if (br[k] != 0xFFFFFFFFu) {
                 const uint32_t b = br[k] >> 8, sw = bcnt[b];
                 const uint32_t pos = (sw & kBkStartMask) + (br[k] & 255u);
                 stage[pos] = ik[k];
-                if (sw & kBkNeedsRank) {
-                    const uint32_t slot = atomicAdd(&nwork, 1u);
-                    if (slot < (uint32_t)kBkWorkMax) work[slot] = pos | (b << 14);
-                }
+                needs = (sw & kBkNeedsRank) != 0u;
+                item = pos | (b << 14);
             }
+            // (one LDS atomic per wave and key slot: ~1 500 lanes adding to ONE counter serialise)
+            const unsigned long long nm = __ballot(needs);
+            if (nm) {
+                const int l0 = __ffsll((unsigned long long)nm) - 1;
+                uint32_t base = 0u;
+                if (lane == l0) base = atomicAdd(&nwork, (uint32_t)__popcll(nm));
+                base = (uint32_t)__builtin_amdgcn_readlane((int)base, l0);
+                const uint32_t slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(nm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nm, 0u));
+                if (needs && slot < (uint32_t)kBkWorkMax) work[slot] = item;
+            }
+        }
         bucket_lds_barrier();
         const int nw = (prm.dbg & 1) ? 0 : (int)nwork;
         if (nw > kBkWorkMax) {                            // (block-uniform; does not happen with buckets of ~8)
@@ -317,18 +332,18 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 && KPT <= 10) ? 8 : 4) void b
         }
         // exact rank of the listed entries inside their buckets: rank by counting over the bucket (<= 32 entries); the flag is the
         // entries' lowest bit, so whole entries compare like (ord, index)
-        uint32_t we[WPT], ws[WPT], wr[WPT];
+        uint32_t we[WPT], ws[WPT];                        // entry; start : 15 | size : 6 | rank : 6 | head : 1
 #pragma unroll
         for (int h = 0; h < WPT; ++h) {
             const int i = tid + BLOCK * h;
-            we[h] = 0xFFFFFFFFu; ws[h] = 0u; wr[h] = 0u;
+            we[h] = 0xFFFFFFFFu; ws[h] = 0u;
             if (i < nw) {
                 const uint32_t it = work[i], b = it >> 14;
                 const uint32_t s = bcnt[b] & kBkStartMask, n = (bcnt[b + 1] & kBkStartMask) - s;
                 const uint32_t e = stage[it & 0x3FFFu];
                 uint32_t rank = 0u;
                 for (uint32_t j = 0; j < n; ++j) rank += stage[s + j] < e ? 1u : 0u;
-                we[h] = e; ws[h] = s | (n << 15) | (b << 21); wr[h] = rank;
+                we[h] = e; ws[h] = s | (n << 15) | (rank << 21) | ((int)b < nhead ? 1u << 27 : 0u);
             }
         }
         bucket_lds_barrier();                             // every rank is counted before an entry moves
@@ -336,19 +351,19 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 && KPT <= 10) ? 8 : 4) void b
 #pragma unroll
         for (int h = 0; h < WPT; ++h)
             if (we[h] != 0xFFFFFFFFu) {
-                const uint32_t b = ws[h] >> 21, s = ws[h] & 0x7FFFu;
-                stage[s + wr[h]] = we[h] | kBkFlag;       // (every entry of an ordered bucket is a bucket of its own)
-                if ((int)b < nhead) head[s + wr[h]] = (uint16_t)bucket_entry_index(we[h]);
+                const uint32_t s = ws[h] & 0x7FFFu, r = (ws[h] >> 21) & 63u;
+                stage[s + r] = we[h] | kBkFlag;           // (every entry of an ordered bucket is a bucket of its own)
+                if (head && (ws[h] >> 27)) head[s + r] = (uint16_t)bucket_entry_index(we[h]);
             }
         bucket_lds_barrier();
         // two neighbours with the same ord?  then the entry values did not decide their order: that bucket again, by full keys
 #pragma unroll
         for (int h = 0; h < WPT; ++h)
             if (we[h] != 0xFFFFFFFFu) {
-                const uint32_t b = ws[h] >> 21, s = ws[h] & 0x7FFFu, n = (ws[h] >> 15) & 63u;
-                if (wr[h] + 1u < n && ((stage[s + wr[h] + 1u] ^ we[h]) >> 15) == 0u && !(atomicOr(&bcnt[b], kBkTied) & kBkTied)) {
+                const uint32_t s = ws[h] & 0x7FFFu, n = (ws[h] >> 15) & 63u, r = (ws[h] >> 21) & 63u;
+                if (r + 1u < n && ((stage[s + r + 1u] ^ we[h]) >> 15) == 0u) {
                     const uint32_t t = atomicAdd(&ntied, 1u);
-                    if (t < 64u) tied[t] = b; else sfail = 1;
+                    if (t < 64u) tied[t] = ws[h] & 0x083FFFFFu; else sfail = 1;      // start | size | head (a bucket may be listed twice)
                 }
             }
         bucket_lds_barrier();
@@ -359,22 +374,25 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 && KPT <= 10) ? 8 : 4) void b
         }
         const int nt = (int)ntied;                        // (block-uniform) rare
         if (nt) {
-            for (int i = w; i < nt; i += NW) {
-                const uint32_t b = tied[i];
-                const int s = (int)(bcnt[b] & kBkStartMask), n = (int)(bcnt[b + 1] & kBkStartMask) - s;
-                const bool member = lane < n;
-                const uint32_t ekey = member ? (stage[s + lane] & ~kBkFlag) : 0xFFFFFFFFu;
-                const uint32_t rank = bucket_rank_members<FLOATS>(ekey, member, 0, n, src);
-                if (member) {
-                    stage[s + (int)rank] = ekey | kBkFlag;
-                    if ((int)b < nhead) head[s + (int)rank] = (uint16_t)bucket_entry_index(ekey);
+            if (w == 0)                                   // one wave, one listed bucket after the other (a bucket listed twice is simply redone)
+                for (int i = 0; i < nt; ++i) {
+                    const uint32_t t = tied[i];
+                    const int s = (int)(t & 0x7FFFu), n = (int)((t >> 15) & 63u);
+                    const bool member = lane < n;
+                    const uint32_t ekey = member ? (stage[s + lane] & ~kBkFlag) : 0xFFFFFFFFu;
+                    const uint32_t rank = bucket_rank_members<FLOATS>(ekey, member, 0, n, src);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    if (member) {
+                        stage[s + (int)rank] = ekey | kBkFlag;
+                        if (head && (t >> 27)) head[s + (int)rank] = (uint16_t)bucket_entry_index(ekey);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 }
-            }
             bucket_lds_barrier();
         }
         if (tid == 0) {
             prm.ncand[p] = ncand;
-            prm.nsb[p] = (int)(bcnt[nhead] & kBkStartMask);
+            prm.nsb[p] = prm.order ? (int)(bcnt[nhead] & kBkStartMask) : 0;       // entries of `order` written in exact order
         }
         if (!(prm.dbg & 2)) {
             uint32_t *out = prm.ent + (int64_t)p * prm.B;

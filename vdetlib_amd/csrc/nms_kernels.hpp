@@ -1664,11 +1664,13 @@ __device__ __forceinline__ void walk_list_bucketed(const WalkParams &prm, lds_ma
         const int na = __popcll(am);
         if (na) {                                                 // (scalar branch)
             uint32_t rank = 0u, key = 0u;
-            if (prm.dbg & 1) {
+            // a chunk of one-entry buckets (the head of the list, ordered by bucket_kernel; ordered buckets elsewhere): lane order
+            const unsigned long long fm = __ballot(valid && (e & kBkFlag) != 0u);
+            const bool exact = fm == __ballot(valid);
+            if (exact || (prm.dbg & 1)) {
                 rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));
             } else if (na > 1) {
                 // rank key: buckets of a chunk in lane order, entries of a bucket by ord
-                const unsigned long long fm = __ballot(valid && (e & kBkFlag) != 0u);
                 const uint32_t bid = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u)) +
                                      ((e & kBkFlag) ? 1u : 0u);
                 key = (bid << 16) | (e >> 15);
@@ -1695,7 +1697,7 @@ __device__ __forceinline__ void walk_list_bucketed(const WalkParams &prm, lds_ma
                 lds_f4v bv; bv.x = b_cur.x; bv.y = b_cur.y; bv.z = b_cur.z; bv.w = b_cur.w;
                 ringb[2 * s + 1] = bv;
             }
-            if (na > 1 && !(prm.dbg & 3)) {
+            if (na > 1 && !exact && !(prm.dbg & 3)) {
                 // equal keys share a slot: does the slot hold what this lane wrote?  (the wave's LDS queue is in order)
                 const bool clash = alive && ring[8 * ring_wrap(slot0 + (int)rank)] != (uint32_t)c;
                 const unsigned long long cm = __ballot(clash);

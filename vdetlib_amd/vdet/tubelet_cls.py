@@ -135,14 +135,26 @@ def dets_spatial_max_pooling(vid_proto, track_proto, det_proto, class_idx, overl
     return score_proto
 
 
-def _class_dets_by_frame(det_proto, class_idx):
-    """frame -> (bboxes [n,4], class scores [n]) of a det_proto, detections in protocol order"""
-    grouped = defaultdict(lambda: ([], []))
-    for det in det_proto['detections']:
-        bboxes, scores = grouped[det['frame']]
-        bboxes.append(det['bbox'])
-        scores.append(det['scores'][class_idx - 1]['score'])
-    return {frame: (np.asarray(bb), np.asarray(sc)) for frame, (bb, sc) in grouped.items()}
+class _ClassDetsByFrame(object):
+    """frame -> (bboxes [n,4], class scores [n]) of a det_proto, detections in protocol order.  Only the frames that are
+    asked for are touched (and remembered): a det_proto whose detections of OTHER frames carry short score lists must not
+    fail here -- the reference only reads the anchor frames' detections (:366-374)."""
+
+    def __init__(self, det_proto, class_idx):
+        self._dets = det_proto['detections']
+        self._cls = class_idx - 1
+        self._by_frame = defaultdict(list)
+        for i, det in enumerate(self._dets):
+            self._by_frame[det['frame']].append(i)
+        self._memo = {}
+
+    def __call__(self, frame):
+        got = self._memo.get(frame)
+        if got is None:
+            idx = self._by_frame.get(frame, ())
+            got = self._memo[frame] = (np.asarray([self._dets[i]['bbox'] for i in idx]),
+                                       np.asarray([self._dets[i]['scores'][self._cls]['score'] for i in idx]))
+        return got
 
 
 def anchor_propagate(vid_proto, track_proto, det_proto, class_idx):
@@ -152,12 +164,11 @@ def anchor_propagate(vid_proto, track_proto, det_proto, class_idx):
     tubelets_proto = tubelets_proto_from_tracks_proto(track_proto['tracks'], class_idx)
     logging.info("Propagating anchor scores in {} for {}...".format(vid_proto['video'],
                                                                      imagenet_vdet_classes[class_idx]))
-    dets = _class_dets_by_frame(det_proto, class_idx)
-    empty = (np.asarray([]), np.asarray([]))
+    dets = _ClassDetsByFrame(det_proto, class_idx)
     for tubelet in tubelets_proto:
         anchors = [box for box in tubelet['boxes'] if box['anchor'] == 0]
         assert len(anchors) == 1
-        det_boxes, det_scores = dets.get(anchors[0]['frame'], empty)
+        det_boxes, det_scores = dets(anchors[0]['frame'])
         best = int(np.argmax(iou([anchors[0]['bbox']], det_boxes)[0]))
         for box in tubelet['boxes']:
             box['det_score'] = det_scores[best]
