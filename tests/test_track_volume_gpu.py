@@ -492,3 +492,37 @@ def test_link_table_up_front_equals_scanning_on_demand(case):
     if res[0] is not None:
         for a, b in zip(*res):
             assert torch.equal(a.nan_to_num(-7.0), b.nan_to_num(-7.0))
+
+
+def test_coherent_videos_get_their_anchors_predicted(oracle):
+    """proposals that persist over the frames (large frames: no up-front link table): the raw best detections of a class are
+    one object in every frame; the extra warm-anchor slots predict the OTHER objects' anchors the way the loop will pick them,
+    so the tracking loop scans (almost) nothing itself -- with tubelets identical to the oracle's and to VDET_LINK_COHERENT=0"""
+    import os
+    import torch
+    from vdetlib_amd import ops, _lib
+    rng = np.random.RandomState(5)
+    F, B, C = 14, 1400, 3
+    base = synth.boxes_1(rng, B)
+    boxes = np.stack([base + rng.randint(-3, 4, (B, 4)).astype(np.float32) for _ in range(F)], 0).astype(np.float32)
+    boxes[..., 2:] = np.maximum(boxes[..., 2:], boxes[..., :2] + 4)
+    scores = (0.8 * rng.rand(B, C)[None] + 0.2 * rng.rand(F, B, C)).astype(np.float32)
+    tb, ts = torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda()
+    kw = dict(nms_thres=0.3, thres=0.5, max_tracks=8, link_thres=0.5)
+    res, scanned = [], []
+    for knob in ("0", "1"):
+        os.environ["VDET_LINK_COHERENT"] = knob
+        try:
+            cx = _lib.Context(torch.cuda.current_device())
+        finally:
+            del os.environ["VDET_LINK_COHERENT"]
+        res.append(ops.track_volume(tb, ts, ctx=cx, **kw))
+        scanned.append(cx.query(5))                      # link steps the tracking LOOP had to scan itself
+        cx.close()
+    for a, b in zip(*res):
+        assert torch.equal(a.nan_to_num(-7.0), b.nan_to_num(-7.0))
+    assert scanned[1] < scanned[0] // 2, scanned         # the predicted anchors' chains were warmed up front
+    tr, an, nt = [t.cpu().numpy() for t in res[1]]
+    for c in range(C):
+        wt, wa, wn = oracle.greedy_track_volume(boxes, scores[:, :, c], 0.3, 0.5, 8, 0.5, 0)
+        assert nt[c] == wn and np.array_equal(an[c, :wn], wa[:wn]) and np.array_equal(tr[c, :wn], wt[:wn], equal_nan=True)

@@ -67,6 +67,7 @@ struct BucketParams {
     uint16_t *order;               // [P, B] exact head of every list (tracking), or null
     int32_t *fail_list;            // [P]
     int *nfail;
+    int head;                      // leading buckets put in exact order (kBkHead; VDET_BUCKET_HEAD is an A-B knob)
     int dbg;                       // VDET_BK_DBG (timing experiments only; results invalid): 1 no exact-order phase, 2 no copy-out, 4 stop after the scan, 8 stop after the load
 };
 
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 && KPT <= 10) ? 8 : 4) void b
             continue;
         }
         const int nbk = (ncand + 7) >> 3;                 // buckets in use (est. rank < ncand)
-        const int nhead = nbk < kBkHead ? nbk : kBkHead;
+        const int nhead = nbk < prm.head ? nbk : prm.head;
         {
             // a bucket across a 64-entry chunk border, or one of the head the tracking kernels read, is put in exact order
             uint32_t st = bincl - bsum;
@@ -341,8 +342,15 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 && KPT <= 10) ? 8 : 4) void b
                 const uint32_t it = work[i], b = it >> 14;
                 const uint32_t s = bcnt[b] & kBkStartMask, n = (bcnt[b + 1] & kBkStartMask) - s;
                 const uint32_t e = stage[it & 0x3FFFu];
+                // (eight independent LDS reads per turn: at 4 waves per SIMD a dependent read per turn is ~100 idle cycles each)
                 uint32_t rank = 0u;
-                for (uint32_t j = 0; j < n; ++j) rank += stage[s + j] < e ? 1u : 0u;
+                for (uint32_t j0 = 0; j0 < n; j0 += 8u) {
+                    uint32_t v[8];
+#pragma unroll
+                    for (uint32_t t = 0; t < 8u; ++t) v[t] = stage[s + min(j0 + t, n - 1u)];
+#pragma unroll
+                    for (uint32_t t = 0; t < 8u; ++t) rank += (j0 + t < n && v[t] < e) ? 1u : 0u;
+                }
                 we[h] = e; ws[h] = s | (n << 15) | (rank << 21) | ((int)b < nhead ? 1u << 27 : 0u);
             }
         }

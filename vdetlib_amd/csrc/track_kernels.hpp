@@ -1007,17 +1007,39 @@ __global__ __launch_bounds__(256) void link_fill_kernel(const float4 *__restrict
 // never correctness: the memo only ever holds next(f, j, dir), which no prediction can change.
 // One block per class; warm[c * m + k] = flat index or -1.
 // ------------------------------------------------------------------------------------------------
+// Coherent videos (round 4).  When proposals persist from frame to frame (real box protos do) the best detections of a
+// class are the SAME object in every frame: the m best candidates above sit on one or two chains, the other tubelets'
+// anchors are not predicted and the tracking loop scans their ~300 steps each itself, serially (measured on a coherent
+// config-2 video: 650 k of 660 k link steps scanned inside the loop, 4.4 ms instead of 0.56).  So, when a class's
+// raw candidates overlap each other ACROSS frames (>= kWarmCoherent of them repeat an earlier candidate's object), the
+// slots [m_raw, m) are filled by what the loop will do: candidates in the same global order, but one that overlaps an
+// already predicted anchor's box (as if it stood in the same frame: the object barely moves) is skipped -- the real
+// track through its frame would have suppressed it (utils/nms.pyx:163-183).  On independent frames the test fails and
+// the extra slots stay empty: nothing changes there.
+struct WarmExtra {
+    const float4 *boxes;      // [F*B] (null: raw candidates only)
+    float t32;                // the NMS threshold of the lists
+    int m_raw;                // slots filled by raw rank
+};
+constexpr int kWarmCoherent = 4;
+constexpr int kWarmMax = 32;
+
 __device__ __forceinline__ void track_warm_anchors_body(const int c, const uint32_t *__restrict__ keys, uint16_t *lists,
                                                         const int32_t *__restrict__ cnt, int F, int B, int C,
                                                         const float *__restrict__ scores, double thres, int m,
-                                                        int32_t *__restrict__ warm, const BucketLists &bkl)
+                                                        int32_t *__restrict__ warm, const BucketLists &bkl, const WarmExtra &wx)
 {
     __shared__ uint32_t sk[256];
     __shared__ int sf[256];
+    __shared__ float4 pb[kWarmMax];      // boxes of the predicted anchors (distinct objects first)
+    __shared__ int spf[kWarmMax];        // ... their flat indices
+    __shared__ int snpb, sdup;
     const int tid = threadIdx.x;
+    const int m_raw = (wx.boxes && wx.m_raw < m) ? wx.m_raw : m;
     uint32_t lk = 0xFFFFFFFFu;       // cursor: the last candidate taken (key, flat); everything at or before it is out
     int lf = -1;
-    for (int k = 0; k < m; ++k) {
+    int nraw = 0;
+    for (int k = 0; k < m_raw; ++k) {
         uint32_t bk = 0;
         int bflat = -1;
         for (int f = tid; f < F; f += 256) {
@@ -1058,15 +1080,92 @@ __device__ __forceinline__ void track_warm_anchors_body(const int c, const uint3
             if (tid == 0) for (int r = k + 1; r < m; ++r) warm[c * m + r] = -1;
             return;
         }
+        if (tid == 0 && k < kWarmMax) spf[k] = lf;
+        nraw = k + 1;
+    }
+    if (m_raw >= m) return;
+    // ---- do the raw candidates repeat each other's objects?  distinct ones -> pb[0 .. npb)
+    __syncthreads();
+    if (tid == 0) {
+        int npb = 0, dup = 0;
+        for (int k = 0; k < nraw && k < kWarmMax; ++k) {
+            const float4 bx = wx.boxes[spf[k]];
+            const float ar = box_area(bx);
+            bool rep = false;
+            for (int j = 0; j < npb && !rep; ++j) rep = (pair_pred(pb[j], box_area(pb[j]), bx, ar, wx.t32) & 1u) != 0u;
+            if (rep) ++dup; else pb[npb++] = bx;
+        }
+        snpb = npb; sdup = dup;
+    }
+    __syncthreads();
+    if (sdup < kWarmCoherent) {       // independent frames: the raw ranks are the anchors (measured: 99.9 % of them)
+        if (tid == 0) for (int r = m_raw; r < m; ++r) warm[c * m + r] = -1;
+        return;
+    }
+    // ---- coherent: the remaining slots by the loop's own rule (global order, minus what a predicted anchor's object covers)
+    int pos[2] = {0, 0};              // per frame of this thread (F <= 512 here: the host limits the extra slots to such videos)
+    for (int k = m_raw; k < m; ++k) {
+        const int npb = snpb;
+        uint32_t bk = 0;
+        int bflat = -1;
+        int h = 0;
+        for (int f = tid; f < F && h < 2; f += 256, ++h) {
+            const int p = f * C + c;
+            const int n = min(cnt[p], 64);                       // (prediction only: the head of the list is plenty)
+            uint16_t *l = lists + (int64_t)p * B;
+            int upto = bucket_sorted_len(bkl, p, cnt[p]);
+            while (pos[h] < n) {
+                bucket_need(bkl, p, B, l, keys + (int64_t)p * B, cnt[p], upto, pos[h]);
+                const int e = l[pos[h]];
+                const float4 bx = wx.boxes[(int64_t)f * B + e];
+                const float ar = box_area(bx);
+                bool covered = false;
+                for (int j = 0; j < npb && !covered; ++j) covered = (pair_pred(pb[j], box_area(pb[j]), bx, ar, wx.t32) & 1u) != 0u;
+                if (!covered) break;
+                ++pos[h];
+            }
+            if (pos[h] < n) {
+                const int e = l[pos[h]];
+                const uint32_t kk = keys[(int64_t)p * B + e];
+                const int flat = f * B + e;
+                if (bflat < 0 || kk > bk || (kk == bk && flat < bflat)) { bk = kk; bflat = flat; }
+            }
+        }
+        sk[tid] = bk; sf[tid] = bflat;
+        __syncthreads();
+        for (int d = 128; d > 0; d >>= 1) {
+            if (tid < d) {
+                const uint32_t k2 = sk[tid + d];
+                const int f2 = sf[tid + d];
+                if (f2 >= 0 && (sf[tid] < 0 || k2 > sk[tid] || (k2 == sk[tid] && f2 < sf[tid]))) { sk[tid] = k2; sf[tid] = f2; }
+            }
+            __syncthreads();
+        }
+        const int pick = sf[0];
+        __syncthreads();
+        bool stop = pick < 0;
+        if (!stop) {
+            const int f = pick / B, b = pick - f * B;
+            stop = (double)scores[((int64_t)f * B + b) * C + c] < thres;
+        }
+        if (stop) {
+            if (tid == 0) for (int r = k; r < m; ++r) warm[c * m + r] = -1;
+            return;
+        }
+        if (tid == 0) {
+            warm[c * m + k] = pick;
+            if (snpb < kWarmMax) { pb[snpb] = wx.boxes[pick]; snpb = snpb + 1; }
+        }
+        __syncthreads();
     }
 }
 
 __global__ __launch_bounds__(256) void track_warm_anchors_kernel(const uint32_t *__restrict__ keys, uint16_t *lists,
                                                                  const int32_t *__restrict__ cnt, int F, int B, int C,
                                                                  const float *__restrict__ scores, double thres, int m,
-                                                                 int32_t *__restrict__ warm, const BucketLists bk)
+                                                                 int32_t *__restrict__ warm, const BucketLists bk, const WarmExtra wx)
 {
-    track_warm_anchors_body(blockIdx.x, keys, lists, cnt, F, B, C, scores, thres, m, warm, bk);
+    track_warm_anchors_body(blockIdx.x, keys, lists, cnt, F, B, C, scores, thres, m, warm, bk, wx);
 }
 
 // ------------------------------------------------------------------------------------------------

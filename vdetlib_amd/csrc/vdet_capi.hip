@@ -166,6 +166,7 @@ struct vdet_ctx {
     int bucket_mode = 1;          // VDET_BUCKETS=0: always the LSD sort; 1 (default): volumes of more than 1024 boxes per frame whose
                                   // regular frames take the packed walk; 2: every volume the kernel can take (tests)
     int bk_dbg = 0, walk_dbg = 0; // VDET_BK_DBG / VDET_WALK_DBG: timing experiments (results invalid)
+    int bucket_head = kBkHead;    // VDET_BUCKET_HEAD: leading buckets of every list put in exact order by bucket_kernel (A-B knob)
     int bucket_block = 512;       // VDET_BUCKET_BLOCK=1024: 1 024 threads x 10 keys per list at B <= 10 240 (A-B knob)
     bool lists_bucketed = false;  // the context's lists (c->order / c->ncand) are bucketed: c->ent / c->bst / c->nsb describe them
     bool last_sort_bucketed = false;   // the last per-(frame, class) sort went through bucket_kernel (vdet_query 10 / 11)
@@ -186,6 +187,7 @@ struct vdet_ctx {
     bool link_lpt = true;         // VDET_LINK_LPT=0: the warm-up's chains in launch order instead of longest first (A-B knob)
     bool link_u16 = true;         // VDET_LINK_U16=0: the LINK window scans read the float4 index on every frame (A-B knob)
     int link_maxb = 8;            // VDET_LINK_MAXB=8|16: boxes per thread and batch in the warm-up's window scans (A-B knob)
+    bool link_coherent = true;    // VDET_LINK_COHERENT=0: no extra warm-anchor slots for coherent videos (A-B knob / tests)
     int link_fill = 1024;         // VDET_LINK_FILL=b: frames of up to b proposals get their WHOLE link table computed up front (link_fill_kernel:
                                   // every chain is pointer chasing afterwards, no anchor prediction, no warm-up scans); 0: never (A-B knob / tests)
     int link_warm = -1;           // VDET_LINK_WARM=m: chains warmed per class (-1: max_tracks + 2; 0: none)
@@ -729,6 +731,7 @@ int launch_sort_walk(vdet_ctx *c, const SortWalkArgs &a, int nmax, int64_t order
             bp.fail_list = reinterpret_cast<int32_t *>(c->sortctl.as<char>() + sizeof(BinSortCtl));
             bp.nfail = &c->sortctl.as<BinSortCtl>()->nfail;
             bp.dbg = c->bk_dbg;
+            bp.head = c->bucket_head;
             c->bk_raw = bp.raw; c->bk_floats = floats ? 1 : 0;
 #define VDET_BKK(BL, KP) (floats ? reinterpret_cast<const void *>(bucket_kernel<BL, KP, true>) : reinterpret_cast<const void *>(bucket_kernel<BL, KP, false>))
             const bool wide = c->bucket_block == 1024 && nmax > 4096 && nmax <= 10240;     // VDET_BUCKET_BLOCK=1024 (A-B knob)
@@ -970,7 +973,9 @@ int vdet_create(vdet_ctx **out, int device)
     if (const char *e = getenv("VDET_BINSORT")) c->binsort = atoi(e) != 0;
     if (const char *e = getenv("VDET_BUCKETS")) c->bucket_mode = atoi(e);
     if (const char *e = getenv("VDET_LINK_FILL")) c->link_fill = atoi(e);
+    if (const char *e = getenv("VDET_LINK_COHERENT")) c->link_coherent = atoi(e) != 0;
     if (const char *e = getenv("VDET_BUCKET_BLOCK")) c->bucket_block = atoi(e);
+    if (const char *e = getenv("VDET_BUCKET_HEAD")) c->bucket_head = std::max(0, std::min(atoi(e), 400));
     if (const char *e = getenv("VDET_BK_DBG")) c->bk_dbg = atoi(e);
     if (const char *e = getenv("VDET_WALK_DBG")) c->walk_dbg = atoi(e);
     if (const char *e = getenv("VDET_TRACK_LOOP")) c->track_loop = atoi(e) != 0;
@@ -1606,7 +1611,12 @@ int vdet_nms_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scor
         // 2 C latency-bound blocks per track); the tracking loop below then mostly walks known steps.  The warm-up only
         // reads the sorted lists, so it runs on the context's second stream NEXT TO the NMS walk of the same video
         // (per-stage timing keeps everything on one stream: HIP events on two streams would not add up)
-        const int wm = c->link_warm < 0 ? std::min(max_tracks + (c->link_materialize ? 6 : 2), 24) : std::min(c->link_warm, 64);   // (measured: 12 / 16 of 10 tracks)
+        const int wm_raw = c->link_warm < 0 ? std::min(max_tracks + (c->link_materialize ? 6 : 2), 24) : std::min(c->link_warm, 64);   // (measured: 12 / 16 of 10 tracks)
+        // + slots for the anchors of COHERENT videos (track_warm_anchors_body: filled only when a class's raw candidates repeat
+        // each other's objects across frames; empty -- and free -- otherwise).  Large frames only: small ones get the whole table
+        const bool coherent_slots = c->link_coherent && c->link_warm < 0 && wm_raw > 0 && F <= 512 && regular_ok &&
+                                    !(c->link_fill > 0 && B <= c->link_fill && w_ix.xbox != nullptr);
+        const int wm = coherent_slots ? std::min(wm_raw + max_tracks, 32) : wm_raw;
         hipStream_t ws = c->stream;
         if (c->use_aux && want_nms && !c->timing && wm > 0 && max_tracks > 0) {
             if (!c->aux_stream) {
@@ -1634,7 +1644,8 @@ int vdet_nms_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scor
             StageTimer tm(c, ST_TLINK);
             hipLaunchKernelGGL(track_warm_anchors_kernel, dim3((unsigned)C), dim3(256), 0, ws, c->tkeys.as<uint32_t>(),
                                c->order.as<uint16_t>(), c->ncand.as<int32_t>(), (int)F, (int)B, (int)C, d_scores, thres, wm,
-                               c->linkwarm.as<int32_t>(), bkl);
+                               c->linkwarm.as<int32_t>(), bkl,
+                               WarmExtra{coherent_slots ? reinterpret_cast<const float4 *>(d_boxes) : nullptr, t32, wm_raw});
             const int32_t *w_order = nullptr;
             if (c->link_lpt && !filled) {       // longest chains first
                 HIPCHK(c, c->linkorder.reserve((size_t)C * wm * 2 * 4));
