@@ -1,7 +1,7 @@
 """-m gpu: the bucketed per-(frame, class) lists (csrc/bucket_kernels.hpp, round 4) -- lists cut into score-ordered
 buckets instead of sorted, alive entries ranked by the walk -- against the oracle (utils/nms.pyx:17-68 per list,
-vdet/track.py:189-252 for the tracking kernels that read the lists' heads), on sizes where the bucket path is the
-default (more than 1024 boxes per frame), incl. the cases the entry values alone do not order (equal keys, keys of a
+vdet/track.py:189-252 for the tracking kernels that read the lists' heads), on contexts created with VDET_BUCKETS=1
+(the default is the LSD sort: the bucket path measured no faster) at more than 1024 boxes per frame, incl. the cases the entry values alone do not order (equal keys, keys of a
 thin histogram bin that interpolate to the same rank) and the lists it hands back to the LSD sort."""
 import numpy as np
 import pytest
@@ -12,9 +12,19 @@ pytestmark = pytest.mark.gpu
 
 
 def _ctx():
+    """a context with the bucket path on (VDET_BUCKETS is read at vdet_create; the default is the LSD sort)"""
+    import os
     import torch
     from vdetlib_amd import _lib
-    return _lib.Context(torch.cuda.current_device())
+    old = os.environ.get("VDET_BUCKETS")
+    os.environ["VDET_BUCKETS"] = "1"
+    try:
+        return _lib.Context(torch.cuda.current_device())
+    finally:
+        if old is None:
+            del os.environ["VDET_BUCKETS"]
+        else:
+            os.environ["VDET_BUCKETS"] = old
 
 
 def _check_nms(oracle, boxes, scores, ctx, layout="FBC", score_thresh=None, expect_bucketed=True, max_fail=0):

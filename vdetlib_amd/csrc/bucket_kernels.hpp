@@ -25,11 +25,10 @@
 // bin within 32 / count of each other): whoever orders entries detects equal ords and lets the full keys decide.
 // ~8 LDS operations per key and 10 barriers against ~20 and 22 of the LSD sort.
 //
-// The first kBkHead buckets (~1 500 entries) are put in exact order as well: nearly all of them are still alive when the
-// walk reaches them, so ranking them there (a lane-broadcast loop per alive lane in the issue-bound walk) costs more
-// than counting ranks here (LDS reads in a kernel with instruction slots to spare); a chunk of one-entry buckets is
-// taken in lane order by the walk.  With `order` given they are also written there as plain indices for the tracking
-// kernels, which read the head of every list (track_kernels.hpp: bucket_extend orders further buckets on demand).
+// The first kBkHead buckets are put in exact order as well (a chunk of one-entry buckets is taken in lane order by the
+// walk); with `order` given they are also written there as plain indices for the tracking kernels, which read the head of
+// every list (track_kernels.hpp: bucket_extend orders further buckets on demand).  Ordering a longer head here instead of
+// ranking its alive entries in the walk moves the cost from one kernel to the other, one for one (measured, kBkHead).
 //
 // A list whose buckets this map cannot keep small (a bucket of more than 32 keys: heavily tied / quantised scores) or a
 // list of an irregular frame (the eager track_det_nms walk reads whole lists) goes to a fail list and is sorted by the
@@ -46,8 +45,9 @@ namespace vdet {
 
 constexpr int kBkMaxB = 16384;            // 14 index bits per entry
 constexpr int kBkMax = 32;                // keys per bucket (a bucket and its neighbours fit one wave)
-constexpr int kBkHead = 192;              // leading buckets (~1 500 entries) put in exact order: nearly every one of them is still alive when
-                                          // the walk gets there (ranking them there costs more than here), and the tracking kernels read them
+constexpr int kBkHead = 32;               // leading buckets (~250 entries) put in exact order: the tracking kernels read the head of every list,
+                                          // and the walk takes a chunk of one-entry buckets in lane order (measured with 32 / 96 / 192 / 320
+                                          // buckets: bucket kernel 2.14 / 2.60 / 2.70 / 3.27 ms, walk 3.95 / 3.85 / 3.72 / 3.62 ms)
 constexpr int kBkDigitBits = 13;
 constexpr int kBkHistWords = (1 << kBkDigitBits) / 2 + 4;    // u16 counters (+ cum[last + 1])
 constexpr int kBkCntWords = 2048 + 8;     // bucket counters / starts (+ start[2048])
@@ -342,15 +342,9 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 && KPT <= 10) ? 8 : 4) void b
                 const uint32_t it = work[i], b = it >> 14;
                 const uint32_t s = bcnt[b] & kBkStartMask, n = (bcnt[b + 1] & kBkStartMask) - s;
                 const uint32_t e = stage[it & 0x3FFFu];
-                // (eight independent LDS reads per turn: at 4 waves per SIMD a dependent read per turn is ~100 idle cycles each)
+                // (measured: eight independent reads per turn instead of one did NOT help, 2.85 vs 2.70 ms -- more instructions)
                 uint32_t rank = 0u;
-                for (uint32_t j0 = 0; j0 < n; j0 += 8u) {
-                    uint32_t v[8];
-#pragma unroll
-                    for (uint32_t t = 0; t < 8u; ++t) v[t] = stage[s + min(j0 + t, n - 1u)];
-#pragma unroll
-                    for (uint32_t t = 0; t < 8u; ++t) rank += (j0 + t < n && v[t] < e) ? 1u : 0u;
-                }
+                for (uint32_t j = 0; j < n; ++j) rank += stage[s + j] < e ? 1u : 0u;
                 we[h] = e; ws[h] = s | (n << 15) | (rank << 21) | ((int)b < nhead ? 1u << 27 : 0u);
             }
         }

@@ -163,8 +163,11 @@ struct vdet_ctx {
     std::vector<int64_t> h_seg_off;   // the offsets h_seg / segtab were built from
     DevBuf sortctl;               // binsort_kernel's work counter + the list of problems it handed to the LSD kernel
     // round 4: per-(frame, class) lists cut into score-ordered buckets instead of sorted (bucket_kernels.hpp)
-    int bucket_mode = 1;          // VDET_BUCKETS=0: always the LSD sort; 1 (default): volumes of more than 1024 boxes per frame whose
-                                  // regular frames take the packed walk; 2: every volume the kernel can take (tests)
+    int bucket_mode = 0;          // VDET_BUCKETS=1: volumes of more than 1024 boxes per frame whose regular frames take the packed walk get
+                                  // their lists cut into score-ordered buckets (bucket_kernels.hpp) instead of sorted; 2: every volume
+                                  // the kernel can take (tests); 0 (default): always the LSD sort.  Bit-identical results; measured at the
+                                  // LSD path's speed one video at a time (bucket kernel 2.14 + walk 3.95 ms vs sort 3.18 + walk 2.94)
+                                  // and 0.5 ms per step SLOWER with 4 videos in flight, so off
     int bk_dbg = 0, walk_dbg = 0; // VDET_BK_DBG / VDET_WALK_DBG: timing experiments (results invalid)
     int bucket_head = kBkHead;    // VDET_BUCKET_HEAD: leading buckets of every list put in exact order by bucket_kernel (A-B knob)
     int bucket_block = 512;       // VDET_BUCKET_BLOCK=1024: 1 024 threads x 10 keys per list at B <= 10 240 (A-B knob)
@@ -187,7 +190,10 @@ struct vdet_ctx {
     bool link_lpt = true;         // VDET_LINK_LPT=0: the warm-up's chains in launch order instead of longest first (A-B knob)
     bool link_u16 = true;         // VDET_LINK_U16=0: the LINK window scans read the float4 index on every frame (A-B knob)
     int link_maxb = 8;            // VDET_LINK_MAXB=8|16: boxes per thread and batch in the warm-up's window scans (A-B knob)
-    bool link_coherent = true;    // VDET_LINK_COHERENT=0: no extra warm-anchor slots for coherent videos (A-B knob / tests)
+    bool link_coherent = false;   // VDET_LINK_COHERENT=1: extra warm-anchor slots for coherent videos (track_warm_anchors_body).  A LATENCY
+                                  // option: a coherent config-2 video alone 20.2 -> 18.6 ms (the loop's serial scans move into the
+                                  // chip-filling warm-up), but with 4 videos in flight 15.4 -> 17.1 ms (the serial scans were hidden
+                                  // under the other videos, the warm-up's are not) and +0.1 ms on independent frames, so off
     int link_fill = 1024;         // VDET_LINK_FILL=b: frames of up to b proposals get their WHOLE link table computed up front (link_fill_kernel:
                                   // every chain is pointer chasing afterwards, no anchor prediction, no warm-up scans); 0: never (A-B knob / tests)
     int link_warm = -1;           // VDET_LINK_WARM=m: chains warmed per class (-1: max_tracks + 2; 0: none)
