@@ -23,7 +23,8 @@ STAGES = [("iou_bits_sym_kernel", "iou_bits"), ("iou_bits_kernel", "iou_bits_gen
           ("rescore_spatial_kernel", "rescore_spatial"), ("rescore_series_kernel", "rescore_series"),
           ("rescore_series_wave_kernel", "rescore_series"), ("rescore_adj_kernel", "rescore_adj"), ("track_loop_kernel", "track_loop"),
           ("track_link_memo_kernel", "track_link"), ("track_warm_anchors_kernel", "track_warm"), ("binsort_kernel", "sort"),
-          ("sort_list_kernel", "sort_fallback")]
+          ("sort_list_kernel", "sort_fallback"), ("bucket_kernel", "sort"), ("link_fill_kernel", "track_fill"),
+          ("det_nms_kernel", "det_nms"), ("check_order_kernel", "check_order")]
 
 
 def per_kernel(db, counter):

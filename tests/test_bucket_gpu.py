@@ -171,8 +171,7 @@ def test_tracking_orders_every_bucket_on_demand(oracle):
 
 
 def test_bucket_path_and_lsd_path_agree_at_the_limit():
-    """B = 16 384 (the entry format's index field) against the LSD sort of the same volume (VDET_BUCKETS is read at
-    vdet_create: a second context with the knob off)"""
+    """B = 16 384 (the entry format's index field) against the LSD sort of the same volume (a default context)"""
     import os
     import torch
     from vdetlib_amd import ops
@@ -187,11 +186,8 @@ def test_bucket_path_and_lsd_path_agree_at_the_limit():
     a = _ctx()
     ia, ca = ops.nms_volume(boxes, scores, 0.3, ctx=a)
     assert a.query(10) == 1 and a.query(11) == 0
-    os.environ["VDET_BUCKETS"] = "0"
-    try:
-        b = _ctx()
-    finally:
-        del os.environ["VDET_BUCKETS"]
+    from vdetlib_amd import _lib
+    b = _lib.Context(torch.cuda.current_device())           # the default: LSD lists
     ib, cb = ops.nms_volume(boxes, scores, 0.3, ctx=b)
     assert b.query(10) == 0
     assert torch.equal(ca, cb) and torch.equal(ia, ib)
