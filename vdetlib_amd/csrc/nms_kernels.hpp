@@ -1512,7 +1512,14 @@ __device__ __forceinline__ void walk_ring_drain(const WalkParams &prm, lds_mask_
         const float4 bi = make_float4(vi.x, vi.y, vi.z, vi.w), bj = make_float4(vj.x, vj.y, vj.z, vj.w);
         const bool live = vk && !((mask[cm >> 5] >> (cm & 31)) & 1u);
         const unsigned long long lm = __ballot(live);
-        const bool hit = (pair_pred(bi, box_area(bi), bj, box_area(bj), t32) & 1u) != 0u;
+        // the graph's own edge rule without the division (regular frames only get here): the sign of fma(-t32, union, inter)
+        // decides, the band just below the threshold falls back to the IEEE quotient (pred_regular, as in iou_bits_sym_kernel)
+        const float ai = box_area(bi), aj = box_area(bj);
+        bool border;
+        bool hit = pred_regular(bi, ai, bj, aj, t32, t32 * 4.76837158203125e-7f, border);
+        if (__ballot(border) != 0ull) {
+            if (border) hit = (pair_pred(bi, ai, bj, aj, t32) & 1u) != 0u;
+        }
         const unsigned long long cmask = __ballot(hit && k < sub && sub < ng && live && ((lm >> (8 * sub)) & 1ull));
         unsigned long long surv_s = lm & 0x0101010101010101ull;      // bit 8k <=> member k survives
         if (cmask) {
