@@ -344,6 +344,8 @@ def main():
     ap.add_argument("--no-rescore", action="store_true", help="(ablation) tubelets without the spatial / temporal re-scoring")
     ap.add_argument("--videos", type=int, default=0, help="configs[3]: this many videos sharded over the ranks (LPT), one ragged exchange per pass; "
                     "0 (default): the headline step, one video per rank and step")
+    ap.add_argument("--no-latency-leg", action="store_true", help="skip the single-video run with the library's latency options (profiling: that leg "
+                    "overlaps kernels of two streams, which inflates their traced durations)")
     ap.add_argument("--no-coherent", action="store_true", help="skip the coherent-video leg (reported next to value, never part of it)")
     ap.add_argument("--no-upload", action="store_true", help="skip the PCIe-fed pipeline leg (reported next to value, never part of it)")
     ap.add_argument("--force-exchange", action="store_true",
@@ -815,6 +817,8 @@ def main():
         # warm-up next to the NMS walk): slower with several videos in flight, faster alone -- not the default
         single_video_latency_ms = None
         try:
+            if args.no_latency_leg:
+                raise RuntimeError("skipped (--no-latency-leg)")
             saved = {k: os.environ.get(k) for k in ("VDET_GRAPH_PIPE", "VDET_AUX_STREAM")}
             os.environ["VDET_GRAPH_PIPE"] = "1"; os.environ["VDET_AUX_STREAM"] = "1"
             try:

@@ -91,15 +91,16 @@ __global__ __launch_bounds__(256) void batch_warm_anchors_kernel(const BatchTrac
     track_warm_anchors_body(blockIdx.x, w.keys, w.lists, w.cnt, w.F, bt.B, bt.C, w.scores, bt.thres, bt.wm, w.warm, BucketLists{nullptr, nullptr}, WarmExtra{nullptr, 0.f, 0});
 }
 
-// grid (ceil(Fmax * B / 256), 2, V): the whole link table of every video (link_fill_node)
+// grid (ceil(Fmax * B * kFillLanes / 256), 2, V): the whole link table of every video (link_fill_node)
 __global__ __launch_bounds__(256) void batch_link_fill_kernel(const BatchTrack bt)
 {
     const VidView w = vid_view(bt, blockIdx.z);
-    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t n = t / kFillLanes;
     if (n >= (int64_t)w.F * bt.B) return;
     const int f = (int)(n / bt.B);
-    link_fill_node(f, (int)(n - (int64_t)f * bt.B), blockIdx.y == 0 ? 1 : -1, w.boxes, w.F, bt.B, bt.link_t32, w.group_flags, w.ix,
-                   bt.link_thres, w.memo);
+    link_fill_node(f, (int)(n - (int64_t)f * bt.B), blockIdx.y == 0 ? 1 : -1, (int)(t & (kFillLanes - 1)), w.boxes, w.F, bt.B, bt.link_t32,
+                   w.group_flags, w.ix, bt.link_thres, w.memo);
 }
 
 // grid (C * wm, 2, V); MODE 1: memo warm-up, MODE 2: materialise the warm chains
@@ -145,7 +146,8 @@ __global__ __launch_bounds__(256) void batch_loop_kernel(const BatchTrack bt)
     lz.boxes = w.boxes; lz.tracks = w.tracks; lz.t32 = bt.t32;
     lz.t1 = bt.heads + fc; lz.head = bt.heads + FC + fc; lz.nkp = bt.heads + 2 * FC + fc; lz.pos = bt.heads + 3 * FC + fc;
     lz.group_flags = bt.lazy ? w.group_flags : nullptr;
-    const ResolveArgs rv{w.warm, bt.wm, w.chains, w.chain_nodes, w.tracks, w.track_nodes};
+    // (bt.wm == 0: the whole link table is known -- no predicted chains to copy, every tubelet is walked here, by pointer chasing)
+    const ResolveArgs rv{w.warm, bt.wm, bt.wm > 0 ? w.chains : (float *)nullptr, w.chain_nodes, w.tracks, w.track_nodes};
     LoopArgs la{};
     la.keys = w.keys; la.lists = w.lists; la.cnt = w.cnt;
     la.scores = w.scores; la.thres = bt.thres; la.link_thres = bt.link_thres; la.anchors = w.anchors;

@@ -937,7 +937,12 @@ __global__ __launch_bounds__(1024) void warm_order_kernel(const int32_t *__restr
 // inside the tracking loop (on coherent videos the warm-up predicted one chain per class and the loop scanned the rest).
 // The values are the ones a scan would publish, so the memo-driven kernels are unchanged.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void link_fill_node(const int f, const int j, const int dir, const float4 *__restrict__ boxes, int F, int B,
+// kFillLanes lanes share a node: lane `sub` takes every kFillLanes-th candidate of the window, a quad reduction (DPP) picks the
+// winner -- trip counts of the lanes of a wave are more even than with one whole window each, and a quad reads 64 contiguous
+// bytes of the x-sorted index per turn.
+constexpr int kFillLanes = 4;
+
+__device__ __forceinline__ void link_fill_node(const int f, const int j, const int dir, const int sub, const float4 *__restrict__ boxes, int F, int B,
                                                float link_t32, const uint32_t *__restrict__ group_flags, const FrameIndex &ix,
                                                double link_thres, unsigned long long *memo)
 {
@@ -962,7 +967,7 @@ __device__ __forceinline__ void link_fill_node(const int f, const int j, const i
         const int r1 = (int)cum[xbucket(fminf(hi, 3.0e38f), xmin, scale) + 1];
         const float4 *xb = ix.xbox + (int64_t)f2 * B;
         const uint16_t *xo = ix.xord + (int64_t)f2 * B;
-        for (int r = r0; r < r1; ++r) {
+        for (int r = r0 + sub; r < r1; r += kFillLanes) {
             const float4 x = xb[r];
             bool border;
             const bool pass = pred_regular(cur, carea, x, box_area(x), link_t32, t32e, border);
@@ -975,11 +980,20 @@ __device__ __forceinline__ void link_fill_node(const int f, const int j, const i
     } else {
         // irregular frame / no index / degenerate current box: the plain arg-max (NaN never wins, lowest index on ties)
         const float4 *fb = boxes + (int64_t)f2 * B;
-        for (int b = 0; b < B; ++b) {
+        for (int b = sub; b < B; b += kFillLanes) {
             const float v = link_iou(cur, carea, fb[b]);
             if (v > bv) { bv = v; bi = b; }
         }
     }
+    // the quad's winner: highest IoU, lowest index on ties (a lane without a candidate holds bi = -1, bv = -1)
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+        const float ov = __int_as_float(st == 0 ? __builtin_amdgcn_mov_dpp(__float_as_int(bv), 0xB1, 0xf, 0xf, true)
+                                                : __builtin_amdgcn_mov_dpp(__float_as_int(bv), 0x4E, 0xf, 0xf, true));
+        const int oi = st == 0 ? __builtin_amdgcn_mov_dpp(bi, 0xB1, 0xf, 0xf, true) : __builtin_amdgcn_mov_dpp(bi, 0x4E, 0xf, 0xf, true);
+        if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
+    }
+    if (sub != 0) return;
     const bool linked = bi >= 0 && bv >= link_t32;
     unsigned long long *mm = memo + (int64_t)(dir > 0 ? 0 : 1) * F * B;
     __hip_atomic_store(&mm[(int64_t)f * B + j],
@@ -987,15 +1001,17 @@ __device__ __forceinline__ void link_fill_node(const int f, const int j, const i
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// grid (ceil(F * B / 256), 2)
+// grid (ceil(F * B * kFillLanes / 256), 2)
 __global__ __launch_bounds__(256) void link_fill_kernel(const float4 *__restrict__ boxes, int F, int B, float link_t32,
                                                         const uint32_t *__restrict__ group_flags, const FrameIndex ix, double link_thres,
                                                         unsigned long long *memo)
 {
-    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t n = t / kFillLanes;
     if (n >= (int64_t)F * B) return;
     const int f = (int)(n / B);
-    link_fill_node(f, (int)(n - (int64_t)f * B), blockIdx.y == 0 ? 1 : -1, boxes, F, B, link_t32, group_flags, ix, link_thres, memo);
+    link_fill_node(f, (int)(n - (int64_t)f * B), blockIdx.y == 0 ? 1 : -1, (int)(t & (kFillLanes - 1)), boxes, F, B, link_t32, group_flags, ix,
+                   link_thres, memo);
 }
 
 // ------------------------------------------------------------------------------------------------

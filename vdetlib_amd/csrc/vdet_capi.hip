@@ -190,6 +190,7 @@ struct vdet_ctx {
     bool link_lpt = true;         // VDET_LINK_LPT=0: the warm-up's chains in launch order instead of longest first (A-B knob)
     bool link_u16 = true;         // VDET_LINK_U16=0: the LINK window scans read the float4 index on every frame (A-B knob)
     int link_maxb = 8;            // VDET_LINK_MAXB=8|16: boxes per thread and batch in the warm-up's window scans (A-B knob)
+    bool batch_chains = false;    // VDET_BATCH_CHAINS=1: batched small videos with the link table up front still predict + materialise chains (A-B knob)
     bool link_coherent = false;   // VDET_LINK_COHERENT=1: extra warm-anchor slots for coherent videos (track_warm_anchors_body).  A LATENCY
                                   // option: a coherent config-2 video alone 20.2 -> 18.6 ms (the loop's serial scans move into the
                                   // chip-filling warm-up), but with 4 videos in flight 15.4 -> 17.1 ms (the serial scans were hidden
@@ -980,6 +981,7 @@ int vdet_create(vdet_ctx **out, int device)
     if (const char *e = getenv("VDET_BUCKETS")) c->bucket_mode = atoi(e);
     if (const char *e = getenv("VDET_LINK_FILL")) c->link_fill = atoi(e);
     if (const char *e = getenv("VDET_LINK_COHERENT")) c->link_coherent = atoi(e) != 0;
+    if (const char *e = getenv("VDET_BATCH_CHAINS")) c->batch_chains = atoi(e) != 0;
     if (const char *e = getenv("VDET_BUCKET_BLOCK")) c->bucket_block = atoi(e);
     if (const char *e = getenv("VDET_BUCKET_HEAD")) c->bucket_head = std::max(0, std::min(atoi(e), 400));
     if (const char *e = getenv("VDET_BK_DBG")) c->bk_dbg = atoi(e);
@@ -1642,7 +1644,7 @@ int vdet_nms_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scor
         const bool filled = c->link_fill > 0 && B <= c->link_fill && w_ix.xbox != nullptr && max_tracks > 0;
         if (filled) {
             StageTimer tm(c, ST_TLINK);
-            hipLaunchKernelGGL(link_fill_kernel, dim3((unsigned)((F * B + 255) / 256), 2), dim3(256), 0, ws, reinterpret_cast<const float4 *>(d_boxes),
+            hipLaunchKernelGGL(link_fill_kernel, dim3((unsigned)((F * B * kFillLanes + 255) / 256), 2), dim3(256), 0, ws, reinterpret_cast<const float4 *>(d_boxes),
                                (int)F, (int)B, link_t32, w_flags, w_ix, link_thres, c->linkmemo.as<unsigned long long>());
         }
         if (wm > 0 && max_tracks > 0) {
@@ -1921,12 +1923,21 @@ int vdet_video_batch(vdet_ctx *c, const float *d_boxes, const float *d_scores, c
     bt.status = &c->d_cnt->status; bt.n_irregular = &c->d_cnt->irregular;
     {
         StageTimer tm(c, ST_TLINK);
-        hipLaunchKernelGGL(batch_warm_anchors_kernel, dim3((unsigned)C, (unsigned)V), dim3(256), 0, c->stream, bt);
-        if (c->link_fill > 0 && B <= c->link_fill && have_ix)       // the whole link table of every video: no chain ever scans
-            hipLaunchKernelGGL(batch_link_fill_kernel, dim3((unsigned)((Fmax * B + 255) / 256), 2, (unsigned)V), dim3(256), 0, c->stream, bt);
-        else
+        if (c->link_fill > 0 && B <= c->link_fill && have_ix) {
+            // the whole link table of every video: no chain ever scans, whatever its anchor -- so nothing is predicted or
+            // materialised either (VDET_BATCH_CHAINS=1 keeps the predicted chains: measured below)
+            hipLaunchKernelGGL(batch_link_fill_kernel, dim3((unsigned)((Fmax * B * kFillLanes + 255) / 256), 2, (unsigned)V), dim3(256), 0, c->stream, bt);
+            if (c->batch_chains) {
+                hipLaunchKernelGGL(batch_warm_anchors_kernel, dim3((unsigned)C, (unsigned)V), dim3(256), 0, c->stream, bt);
+                hipLaunchKernelGGL((batch_link_kernel<64, 2>), dim3((unsigned)(C * wm), 2, (unsigned)V), dim3(64), 0, c->stream, bt);
+            } else {
+                bt.wm = 0;
+            }
+        } else {
+            hipLaunchKernelGGL(batch_warm_anchors_kernel, dim3((unsigned)C, (unsigned)V), dim3(256), 0, c->stream, bt);
             hipLaunchKernelGGL((batch_link_kernel<256, 1>), dim3((unsigned)(C * wm), 2, (unsigned)V), dim3(256), 0, c->stream, bt);
-        hipLaunchKernelGGL((batch_link_kernel<64, 2>), dim3((unsigned)(C * wm), 2, (unsigned)V), dim3(64), 0, c->stream, bt);
+            hipLaunchKernelGGL((batch_link_kernel<64, 2>), dim3((unsigned)(C * wm), 2, (unsigned)V), dim3(64), 0, c->stream, bt);
+        }
     }
     {
         StageTimer tm(c, ST_TLOOP);
