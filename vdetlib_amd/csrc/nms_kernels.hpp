@@ -1380,6 +1380,19 @@ __device__ __forceinline__ void lds_and(lds_mask_t m, int word, uint32_t bits)
     __hip_atomic_fetch_and((lds_u32_t *)(m + word), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
 
+// Two adjacency entries (one dword) -> two dead bits.  The word index comes from v_bfe_u32 (hipcc
+// otherwise rewrites (e & 0xFFFF) >> 5 << 2 as shift + mask and needs a separate add for the mask's LDS base; bit-field
+// extract + v_lshl_add_u32 is one instruction less per entry in the walk's hottest sequence), the bit from a shift that
+// only looks at the operand's low five bits.
+__device__ __forceinline__ void lds_or_pair(lds_mask_t m, uint32_t d)
+{
+    uint32_t w0, w1;
+    asm("v_bfe_u32 %0, %1, 5, 11" : "=v"(w0) : "v"(d));      // (inline asm: the builtin is folded back into shift + mask)
+    asm("v_bfe_u32 %0, %1, 21, 11" : "=v"(w1) : "v"(d));
+    lds_or(m, (int)w0, 1u << (d & 31u));
+    lds_or(m, (int)w1, 1u << ((d >> 16) & 31u));
+}
+
 constexpr int kWalkGrp = 4;
 
 // One 64-entry slice of a survivor's adjacency list -> dead bits.  HASZ = false (every regular
@@ -1551,8 +1564,7 @@ __device__ __forceinline__ void walk_ring_drain(const WalkParams &prm, lds_mask_
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const uint32_t d = a0.v[t];
-                    lds_or(mask, (int)((d & 0xFFFFu) >> 5), 1u << (d & 31u));
-                    lds_or(mask, (int)(d >> 21), 1u << ((d >> 16) & 31u));
+                    lds_or_pair(mask, d);
                 }
             }
             if (__ballot(has1) != 0ull) {
@@ -1560,8 +1572,7 @@ __device__ __forceinline__ void walk_ring_drain(const WalkParams &prm, lds_mask_
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         const uint32_t d = a1.v[t];
-                        lds_or(mask, (int)((d & 0xFFFFu) >> 5), 1u << (d & 31u));
-                        lds_or(mask, (int)(d >> 21), 1u << ((d >> 16) & 31u));
+                        lds_or_pair(mask, d);
                     }
                 }
                 unsigned long long lg = __ballot(sub == 0 && deg > 128);
@@ -1783,8 +1794,7 @@ __device__ __forceinline__ void walk_list_packed2(const WalkParams &prm, lds_mas
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const uint32_t d = a0.v[t];
-                lds_or(mask, (int)((d & 0xFFFFu) >> 5), 1u << (d & 31u));
-                lds_or(mask, (int)(d >> 21), 1u << ((d >> 16) & 31u));
+                lds_or_pair(mask, d);
             }
         }
         if (__ballot(has1) != 0ull) {
@@ -1792,8 +1802,7 @@ __device__ __forceinline__ void walk_list_packed2(const WalkParams &prm, lds_mas
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const uint32_t d = a1.v[t];
-                    lds_or(mask, (int)((d & 0xFFFFu) >> 5), 1u << (d & 31u));
-                    lds_or(mask, (int)(d >> 21), 1u << ((d >> 16) & 31u));
+                    lds_or_pair(mask, d);
                 }
             }
             unsigned long long lg = __ballot(sub == 0 && deg > 128);

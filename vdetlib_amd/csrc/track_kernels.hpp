@@ -967,14 +967,24 @@ __device__ __forceinline__ void link_fill_node(const int f, const int j, const i
         const int r1 = (int)cum[xbucket(fminf(hi, 3.0e38f), xmin, scale) + 1];
         const float4 *xb = ix.xbox + (int64_t)f2 * B;
         const uint16_t *xo = ix.xord + (int64_t)f2 * B;
-        for (int r = r0 + sub; r < r1; r += kFillLanes) {
-            const float4 x = xb[r];
-            bool border;
-            const bool pass = pred_regular(cur, carea, x, box_area(x), link_t32, t32e, border);
-            if (pass || border) {
-                const float v = link_iou(cur, carea, x);
-                const int b = (int)xo[r];
-                if (v >= link_t32 && (v > bv || (v == bv && b < bi))) { bv = v; bi = b; }
+        // four candidates per turn, every load issued before the first use (a load that is waited for right away costs a full
+        // memory latency per candidate: measured, the kernel took the same 4.35 ms with one lane per node and with four)
+        for (int r = r0 + sub; r < r1; r += 4 * kFillLanes) {
+            float4 x[4];
+            uint16_t xi[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) x[t] = xb[min(r + t * kFillLanes, B - 1)];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) xi[t] = xo[min(r + t * kFillLanes, B - 1)];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                bool border;
+                const bool pass = pred_regular(cur, carea, x[t], box_area(x[t]), link_t32, t32e, border);
+                if ((pass || border) && r + t * kFillLanes < r1) {
+                    const float v = link_iou(cur, carea, x[t]);
+                    const int b = (int)xi[t];
+                    if (v >= link_t32 && (v > bv || (v == bv && b < bi))) { bv = v; bi = b; }
+                }
             }
         }
     } else {
