@@ -170,6 +170,36 @@ __global__ __launch_bounds__(256) void batch_rescore_spatial_kernel(const BatchT
                      out_box + 4 * o, w.ix, w.group_flags);
 }
 
+// The same with the candidates of a tubelet box taken from the suppression graph (rescore_adj_one: the neighbours of the proposal
+// the box came from, 16 lanes per box): grid (ceil(Fmax * C * T / 16), V); what the graph can not serve goes on `todo` as
+// {video, box} for batch_rescore_todo_kernel (the window scan, grid-stride)
+__global__ __launch_bounds__(256) void batch_rescore_adj_kernel(const BatchTrack bt, double thres, double min_self_iou, double *__restrict__ out_score,
+                                                                float *__restrict__ out_box, int2 *__restrict__ todo, unsigned int *__restrict__ todo_cnt)
+{
+    const VidView w = vid_view(bt, blockIdx.y);
+    const int l = threadIdx.x & 15;
+    const int64_t wv = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (wv >= (int64_t)w.F * bt.C * bt.T) return;
+    const int64_t o = (int64_t)bt.C * bt.T * w.f0;
+    if (!rescore_adj_one(wv, l, w.tracks, w.ntracks, w.boxes, w.scores, w.F, bt.B, bt.C, bt.T, thres, out_score + o, out_box + 4 * o,
+                         w.group_flags, w.track_nodes, bt.row_meta + (int64_t)w.f0 * bt.B, bt.adj, min_self_iou) && l == 0)
+        todo[atomicAdd(todo_cnt, 1u)] = make_int2((int)blockIdx.y, (int)wv);
+}
+
+__global__ __launch_bounds__(256) void batch_rescore_todo_kernel(const BatchTrack bt, double thres, double *__restrict__ out_score,
+                                                                 float *__restrict__ out_box, const int2 *__restrict__ todo,
+                                                                 const unsigned int *__restrict__ todo_cnt)
+{
+    const int64_t n = (int64_t)*todo_cnt;
+    for (int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += (int64_t)gridDim.x * 4) {
+        const int2 t = todo[i];
+        const VidView w = vid_view(bt, t.x);
+        const int64_t o = (int64_t)bt.C * bt.T * w.f0;
+        rescore_one_scan(t.y, threadIdx.x & 63, w.tracks, w.ntracks, w.boxes, w.scores, w.F, bt.B, bt.C, bt.T, thres, out_score + o,
+                         out_box + 4 * o, w.ix, w.group_flags);
+    }
+}
+
 // do_score_completion + temporal max-pool of every tubelet series: grid (ceil(C * T / 4), V); dynamic LDS 4 * stride_bytes
 __global__ __launch_bounds__(256) void batch_rescore_series_kernel(const BatchTrack bt, double *__restrict__ sc, double *__restrict__ out2,
                                                                    int window, int *__restrict__ err, int stride_bytes)

@@ -1586,17 +1586,15 @@ __global__ __launch_bounds__(256) void rescore_spatial_kernel(const float *__res
 // memory round trips: 0.72 ms); entries this path can not serve (no recorded node, box mismatch, irregular frame,
 // IoU(b_j, T) too small) are appended to `todo` for rescore_spatial_kernel.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void rescore_adj_kernel(const float *__restrict__ tracks, const int32_t *__restrict__ ntracks,
-                                                          const float4 *__restrict__ boxes, const float *__restrict__ scores,
-                                                          int F, int B, int C, int T, double thres, double *__restrict__ out_score,
-                                                          float *__restrict__ out_box, const uint32_t *__restrict__ group_flags,
-                                                          const int32_t *__restrict__ nodes, const uint2 *__restrict__ row_meta,
-                                                          const uint16_t *__restrict__ adj, double min_self_iou,
-                                                          int32_t *__restrict__ todo, unsigned int *__restrict__ todo_cnt)
+// one tubelet box (class, track, frame) = wv, 16 lanes (l = lane in the group).  Returns false -- for all 16 lanes -- when the box
+// can not be served from the graph (the caller hands it to the window scan)
+__device__ __forceinline__ bool rescore_adj_one(const int64_t wv, const int l, const float *__restrict__ tracks, const int32_t *__restrict__ ntracks,
+                                                const float4 *__restrict__ boxes, const float *__restrict__ scores,
+                                                int F, int B, int C, int T, double thres, double *__restrict__ out_score,
+                                                float *__restrict__ out_box, const uint32_t *__restrict__ group_flags,
+                                                const int32_t *__restrict__ nodes, const uint2 *__restrict__ row_meta,
+                                                const uint16_t *__restrict__ adj, double min_self_iou)
 {
-    const int l = threadIdx.x & 15;
-    const int64_t wv = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
-    if (wv >= (int64_t)F * C * T) return;
     const int t = (int)(wv % T);
     const int fc = (int)(wv / T);
     const int f = fc / C, c = fc - f * C;
@@ -1606,7 +1604,7 @@ __global__ __launch_bounds__(256) void rescore_adj_kernel(const float *__restric
     if (t >= ntracks[c] || r0 != r0) {
         if (l == 0) out_score[e] = __longlong_as_double(0x7FF8000000000000ll);
         if (l < 4) out_box[e * 4 + l] = __uint_as_float(0x7FC00000u);
-        return;
+        return true;
     }
     const double p[4] = {(double)r0, (double)r1, (double)r2, (double)r3};
     bool ok = false;
@@ -1622,10 +1620,7 @@ __global__ __launch_bounds__(256) void rescore_adj_kernel(const float *__restric
             }
         }
     }
-    if (!ok) {     // (uniform over the 16 lanes of the box)
-        if (l == 0) todo[atomicAdd(todo_cnt, 1u)] = (int32_t)wv;
-        return;
-    }
+    if (!ok) return false;     // (uniform over the 16 lanes of the box)
     const uint2 meta = row_meta[(int64_t)f * B + j];
     const int n = (int)meta.y + 1;                // the neighbours + j itself
     double bs = 0.0;
@@ -1663,6 +1658,23 @@ __global__ __launch_bounds__(256) void rescore_adj_kernel(const float *__restric
             out_box[e * 4 + 0] = r0; out_box[e * 4 + 1] = r1; out_box[e * 4 + 2] = r2; out_box[e * 4 + 3] = r3;
         }
     }
+    return true;
+}
+
+__global__ __launch_bounds__(256) void rescore_adj_kernel(const float *__restrict__ tracks, const int32_t *__restrict__ ntracks,
+                                                          const float4 *__restrict__ boxes, const float *__restrict__ scores,
+                                                          int F, int B, int C, int T, double thres, double *__restrict__ out_score,
+                                                          float *__restrict__ out_box, const uint32_t *__restrict__ group_flags,
+                                                          const int32_t *__restrict__ nodes, const uint2 *__restrict__ row_meta,
+                                                          const uint16_t *__restrict__ adj, double min_self_iou,
+                                                          int32_t *__restrict__ todo, unsigned int *__restrict__ todo_cnt)
+{
+    const int l = threadIdx.x & 15;
+    const int64_t wv = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (wv >= (int64_t)F * C * T) return;
+    if (!rescore_adj_one(wv, l, tracks, ntracks, boxes, scores, F, B, C, T, thres, out_score, out_box, group_flags, nodes, row_meta, adj,
+                         min_self_iou) && l == 0)
+        todo[atomicAdd(todo_cnt, 1u)] = (int32_t)wv;
 }
 
 // one thread per (class, track): completion over the track's boxes (its non-NaN frames, in order),

@@ -1946,6 +1946,19 @@ int vdet_video_batch(vdet_ctx *c, const float *d_boxes, const float *d_scores, c
     if (want_rescore) {
         {
             StageTimer tm(c, ST_RSPATIAL);
+            // candidates from the suppression graph wherever the tracking loop recorded the proposal a tubelet box came from (as
+            // vdet_rescore_tracks does; needs overlap_thres well above the graph's threshold), the window scan for the rest
+            const bool use_adj = c->rescore_adj && g_flags && overlap_thres - nms_thres > 0.05 && nms_thres > 0.0 && overlap_thres < 1.0;
+            if (use_adj) {
+                const int64_t nb = F * C * T;
+                HIPCHK(c, c->rtodo.reserve((size_t)nb * 8 + 16));
+                unsigned int *cnt = reinterpret_cast<unsigned int *>(c->rtodo.as<char>() + (size_t)nb * 8);
+                HIPCHK(c, hipMemsetAsync(cnt, 0, 4, c->stream));
+                hipLaunchKernelGGL(batch_rescore_adj_kernel, dim3((unsigned)((Fmax * C * T + 15) / 16), (unsigned)V), dim3(256), 0, c->stream, bt,
+                                   overlap_thres, 1.0 - (overlap_thres - nms_thres) + 0.02, d_det_score, d_boxes_out, c->rtodo.as<int2>(), cnt);
+                hipLaunchKernelGGL(batch_rescore_todo_kernel, dim3((unsigned)std::min<int64_t>((nb + 3) / 4, 8 * c->n_cu)), dim3(256), 0, c->stream, bt,
+                                   overlap_thres, d_det_score, d_boxes_out, c->rtodo.as<int2>(), cnt);
+            } else
             hipLaunchKernelGGL(batch_rescore_spatial_kernel, dim3((unsigned)((Fmax * C * T + 3) / 4), (unsigned)V), dim3(256), 0, c->stream, bt,
                                overlap_thres, d_det_score, d_boxes_out);
         }
