@@ -1587,6 +1587,11 @@ __device__ __forceinline__ void walk_ring_drain(const WalkParams &prm, lds_mask_
                     }
                 }
             }
+            // every list load of this turn has landed before the next turn starts (vmcnt(0) only).  Without it the loads of a
+            // turn whose lanes all skipped their pieces are still pending on the back edge, and hipcc then waits for vmcnt(0) at
+            // the loop HEADER -- where it also drains the next chunk's prefetched records before this chunk's first lists can
+            // even be requested (one exposed round trip per chunk)
+            __builtin_amdgcn_s_waitcnt(0x0F70);
         }
         qh = ring_wrap(qh + ng);
         qn -= ng;
@@ -1603,37 +1608,56 @@ __device__ __forceinline__ void walk_list_packed(const WalkParams &prm, lds_mask
     const float t32 = prm.t32;
     int qh = 0, qn = 0, nk = 0;                                   // ring head, queued candidates, survivors (wave-uniform)
     const int last = max(ncand - 1, 0);
-    int c_cur = (int)order[(uint32_t)min(lane, last)];
-    int c_nxt = (int)order[(uint32_t)min(64 + lane, last)];
-    uint2 m_cur = make_uint2(0u, 0u);
-    float4 b_cur = make_float4(0.f, 0.f, 0.f, 0.f);
+    // Software pipeline over the chunks of 64 candidates, three register sets taken in turn (the loop is unrolled by three):
+    // chunk k's pass uses set k % 3, requests the records of chunk k + 1 (for the lanes alive NOW) into set (k + 1) % 3 and
+    // the candidate ids of chunk k + 2 into set (k + 2) % 3.  With ONE set of names rotated by register copies at the bottom of
+    // the loop (round 2/3) hipcc has to wait for every load in flight right there -- a copy reads its source -- so the
+    // "prefetch" was drained once per chunk; a chunk that queues fewer than eight candidates (no lists to fetch, nothing to
+    // hide behind) then paid the records' whole round trip (found in the ISA, round 4: s_waitcnt vmcnt(0) in front of the copies).
+    int cc[3];
+    uint2 mm[3];
+    float4 bb[3];
+    cc[0] = (int)order[(uint32_t)min(lane, last)];
+    cc[1] = (int)order[(uint32_t)min(64 + lane, last)];
+    cc[2] = 0;
+    mm[0] = mm[1] = mm[2] = make_uint2(0u, 0u);
+    bb[0] = bb[1] = bb[2] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (lane < ncand) {                                           // chunk 0: everything is alive
-        const WalkMeta *wm = wmeta + (uint32_t)c_cur;
-        b_cur = wm->box; const uint4 rw = wm->row; m_cur = make_uint2(rw.x, rw.y);
+        const WalkMeta *wm = wmeta + (uint32_t)cc[0];
+        bb[0] = wm->box; const uint4 rw = wm->row; mm[0] = make_uint2(rw.x, rw.y);
     }
-    for (int q0 = 0; q0 < ncand; q0 += 64) {
-        const int c = c_cur;
-        const int c_nn = (int)order[(uint32_t)min(q0 + 128 + lane, last)];
-        uint2 m_nxt = make_uint2(0u, 0u);
-        float4 b_nxt = make_float4(0.f, 0.f, 0.f, 0.f);
-        if ((q0 + 64 + lane) < ncand && !((mask[c_nxt >> 5] >> (c_nxt & 31)) & 1u)) {
-            const WalkMeta *wm = wmeta + (uint32_t)c_nxt;
-            b_nxt = wm->box; const uint4 rw = wm->row; m_nxt = make_uint2(rw.x, rw.y);
-        }
-        const bool alive = (q0 + lane) < ncand && !((mask[c >> 5] >> (c & 31)) & 1u);
-        const unsigned long long am = __ballot(alive);
-        if (alive) {
-            const int s = ring_wrap(qh + qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u)));
-            ring[8 * s] = (uint32_t)c;
-            ring[8 * s + 1] = m_cur.x;
-            ring[8 * s + 2] = m_cur.y;
-            lds_f4v bv; bv.x = b_cur.x; bv.y = b_cur.y; bv.z = b_cur.z; bv.w = b_cur.w;
-            ringb[2 * s + 1] = bv;
-        }
-        qn += __popcll(am);
-        walk_ring_drain(prm, mask, ring, ringb, lane, t32, q0 + 64 >= ncand, qh, qn, nk, out, cap);
-        c_cur = c_nxt; c_nxt = c_nn; m_cur = m_nxt; b_cur = b_nxt;
+#define VDET_WALK_PASS(Q0, CUR, NXT, NN)                                                                                             \
+    {                                                                                                                                \
+        const int q0_ = (Q0);                                                                                                        \
+        const int c = cc[CUR];                                                                                                       \
+        cc[NN] = (int)order[(uint32_t)min(q0_ + 128 + lane, last)];                                                                  \
+        {   /* (no branch around the loads: a lane that needs no record reads record 0 -- one shared line -- so that the number */ \
+            /*  of loads in flight does not depend on the path and hipcc can wait for exactly the older ones)                   */ \
+            const bool want = (q0_ + 64 + lane) < ncand && !((mask[cc[NXT] >> 5] >> (cc[NXT] & 31)) & 1u);                           \
+            const WalkMeta *wm = wmeta + (want ? (uint32_t)cc[NXT] : 0u);                                                            \
+            bb[NXT] = wm->box; const uint4 rw = wm->row; mm[NXT] = make_uint2(rw.x, rw.y);                                           \
+        }                                                                                                                            \
+        const bool alive = (q0_ + lane) < ncand && !((mask[c >> 5] >> (c & 31)) & 1u);                                               \
+        const unsigned long long am = __ballot(alive);                                                                               \
+        if (alive) {                                                                                                                 \
+            const int s = ring_wrap(qh + qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u))); \
+            ring[8 * s] = (uint32_t)c;                                                                                               \
+            ring[8 * s + 1] = mm[CUR].x;                                                                                             \
+            ring[8 * s + 2] = mm[CUR].y;                                                                                             \
+            lds_f4v bv; bv.x = bb[CUR].x; bv.y = bb[CUR].y; bv.z = bb[CUR].z; bv.w = bb[CUR].w;                                      \
+            ringb[2 * s + 1] = bv;                                                                                                   \
+        }                                                                                                                            \
+        qn += __popcll(am);                                                                                                          \
+        walk_ring_drain(prm, mask, ring, ringb, lane, t32, q0_ + 64 >= ncand, qh, qn, nk, out, cap);                                 \
     }
+    for (int q0 = 0; q0 < ncand; q0 += 192) {
+        VDET_WALK_PASS(q0, 0, 1, 2)
+        if (q0 + 64 >= ncand) break;
+        VDET_WALK_PASS(q0 + 64, 1, 2, 0)
+        if (q0 + 128 >= ncand) break;
+        VDET_WALK_PASS(q0 + 128, 2, 0, 1)
+    }
+#undef VDET_WALK_PASS
     nk_out = nk;
 }
 
