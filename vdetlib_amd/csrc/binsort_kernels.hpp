@@ -82,6 +82,7 @@ __global__ __launch_bounds__(512, CPW <= 20 ? 4 : 2) void binsort_kernel(const B
     __shared__ uint32_t tab[512];        // per exponent value: first bin << 16 | number of sub-bins
     __shared__ uint32_t wsum[NW];
     __shared__ int snext;
+    __shared__ int sbad;
 
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int P = prm.P, N = prm.N;
@@ -91,14 +92,25 @@ __global__ __launch_bounds__(512, CPW <= 20 ? 4 : 2) void binsort_kernel(const B
         const uint32_t x = row[idx];
         return ~(FLOATS ? score_key(__uint_as_float(x)) : x);
     };
+    // Round 4 (found in the ISA): with `ik[k] = v < N ? ikey(row, v) : ...` every key's load sat in its own basic block with an
+    // s_waitcnt vmcnt(0) behind it -- CPW dependent memory round trips per list -- and the "prefetch" of the next list's keys was
+    // drained by the next __syncthreads() anyway (its fence waits for every global load on gfx9).  Now the RAW words are requested
+    // with unconditional, clamped loads (all in flight together), the barriers of the loop order LDS traffic only
+    // (lds_only_barrier), and the words are turned into inverted keys when the list's turn comes (finish_keys).
     auto load_keys = [&](int p, uint32_t (&ik)[CPW]) {
         const uint32_t *row = prm.raw + (int64_t)p * N;          // (scalar base + 32-bit lane offsets)
         uint32_t off = (uint32_t)tid;
         asm volatile("" : "+v"(off));                            // not hoisted out of the problem loop as CPW 64-bit pointers
 #pragma unroll
+        for (int k = 0; k < CPW; ++k) ik[k] = row[min(off + (uint32_t)(k * BLOCK), (uint32_t)(N - 1))];
+    };
+    auto finish_keys = [&](uint32_t (&ik)[CPW]) {
+        uint32_t off = (uint32_t)tid;
+        asm volatile("" : "+v"(off));
+#pragma unroll
         for (int k = 0; k < CPW; ++k) {
-            const uint32_t v = off + (uint32_t)(k * BLOCK);
-            ik[k] = v < (uint32_t)N ? ikey(row, v) : 0xFFFFFFFFu;
+            const uint32_t x = ik[k];
+            ik[k] = off + (uint32_t)(k * BLOCK) < (uint32_t)N ? ~(FLOATS ? score_key(__uint_as_float(x)) : x) : 0xFFFFFFFFu;
         }
     };
 
@@ -116,6 +128,8 @@ __global__ __launch_bounds__(512, CPW <= 20 ? 4 : 2) void binsort_kernel(const B
     auto fresh_tid = [&]() -> int { int t = tid; asm volatile("" : "+v"(t)); return t; };
     while (p < P) {
         int bad = 0;
+        finish_keys(ik);
+        if (tid == 0) sbad = 0;
         // ---- 1. level 1: exponent histogram, 8 copies per value (lane & 7)
         {
             const int t = fresh_tid();
@@ -128,7 +142,7 @@ __global__ __launch_bounds__(512, CPW <= 20 ? 4 : 2) void binsort_kernel(const B
             }
         }
         if (tid == 0) snext = atomicAdd(&prm.ctl->next, 1);                     // (read after the barriers below)
-        __syncthreads();
+        lds_only_barrier();
         // ---- 2. sub-bins per exponent value: thread e owns value e (BLOCK == 512 values); its level-1 words are zeroed again
         {
             static_assert(BLOCK == 512, "one thread per exponent value");
@@ -140,12 +154,12 @@ __global__ __launch_bounds__(512, CPW <= 20 ? 4 : 2) void binsort_kernel(const B
             const uint32_t m = cnt ? (cnt * (uint32_t)kBinSub + (uint32_t)N - 1u) / (uint32_t)N : 0u;      // (cnt <= N < 2^15, kBinSub < 2^15)
             const uint32_t incl = wave_incl_scan_u32(m);
             if ((e & 63) == 63) wsum[w] = incl;
-            __syncthreads();
+            lds_only_barrier();
             uint32_t run = incl - m;
             for (int k = 0; k < w; ++k) run += wsum[k];
             tab[e] = (run << 16) | m;
         }
-        __syncthreads();
+        lds_only_barrier();
         const int pnext = __builtin_amdgcn_readfirstlane(snext);
         // ---- 3. bin + arrival rank of every key.  Each stage of the phase runs over ALL the thread's keys before the next
         //         one starts (table reads, then atomics, then their returns): 16 waves per CU hide no LDS latency, the
@@ -187,11 +201,13 @@ __global__ __launch_bounds__(512, CPW <= 20 ? 4 : 2) void binsort_kernel(const B
         for (int k = 0; k < CPW; ++k) have |= (unsigned long long)(ik[k] != 0xFFFFFFFFu ? 1u : 0u) << k;
         // the next problem's keys travel while this one is scanned, scattered and fixed up
         if (pnext < P) load_keys(pnext, ik);
-        if (__syncthreads_or(bad)) {
+        if (bad) sbad = 1;
+        lds_only_barrier();
+        if (sbad) {
             // not spreadable (ties / quantised scores / exclusions): hand the problem to the LSD kernel
             if (tid == 0) prm.fail_list[atomicAdd(&prm.ctl->nfail, 1)] = p;
             for (int i = tid; i < kBinWords / 4; i += BLOCK) reinterpret_cast<uint4 *>(hist)[i] = make_uint4(0u, 0u, 0u, 0u);
-            __syncthreads();
+            lds_only_barrier();
             p = pnext;
             continue;
         }
@@ -209,7 +225,7 @@ __global__ __launch_bounds__(512, CPW <= 20 ? 4 : 2) void binsort_kernel(const B
             for (int j = 0; j < WPT / 4; ++j) { const uint4 a = hw[j]; tot += bytesum(a.x) + bytesum(a.y) + bytesum(a.z) + bytesum(a.w); }
             const uint32_t incl = wave_incl_scan_u32(tot);
             if (lane == 63) wsum[w] = incl;
-            __syncthreads();
+            lds_only_barrier();
             uint32_t run = incl - tot;
             for (int k = 0; k < w; ++k) run += wsum[k];
             auto enc = [&](uint32_t x) -> uint32_t {
@@ -227,7 +243,7 @@ __global__ __launch_bounds__(512, CPW <= 20 ? 4 : 2) void binsort_kernel(const B
                 hw2[j] = o;
             }
         }
-        __syncthreads();
+        lds_only_barrier();
         // ---- 5. scatter: position = word start + keys in the word's earlier bins + arrival rank
         {
             const int t5 = fresh_tid();
@@ -244,7 +260,7 @@ __global__ __launch_bounds__(512, CPW <= 20 ? 4 : 2) void binsort_kernel(const B
                 if ((have >> k) & 1ull) ent[pos] = (cs[k] << 16) | (r == 0u ? 0x8000u : 0u) | (uint32_t)(t5 + k * BLOCK);
             }
         }
-        __syncthreads();
+        lds_only_barrier();
         // ---- 6. fix-up + store; the counters are cleared for the next problem meanwhile
         for (int i = fresh_tid(); i < kBinWords / 4; i += BLOCK) reinterpret_cast<uint4 *>(hist)[i] = make_uint4(0u, 0u, 0u, 0u);
         {
@@ -320,7 +336,7 @@ __global__ __launch_bounds__(512, CPW <= 20 ? 4 : 2) void binsort_kernel(const B
             }
             if (tid == 0) prm.ncand[p] = N;
         }
-        __syncthreads();
+        lds_only_barrier();
         p = pnext;
     }
 }

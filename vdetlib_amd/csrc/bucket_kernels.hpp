@@ -102,14 +102,7 @@ __device__ __forceinline__ uint32_t bucket_rank_members(uint32_t ekey, bool memb
     return rank;
 }
 
-// workgroup barrier that orders LDS traffic only: the next list's keys stay in flight across it (a plain __syncthreads()
-// waits for every outstanding global load on gfx9: one counter for loads and stores)
-__device__ __forceinline__ void bucket_lds_barrier()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
+__device__ __forceinline__ void bucket_lds_barrier() { lds_only_barrier(); }   // (nms_kernels.hpp)
 
 constexpr uint32_t kBkNeedsRank = 0x80000000u;   // bucket start word: its entries are put in exact order (chunk border / head)
 constexpr uint32_t kBkStartMask = 0x0000FFFFu;

@@ -77,6 +77,16 @@ struct TileDesc {      // one 256-row tile of one group
 
 constexpr int kRowsPerTile = 256;
 constexpr uint16_t kZTag = 0x8000;
+// Workgroup barrier that orders LDS traffic only: global loads stay in flight across it.  A plain __syncthreads() carries a
+// workgroup-scope fence over ALL address spaces, which on gfx9 (one counter for loads and stores) is s_waitcnt vmcnt(0): every
+// outstanding global load -- e.g. the next list's prefetched keys -- is drained at every barrier.
+__device__ __forceinline__ void lds_only_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // bucketed list entries (bucket_kernels.hpp): {ord : 16 | 0x3FFF ^ box index : 14 | first of its bucket : 1} -- the flag sits
 // below the index, so comparing two entries as integers never looks at it (two entries differ in ord or index)
 constexpr uint32_t kBkIdxMask = 0x3FFFu;
@@ -1050,6 +1060,27 @@ __device__ __forceinline__ void lsd_sort_problem(const SortParams &prm, const in
     uint32_t khi[(CPW + 1) / 2];               // high halves of my keys (key v = tid + k * BLOCK), two per register
 #pragma unroll
     for (int k = 0; k < (CPW + 1) / 2; ++k) khi[k] = 0xFFFFFFFFu;
+    // Every key of the thread is requested BEFORE the first one is looked at (round 4, found in the ISA): with the load inside
+    // the per-key `if (v < N) { if (prm.keys) ... }` hipcc kept each load in its own basic block and waited for it right there
+    // -- CPW dependent memory round trips per list (10 at config 2) at the head of a kernel that has nothing else to do yet.
+    uint32_t raw[CPW];
+    uint32_t exb[CPW];
+    {
+        const int lastv = max(N - 1, 0);
+        if (prm.keys) {
+#pragma unroll
+            for (int k = 0; k < CPW; ++k) raw[k] = prm.keys[pr.sbase + min(tid + k * BLOCK, lastv)];
+        } else {
+#pragma unroll
+            for (int k = 0; k < CPW; ++k) raw[k] = __float_as_uint(prm.scores[pr.sbase + (int64_t)min(tid + k * BLOCK, lastv) * pr.sstride]);
+        }
+#pragma unroll
+        for (int k = 0; k < CPW; ++k) exb[k] = 0u;
+        if (prm.excl) {
+#pragma unroll
+            for (int k = 0; k < CPW; ++k) exb[k] = prm.excl[pr.rb + min(tid + k * BLOCK, lastv)];
+        }
+    }
 #pragma unroll
     for (int k = 0; k < CPW; ++k) {
         const int v = tid + k * BLOCK;         // BLOCK * CPW >= N (host)
@@ -1057,15 +1088,15 @@ __device__ __forceinline__ void lsd_sort_problem(const SortParams &prm, const in
             uint32_t ik;
             bool x = false;
             if (prm.keys) {                    // explicit priorities; 0 marks "not a candidate"
-                const uint32_t kk = prm.keys[pr.sbase + v];
+                const uint32_t kk = raw[k];
                 ik = ~kk;
                 x = (kk == 0u);
             } else {
-                const float sc = prm.scores[pr.sbase + (int64_t)v * pr.sstride];
+                const float sc = __uint_as_float(raw[k]);
                 ik = ~score_key(sc);
                 if (prm.use_thr && !(sc > prm.thr)) x = true;
             }
-            if (prm.excl && prm.excl[pr.rb + v]) x = true;
+            if (exb[k]) x = true;
             if (x) { ik = 0xFFFFFFFFu; ++nx; } // real inverted keys are <= 0xFF800000
             keys0[v] = (uint16_t)(ik & 0xFFFFu);
             khi[k >> 1] = (k & 1) ? ((khi[k >> 1] & 0x0000FFFFu) | (ik & 0xFFFF0000u))
