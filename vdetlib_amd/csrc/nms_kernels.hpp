@@ -767,7 +767,7 @@ __global__ __launch_bounds__(kAdjRows) void adj_build_kernel(const float4 *__res
     __shared__ float2 srt[kMaxWordRows];       // regular group: its reach table (which words of a row were written at all)
     __shared__ uint32_t sscan[8];
     __shared__ unsigned long long sbase;
-    __shared__ uint16_t sstage[kAdjStage];
+    __shared__ __attribute__((aligned(16))) uint16_t sstage[kAdjStage];
     const TileDesc td = tiles[blockIdx.x >> 1];
     const GroupDesc gd = groups[td.group];
     const int B = gd.nbox;
@@ -798,10 +798,8 @@ __global__ __launch_bounds__(kAdjRows) void adj_build_kernel(const float4 *__res
         __syncthreads();
     }
     const int wr = __builtin_amdgcn_readfirstlane(v >> 6);     // my word-row (one per wave: 64 aligned rows)
-    // word c of my row exists iff block (min, max) of the upper triangle was in reach (iou_bits_sym_kernel's own test)
-    auto live = [&](int c) -> bool {
-        return !tr || c == wr || (c > wr ? srt[c].y <= srt[wr].x : srt[wr].y <= srt[c].x);
-    };
+    // word c of my row exists iff block (min, max) of the upper triangle was in reach (iou_bits_sym_kernel's own test):
+    // load_batch below
     if (tr && v < B) {
         const float xmin = ixmin, scale = iscale, wmax = iwmax;
         const float wrow = (bx.z - bx.x) + 1.0f;
@@ -817,12 +815,27 @@ __global__ __launch_bounds__(kAdjRows) void adj_build_kernel(const float4 *__res
 
     // the first batch of the row's words is requested before the scan and the slab reservation (a global atomic): their
     // round trips overlap; inside the loop below the NEXT batch is in flight while this one is taken apart
-    uint64_t mm[kAdjBatch];
-    auto load_batch = [&](uint64_t (&dst)[kAdjBatch], int wb) {
+    // (round 4) TWO register sets that swap roles, and loads without a branch of their own (a word outside the row's
+    // window is requested at a clamped address and masked afterwards): with a conditional load per word the compiler
+    // cannot count the requests in flight and waits for ALL of them before the first use, and a set that is copied into
+    // place at the loop's end has to have landed by then -- either way the "prefetch" was a round trip per batch
+    uint64_t ma[kAdjBatch], mb[kAdjBatch];
+    uint32_t oka = 0u, okb = 0u;               // which words of the set exist (bit j: word wb + j)
+    const float2 swr = tr ? srt[wr] : make_float2(0.f, 0.f);
+    auto load_batch = [&](uint64_t (&dst)[kAdjBatch], uint32_t &ok, int wb) {
+        uint32_t okm = 0u;
 #pragma unroll
-        for (int j = 0; j < kAdjBatch; ++j) dst[j] = (wb + j < w1 && live(wb + j)) ? col[(wb + j) * 64] : 0ull;
+        for (int j = 0; j < kAdjBatch; ++j) {      // (no branch, no short circuit: LDS reads first, then sixteen requests in a row)
+            const int c = wb + j;
+            const float2 sc = srt[min(c, kMaxWordRows - 1)];
+            const bool lv = (tr == nullptr) | (c == wr) | (c > wr ? sc.y <= swr.x : swr.y <= sc.x);
+            okm |= ((c < w1) & lv) ? (1u << j) : 0u;
+        }
+        ok = okm;
+#pragma unroll
+        for (int j = 0; j < kAdjBatch; ++j) dst[j] = col[min(wb + j, w1 - 1) * 64];
     };
-    if (tr && v < B) load_batch(mm, w0);
+    if (tr && v < B && w0 < w1) load_batch(ma, oka, w0);
     uint32_t deg = 0, zc = 0;
     if (v < B && tr) {
         deg = rz;                                // regular group: the degree was accumulated by iou_bits_sym_kernel
@@ -877,23 +890,20 @@ __global__ __launch_bounds__(kAdjRows) void adj_build_kernel(const float4 *__res
             wmeta[gd.box_off + vo].row = make_uint4(p, tot, 0u, 0u);
         }
         uint32_t q = lofs;
-        // words in batches of 8, all loads issued before the serial bit loops (inside the loop each
-        // load would be waited for on its own)
-        if (!tr) load_batch(mm, w0);
-        for (int wb = w0; wb < w1; wb += kAdjBatch) {
-            uint64_t nx[kAdjBatch];
-            load_batch(nx, wb + kAdjBatch);          // (all zero past w1)
-            if (staged) {
-                // (round 3) every half word of the batch gets its place in the stage from a prefix sum of the popcounts, so the
-                // 2 * kAdjBatch extraction chains are independent of each other: at 2 waves per SIMD the kernel is bound by the
-                // LATENCY of its dependent instructions (find-first-set -> store -> clear), not by their number.  A row has
-                // ~1.2 neighbours per 32 columns: four unconditional slots per half word, a loop for what is left.
+        if (!tr && w0 < w1) load_batch(ma, oka, w0);
+        if (staged) {
+            // (round 3) every half word of the batch gets its place in the stage from a prefix sum of the popcounts, so the
+            // 2 * kAdjBatch extraction chains are independent of each other: at 2 waves per SIMD the kernel is bound by the
+            // LATENCY of its dependent instructions (find-first-set -> store -> clear), not by their number.  A row has
+            // ~1.2 neighbours per 32 columns: four unconditional slots per half word, a loop for what is left.
+            auto stage_batch = [&](const uint64_t (&m)[kAdjBatch], uint32_t ok, int wb) {
                 uint32_t qs = q;
 #pragma unroll
                 for (int j = 0; j < kAdjBatch; ++j) {
 #pragma unroll
                     for (int hf = 0; hf < 2; ++hf) {
-                        uint32_t h = hf ? (uint32_t)(mm[j] >> 32) : (uint32_t)mm[j];
+                        uint32_t h = hf ? (uint32_t)(m[j] >> 32) : (uint32_t)m[j];
+                        h = ((ok >> j) & 1u) ? h : 0u;
                         const uint32_t col0 = (uint32_t)((wb + j) * 64 + hf * 32);
                         uint32_t qx = qs;
                         qs += (uint32_t)__popc(h);
@@ -910,26 +920,29 @@ __global__ __launch_bounds__(kAdjRows) void adj_build_kernel(const float4 *__res
                     }
                 }
                 q = qs;
-#pragma unroll
-                for (int j = 0; j < kAdjBatch; ++j) mm[j] = nx[j];
-                continue;
+            };
+            for (int wb = w0; wb < w1; wb += 2 * kAdjBatch) {
+                load_batch(mb, okb, wb + kAdjBatch);         // (nothing exists past w1)
+                stage_batch(ma, oka, wb);
+                if (wb + kAdjBatch >= w1) break;
+                load_batch(ma, oka, wb + 2 * kAdjBatch);
+                stage_batch(mb, okb, wb + kAdjBatch);
             }
+        } else {
+            // a slab too large for the stage (rare): entries go straight to the pool, a dependent translation per edge
+            for (int wb = w0; wb < w1; wb += kAdjBatch) {
+                if (wb != w0) load_batch(ma, oka, wb);
 #pragma unroll
-            for (int j = 0; j < kAdjBatch; ++j) {
-                uint64_t m = mm[j];
-                const int w = wb + j;
-                while (m) {
-                    const int k = __ffsll((unsigned long long)m) - 1;
-                    // staged slabs keep x-ranks here and are translated to box indices in the coalesced
-                    // copy-out below (256 independent gathers in flight instead of one dependent global
-                    // load per edge inside this serial bit loop)
-                    if (staged) sstage[q++] = (uint16_t)(w * 64 + k);
-                    else adj[p++] = tr ? tr[w * 64 + k] : (uint16_t)(w * 64 + k);
-                    m &= m - 1;
+                for (int j = 0; j < kAdjBatch; ++j) {
+                    uint64_t m = ((oka >> j) & 1u) ? ma[j] : 0ull;
+                    const int w = wb + j;
+                    while (m) {
+                        const int k = __ffsll((unsigned long long)m) - 1;
+                        adj[p++] = tr ? tr[w * 64 + k] : (uint16_t)(w * 64 + k);
+                        m &= m - 1;
+                    }
                 }
             }
-#pragma unroll
-            for (int j = 0; j < kAdjBatch; ++j) mm[j] = nx[j];
         }
         if (zc) {  // rare: degenerate boxes.  Recompute which partners have a zero union.
             const float4 brow = boxes[gd.box_off + v];
@@ -950,10 +963,21 @@ __global__ __launch_bounds__(kAdjRows) void adj_build_kernel(const float4 *__res
     }
     if (staged) {   // one coalesced copy of the tile's slab instead of 256 interleaved 2-byte streams
         __syncthreads();
+        // (round 4) eight entries per thread and step: lists are padded to multiples of 8 entries and slabs are sums of such,
+        // so the slab is a whole number of aligned 16-byte groups -- one LDS read, eight independent translations in
+        // flight, one store (before: one 2-byte store and one dependent translation per entry, four in flight)
+        const uint4 *s4 = reinterpret_cast<const uint4 *>(sstage);
+        uint4 *d4 = reinterpret_cast<uint4 *>(adj + base);
+        const uint32_t n8 = tile_total >> 3;
         if (tr) {   // (zero-union entries only exist on irregular frames, which have no x-index: tr == null)
-            for (uint32_t i = tid; i < tile_total; i += kAdjRows) adj[base + i] = tr[sstage[i]];
+            for (uint32_t i = tid; i < n8; i += kAdjRows) {
+                const uint4 e = s4[i];
+                const uint32_t a0 = tr[e.x & 0xFFFFu], a1 = tr[e.x >> 16], a2 = tr[e.y & 0xFFFFu], a3 = tr[e.y >> 16];
+                const uint32_t a4 = tr[e.z & 0xFFFFu], a5 = tr[e.z >> 16], a6 = tr[e.w & 0xFFFFu], a7 = tr[e.w >> 16];
+                d4[i] = make_uint4(a0 | (a1 << 16), a2 | (a3 << 16), a4 | (a5 << 16), a6 | (a7 << 16));
+            }
         } else {
-            for (uint32_t i = tid; i < tile_total; i += kAdjRows) adj[base + i] = sstage[i];
+            for (uint32_t i = tid; i < n8; i += kAdjRows) d4[i] = s4[i];
         }
     }
 }

@@ -1599,47 +1599,68 @@ __device__ __forceinline__ bool rescore_adj_one(const int64_t wv, const int l, c
     const int fc = (int)(wv / T);
     const int f = fc / C, c = fc - f * C;
     const int64_t e = ((int64_t)c * T + t) * F + f;
+    // (round 4) the box is a chain of dependent reads (row -> node -> box + list head -> list -> boxes -> scores): what does
+    // not depend on each other is requested together and without a branch of its own -- a load inside a condition is
+    // waited for on the spot (the compiler also sinks an early load to its first conditional use)
     const float *row = tracks + e * 5;
     const float r0 = row[0], r1 = row[1], r2 = row[2], r3 = row[3];
-    if (t >= ntracks[c] || r0 != r0) {
+    const int nt = ntracks[c];
+    const uint32_t gf = group_flags[f];
+    const int jn = nodes[e];
+    asm volatile("" :: "v"(r3), "v"(jn), "v"(nt), "v"(gf));     // (all seven in flight before the first is looked at)
+    if (t >= nt || r0 != r0) {
         if (l == 0) out_score[e] = __longlong_as_double(0x7FF8000000000000ll);
         if (l < 4) out_box[e * 4 + l] = __uint_as_float(0x7FC00000u);
         return true;
     }
     const double p[4] = {(double)r0, (double)r1, (double)r2, (double)r3};
+    const bool jok = (gf & kFlagRegular) && jn >= 0 && jn < B;
+    const int j = jok ? jn : 0;
+    const float4 bj = boxes[(int64_t)f * B + j];
+    const uint2 meta = row_meta[(int64_t)f * B + j];
+    asm volatile("" :: "v"(bj.w), "v"(meta.y));
     bool ok = false;
-    int j = -1;
-    if (group_flags[f] & kFlagRegular) {
-        j = nodes[e];
-        if (j >= 0 && j < B) {
-            const float4 bj = boxes[(int64_t)f * B + j];
-            const float4 tj = trunc4(bj);
-            if (tj.x == r0 && tj.y == r1 && tj.z == r2 && tj.w == r3) {
-                const double q[4] = {(double)bj.x, (double)bj.y, (double)bj.z, (double)bj.w};
-                ok = iou_f64_pair(p, q) > min_self_iou;
-            }
+    if (jok) {
+        const float4 tj = trunc4(bj);
+        if (tj.x == r0 && tj.y == r1 && tj.z == r2 && tj.w == r3) {
+            const double q[4] = {(double)bj.x, (double)bj.y, (double)bj.z, (double)bj.w};
+            ok = iou_f64_pair(p, q) > min_self_iou;
         }
     }
     if (!ok) return false;     // (uniform over the 16 lanes of the box)
-    const uint2 meta = row_meta[(int64_t)f * B + j];
     const int n = (int)meta.y + 1;                // the neighbours + j itself
     double bs = 0.0;
     int64_t bi = -1;
     const float pa = ((r2 - r0) + 1.0f) * ((r3 - r1) + 1.0f);
     const float thr_lo = (float)thres - 1.0e-3f;  // f32 screen before the f64 IoU, as in the window scan
-    for (int i = l; i < n; i += 16) {
-        const int64_t k = i == 0 ? j : (int64_t)(adj[meta.x + (i - 1)] & 0x7FFF);
-        const float4 bb = boxes[(int64_t)f * B + k];
-        const float sw = (fminf(r2, bb.z) - fmaxf(r0, bb.x)) + 1.0f;
-        const float sh = (fminf(r3, bb.w) - fmaxf(r1, bb.y)) + 1.0f;
-        if (!(sw > 0.0f && sh > 0.0f)) continue;
-        const float sinter = sw * sh;
-        const float suni = (pa + box_area(bb)) - sinter;
-        if (!(sinter > thr_lo * suni)) continue;
-        const double qq[4] = {(double)bb.x, (double)bb.y, (double)bb.z, (double)bb.w};
-        if (iou_f64_pair(p, qq) > thres) {
-            const double s = (double)scores[((int64_t)f * B + k) * C + c];
-            if (argmax_better(s, k, bs, bi)) { bs = s; bi = k; }
+    constexpr int kU = 4;                         // candidates per lane and memory round trip
+    for (int i0 = l; i0 < n; i0 += 16 * kU) {
+        int kk[kU];
+        float4 bbs[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int i = min(i0 + 16 * u, n - 1);
+            const int a = (int)(adj[meta.x + (uint32_t)max(i - 1, 0)] & 0x7FFF);
+            kk[u] = i == 0 ? j : a;
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) bbs[u] = boxes[(int64_t)f * B + kk[u]];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            if (i0 + 16 * u >= n) continue;
+            const float4 bb = bbs[u];
+            const int64_t k = kk[u];
+            const float sw = (fminf(r2, bb.z) - fmaxf(r0, bb.x)) + 1.0f;
+            const float sh = (fminf(r3, bb.w) - fmaxf(r1, bb.y)) + 1.0f;
+            if (!(sw > 0.0f && sh > 0.0f)) continue;
+            const float sinter = sw * sh;
+            const float suni = (pa + box_area(bb)) - sinter;
+            if (!(sinter > thr_lo * suni)) continue;
+            const double qq[4] = {(double)bb.x, (double)bb.y, (double)bb.z, (double)bb.w};
+            if (iou_f64_pair(p, qq) > thres) {
+                const double s = (double)scores[((int64_t)f * B + k) * C + c];
+                if (argmax_better(s, k, bs, bi)) { bs = s; bi = k; }
+            }
         }
     }
 #pragma unroll

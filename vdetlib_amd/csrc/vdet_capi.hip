@@ -153,8 +153,9 @@ struct vdet_ctx {
     bool link_memo = true;        // VDET_LINK_MEMO=0: every link step scans (A-B knob / tests)
     bool track_loop = true;       // VDET_TRACK_LOOP=0: four launches per track (pick / link / suppress / commit) instead of one persistent
                                   // block per class for the whole tracking loop (A-B knob / tests)
-    bool binsort = false;         // VDET_BINSORT=1: untied volume columns by the equalised counting sort (binsort_kernels.hpp) instead of the
-                                  // LSD radix kernel.  Bit-identical; measured at the LSD kernel's speed (3.32 vs 3.37 ms per c2 video), so off
+    bool binsort = true;          // untied volume columns by the equalised counting sort (binsort_kernels.hpp); VDET_BINSORT=0: the LSD radix
+                                  // kernel.  Bit-identical.  Round 4, once every key of a thread is requested before the first is used:
+                                  // 2.31 vs 2.90 ms per c2 video (both were 3.2-3.3 before), so on
     bool last_sort_binned = false;   // the last per-(frame, class) sort went through binsort_kernel (vdet_query 9)
     DevBuf vidtab;                // batched videos: {first frame, frames} per video
     std::vector<VidDesc> h_vids;
