@@ -53,8 +53,11 @@ def main():
         rows.append((k, max(nf, nw), f, w, hbm))
         for pat, stage in STAGES:
             if pat in k:
-                js[stage] = {"hbm_bytes_per_launch": hbm, "fetch_KiB_raw": f, "write_KiB": w, "kernel": k,
-                             "launches_sampled": max(nf, nw)}
+                # (several kernels can share a stage -- the counting sort and the LSD kernel's small x1 sorts: the one that
+                #  moves more bytes over the run stands for the stage)
+                if stage not in js or js[stage]["hbm_bytes_per_launch"] * js[stage]["launches_sampled"] < hbm * max(nf, nw):
+                    js[stage] = {"hbm_bytes_per_launch": hbm, "fetch_KiB_raw": f, "write_KiB": w, "kernel": k,
+                                 "launches_sampled": max(nf, nw)}
                 break
     with open(out_csv, "w") as fo:
         fo.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes, --kernel-trace only);"

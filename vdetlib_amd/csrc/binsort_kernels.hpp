@@ -334,6 +334,8 @@ __global__ __launch_bounds__(512, CPW <= 20 ? 4 : 2) void binsort_kernel(const B
                 for (int u = 0; u < 2; ++u)
                     if (q0 + u * 64 + lane6 < N) out[npos[u]] = (uint16_t)(me[u] & 0x7FFFu);
             }
+            // every key of the list is a candidate HERE: a list with an excluded key (NaN score, key 0xFFFFFFFF -- `bad` in
+            // phase 1, decided on the device, not by the host's gating) was handed to the LSD kernel, which counts its own
             if (tid == 0) prm.ncand[p] = N;
         }
         lds_only_barrier();

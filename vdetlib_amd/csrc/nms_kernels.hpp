@@ -746,7 +746,7 @@ struct WalkMeta {
 constexpr int kMaxWordRows = 320;       // 64-box word-rows of a regular frame (B <= 17 408: 272)
 constexpr int kAdjRows = 128;
 #ifndef VDET_ADJ_BATCH
-#define VDET_ADJ_BATCH 16
+#define VDET_ADJ_BATCH 8
 #endif
 constexpr int kAdjBatch = VDET_ADJ_BATCH;   // bit-matrix words loaded per memory round trip (a row's window is ~42 words)
 constexpr int kAdjStage = 16384;     // u16 entries staged in LDS per block (32 KB)
@@ -922,10 +922,11 @@ __global__ __launch_bounds__(kAdjRows) void adj_build_kernel(const float4 *__res
                 q = qs;
             };
             for (int wb = w0; wb < w1; wb += 2 * kAdjBatch) {
-                load_batch(mb, okb, wb + kAdjBatch);         // (nothing exists past w1)
+                // (a prefetch past the wave's last window is skipped: a wave-uniform branch, the requests stay countable)
+                if (__ballot(wb + kAdjBatch < w1)) load_batch(mb, okb, wb + kAdjBatch); else okb = 0u;
                 stage_batch(ma, oka, wb);
                 if (wb + kAdjBatch >= w1) break;
-                load_batch(ma, oka, wb + 2 * kAdjBatch);
+                if (__ballot(wb + 2 * kAdjBatch < w1)) load_batch(ma, oka, wb + 2 * kAdjBatch); else oka = 0u;
                 stage_batch(mb, okb, wb + kAdjBatch);
             }
         } else {

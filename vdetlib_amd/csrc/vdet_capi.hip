@@ -708,6 +708,8 @@ int launch_sort_walk(vdet_ctx *c, const SortWalkArgs &a, int nmax, int64_t order
         // problem on the device -- lands on a list the LSD kernel works off afterwards (normally empty)
         const size_t bin_lds = binsort_lds_bytes(std::max(nmax, 1));
         const int bin_cpw = nmax <= 4096 ? 8 : nmax <= 10240 ? 20 : 36;      // keys per thread, 512 threads
+        // (threshold / top-k / exclusion lists change ncand: those go to the LSD kernel; a NaN inside an otherwise plain list is
+        //  caught per list on the device, binsort_kernels.hpp phase 1)
         const bool use_bin = c->binsort && (sp.mode == 1 || sp.mode == 3) && a.topk == 0 && !a.use_thr && !a.excl && block == 1024 &&
                              nmax <= 512 * bin_cpw && bin_lds + 4096 <= c->dyn_lds_max && sp.npass == 4;
         // round 4: cut the lists into score-ordered buckets instead of sorting them (bucket_kernels.hpp) wherever the packed
