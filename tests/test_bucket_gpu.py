@@ -11,13 +11,13 @@ import synth
 pytestmark = pytest.mark.gpu
 
 
-def _ctx():
-    """a context with the bucket path on (VDET_BUCKETS is read at vdet_create; the default is the LSD sort)"""
+def _ctx(buckets="1"):
+    """a context with the bucket path on (VDET_BUCKETS is read at vdet_create; the default is sorted lists)"""
     import os
     import torch
     from vdetlib_amd import _lib
     old = os.environ.get("VDET_BUCKETS")
-    os.environ["VDET_BUCKETS"] = "1"
+    os.environ["VDET_BUCKETS"] = buckets
     try:
         return _lib.Context(torch.cuda.current_device())
     finally:
@@ -171,7 +171,7 @@ def test_tracking_orders_every_bucket_on_demand(oracle):
 
 
 def test_bucket_path_and_lsd_path_agree_at_the_limit():
-    """B = 16 384 (the entry format's index field) against the LSD sort of the same volume (a default context)"""
+    """B = 16 384 (the entry format's index field) against the sorted lists of the same volume (the default path)"""
     import os
     import torch
     from vdetlib_amd import ops
@@ -186,8 +186,7 @@ def test_bucket_path_and_lsd_path_agree_at_the_limit():
     a = _ctx()
     ia, ca = ops.nms_volume(boxes, scores, 0.3, ctx=a)
     assert a.query(10) == 1 and a.query(11) == 0
-    from vdetlib_amd import _lib
-    b = _lib.Context(torch.cuda.current_device())           # the default: LSD lists
+    b = _ctx("0")                                            # sorted lists (the default, whatever the suite's environment says)
     ib, cb = ops.nms_volume(boxes, scores, 0.3, ctx=b)
     assert b.query(10) == 0
     assert torch.equal(ca, cb) and torch.equal(ia, ib)

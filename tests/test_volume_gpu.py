@@ -300,3 +300,21 @@ def test_packed_walk_random_sweep(torch_cuda, monkeypatch):
         i8, c8 = ops.nms_volume(tb, ts, t, score_thresh=st, ctx=cx8)
         assert torch.equal(c0, c1) and torch.equal(i0, i1), (it, B, F, C, t, kind)
         assert torch.equal(c0, c8) and torch.equal(i0, i8), (it, B, F, C, t, kind)
+
+
+@pytest.mark.parametrize("kind", ["int", "frac"])
+def test_dense_frames_whose_slabs_miss_the_k2_stage(torch_cuda, oracle, kind):
+    """Frames whose boxes all overlap (degree ~ B / 2): the lists of 128 rows do not fit adj_build_kernel's 32 KB stage, so
+    the rows go straight to the pool (the kernel's second extraction path, lists > 128 entries in the walk), next to an
+    ordinary sparse frame in the same volume -- every (frame, class) against the oracle."""
+    rng = np.random.RandomState(808 + (kind == "frac"))
+    F, B, C = 3, 700, 3
+    x, y = rng.uniform(0, 120, (F, B)), rng.uniform(0, 60, (F, B))
+    boxes = np.stack([x, y, x + rng.uniform(60, 200, (F, B)), y + rng.uniform(60, 200, (F, B))], 2).astype(np.float32)
+    sparse, _ = synth.video(4711, 1, B, C)
+    boxes[1] = sparse[0]                                  # one ordinary frame between the dense ones
+    if kind == "int":
+        boxes = np.round(boxes)
+    scores = rng.rand(F, B, C).astype(np.float32)
+    for t in (0.1, 0.3, 0.6):
+        _check_volume(torch_cuda, oracle, boxes, scores, t)

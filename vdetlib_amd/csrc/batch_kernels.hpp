@@ -88,7 +88,7 @@ __device__ __forceinline__ VidView vid_view(const BatchTrack &bt, const int v)
 __global__ __launch_bounds__(256) void batch_warm_anchors_kernel(const BatchTrack bt)
 {
     const VidView w = vid_view(bt, blockIdx.y);
-    track_warm_anchors_body(blockIdx.x, w.keys, w.lists, w.cnt, w.F, bt.B, bt.C, w.scores, bt.thres, bt.wm, w.warm, BucketLists{nullptr, nullptr}, WarmExtra{nullptr, 0.f, 0});
+    track_warm_anchors_body(blockIdx.x, w.keys, w.lists, w.cnt, w.F, bt.B, bt.C, w.scores, bt.thres, bt.wm, w.warm, BucketLists{nullptr, nullptr}, WarmExtra{nullptr, 0.f, 0, 0});
 }
 
 // grid (ceil(Fmax * B * kFillLanes / 256), 2, V): the whole link table of every video (link_fill_node)

@@ -1046,6 +1046,7 @@ struct WarmExtra {
     const float4 *boxes;      // [F*B] (null: raw candidates only)
     float t32;                // the NMS threshold of the lists
     int m_raw;                // slots filled by raw rank
+    int max_distinct;         // stop predicting once this many DISTINCT objects have an anchor (= max_tracks: the loop takes no more)
 };
 constexpr int kWarmCoherent = 4;
 constexpr int kWarmMax = 32;
@@ -1132,6 +1133,10 @@ __device__ __forceinline__ void track_warm_anchors_body(const int c, const uint3
     int pos[2] = {0, 0};              // per frame of this thread (F <= 512 here: the host limits the extra slots to such videos)
     for (int k = m_raw; k < m; ++k) {
         const int npb = snpb;
+        if (npb >= wx.max_distinct) {     // every tubelet the loop can take has its anchor: more chains would be scanned for nothing
+            if (tid == 0) for (int r = k; r < m; ++r) warm[c * m + r] = -1;
+            return;
+        }
         uint32_t bk = 0;
         int bflat = -1;
         int h = 0;

@@ -1656,7 +1656,7 @@ int vdet_nms_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scor
             hipLaunchKernelGGL(track_warm_anchors_kernel, dim3((unsigned)C), dim3(256), 0, ws, c->tkeys.as<uint32_t>(),
                                c->order.as<uint16_t>(), c->ncand.as<int32_t>(), (int)F, (int)B, (int)C, d_scores, thres, wm,
                                c->linkwarm.as<int32_t>(), bkl,
-                               WarmExtra{coherent_slots ? reinterpret_cast<const float4 *>(d_boxes) : nullptr, t32, wm_raw});
+                               WarmExtra{coherent_slots ? reinterpret_cast<const float4 *>(d_boxes) : nullptr, t32, wm_raw, max_tracks});
             const int32_t *w_order = nullptr;
             if (c->link_lpt && !filled) {       // longest chains first
                 HIPCHK(c, c->linkorder.reserve((size_t)C * wm * 2 * 4));
