@@ -342,7 +342,7 @@ def test_track_volume_random_sweep(oracle, seed):
 
 @pytest.mark.parametrize("knob", ["VDET_FORCE_GENERAL", "VDET_NO_INDEX", "VDET_NO_TRANSPOSE", "VDET_NO_LAZY",
                                   "VDET_WAVE_TRANSPOSE=0", "VDET_ATOMIC_RANK=0", "VDET_LINK_MEMO=0", "VDET_LINK_THREADS=64",
-                                  "VDET_LINK_THREADS=128", "VDET_LINK_WARM=0", "VDET_LINK_MAXB=16", "VDET_LINK_U16=0", "VDET_LINK_LPT=0", "VDET_GRAPH_PIPE=1", "VDET_AUX_STREAM=1", "VDET_WALK_CAREFUL=1", "VDET_WALK_PACKED=0", "VDET_WALK_PACKED=2", "VDET_SERIES_SERIAL=1", "VDET_LINK_MATERIALIZE=0", "VDET_RESCORE_ADJ=0", "VDET_TRACK_LOOP=0", "VDET_BINSORT=0"])
+                                  "VDET_LINK_THREADS=128", "VDET_LINK_WARM=0", "VDET_LINK_MAXB=16", "VDET_LINK_U16=0", "VDET_LINK_LPT=0", "VDET_GRAPH_PIPE=1", "VDET_AUX_STREAM=1", "VDET_WALK_CAREFUL=1", "VDET_WALK_PACKED=0", "VDET_WALK_PACKED=2", "VDET_SERIES_SERIAL=1", "VDET_LINK_MATERIALIZE=0", "VDET_RESCORE_ADJ=0", "VDET_TRACK_LOOP=0", "VDET_BINSORT=0", "VDET_LINK_COHERENT=0", "VDET_WARM_THREADS=64", "VDET_WARM_THREADS=128"])
 def test_alternative_kernel_paths_agree(monkeypatch, knob):
     """Every A/B knob selects a different kernel path for the same result (general predicate kernel,
     no x-index, strided key reads, eager track_det_nms, ballot transposition in K1s, ballot ranks in

@@ -880,7 +880,7 @@ __device__ __forceinline__ void track_link_memo_body(const int chain, const int 
 }
 
 template <int LT, int MODE, int MAXB>
-__global__ __launch_bounds__(LT, (MODE == 1 && LT == 256 && MAXB == 8) ? 5 : 1) void track_link_memo_kernel(const float4 *__restrict__ boxes, int F, int B, int max_tracks,
+__global__ __launch_bounds__(LT, (MODE == 1 && MAXB == 8) ? 5 : 1) void track_link_memo_kernel(const float4 *__restrict__ boxes, int F, int B, int max_tracks,
                                                              float link_t32, int reach, const TrackState *__restrict__ st,
                                                              float *__restrict__ tracks,
                                                              const uint32_t *__restrict__ group_flags,

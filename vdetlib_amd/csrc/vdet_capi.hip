@@ -142,6 +142,7 @@ struct vdet_ctx {
     bool force_general = false;   // VDET_FORCE_GENERAL=1: disable the symmetric fast kernel (tests)
     bool topk_attr_set = false;
     int link_threads = 256;       // VDET_LINK_THREADS=64|128|256: threads per link chain (A-B knob)
+    int warm_threads = 256;       // VDET_WARM_THREADS=64|128|256: threads per chain of the memo warm-up (more chains resident at once)
     bool series_serial = false;   // VDET_SERIES_SERIAL=1: one thread per tubelet series (A-B knob / tests)
     bool link_materialize = true; // VDET_LINK_MATERIALIZE=0: the tracking loop walks every tubelet itself (A-B knob / tests)
     int walk_packed = 1;          // VDET_WALK_PACKED=0: regular frames walk one survivor at a time; 1 (default): eight candidates per pass;
@@ -192,10 +193,12 @@ struct vdet_ctx {
     bool link_u16 = true;         // VDET_LINK_U16=0: the LINK window scans read the float4 index on every frame (A-B knob)
     int link_maxb = 8;            // VDET_LINK_MAXB=8|16: boxes per thread and batch in the warm-up's window scans (A-B knob)
     bool batch_chains = false;    // VDET_BATCH_CHAINS=1: batched small videos with the link table up front still predict + materialise chains (A-B knob)
-    bool link_coherent = false;   // VDET_LINK_COHERENT=1: extra warm-anchor slots for coherent videos (track_warm_anchors_body).  A LATENCY
-                                  // option: a coherent config-2 video alone 20.2 -> 18.6 ms (the loop's serial scans move into the
-                                  // chip-filling warm-up), but with 4 videos in flight 15.4 -> 17.1 ms (the serial scans were hidden
-                                  // under the other videos, the warm-up's are not) and +0.1 ms on independent frames, so off
+    bool link_coherent = true;    // extra warm-anchor slots for coherent videos (track_warm_anchors_body; VDET_LINK_COHERENT=0: none).  The
+                                  // predictor stops at max_tracks distinct objects, so the number of scanned link steps stays what it was
+                                  // (656 k on the coherent config-2 video) but they move from the loop's serial scans into the chip-filling
+                                  // warm-up: that video alone 18.8 -> 15.6 ms, with 4 in flight 14.0 -> 13.8; independent frames unchanged
+                                  // (their raw candidates do not repeat each other: the extra slots stay empty).  Before the stop -- 1.04 M
+                                  // steps scanned -- it was a latency option only (4 in flight 15.4 -> 17.1)
     int link_fill = 1024;         // VDET_LINK_FILL=b: frames of up to b proposals get their WHOLE link table computed up front (link_fill_kernel:
                                   // every chain is pointer chasing afterwards, no anchor prediction, no warm-up scans); 0: never (A-B knob / tests)
     int link_warm = -1;           // VDET_LINK_WARM=m: chains warmed per class (-1: max_tracks + 2; 0: none)
@@ -996,6 +999,7 @@ int vdet_create(vdet_ctx **out, int device)
     if (const char *e = getenv("VDET_LINK_LPT")) c->link_lpt = atoi(e) != 0;
     if (const char *e = getenv("VDET_GRAPH_PIPE")) c->graph_pipe = atoi(e) != 0;
     if (const char *e = getenv("VDET_AUX_STREAM")) c->use_aux = atoi(e) != 0;
+    if (const char *e = getenv("VDET_WARM_THREADS")) { const int v = atoi(e); if (v == 64 || v == 128 || v == 256) c->warm_threads = v; }
     if (const char *e = getenv("VDET_LINK_THREADS")) { const int v = atoi(e); if (v == 64 || v == 128 || v == 256) c->link_threads = v; }
     if (const char *e = getenv("VDET_DEBUG_SYNC")) c->debug_sync = atoi(e) != 0;
     {   // probe: do returning LDS atomics resolve same-address lanes in ascending lane order?
@@ -1664,14 +1668,17 @@ int vdet_nms_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scor
                                    reach, c->linkorder.as<int32_t>());
                 w_order = c->linkorder.as<int32_t>();
             }
-#define VDET_WARM(MB) hipLaunchKernelGGL((track_link_memo_kernel<256, 1, MB>), dim3((unsigned)(C * wm), 2), dim3(256), 0, ws, \
+#define VDET_WARM_LT(LT, MB) hipLaunchKernelGGL((track_link_memo_kernel<LT, 1, MB>), dim3((unsigned)(C * wm), 2), dim3(LT), 0, ws, \
                                reinterpret_cast<const float4 *>(d_boxes), (int)F, (int)B, max_tracks, link_t32, reach, \
                                (const TrackState *)nullptr, (float *)nullptr, w_flags, w_ix, link_thres, \
                                c->linkmemo.as<unsigned long long>(), c->linkstats.as<unsigned int>(), c->linkwarm.as<int32_t>(), \
                                (int32_t *)nullptr, w_order)
             if (filled) {}                   // (every step is known already)
-            else if (c->link_maxb == 16) VDET_WARM(16); else VDET_WARM(8);
-#undef VDET_WARM
+            else if (c->link_maxb == 16) VDET_WARM_LT(256, 16);
+            else if (c->warm_threads == 64) VDET_WARM_LT(64, 8);
+            else if (c->warm_threads == 128) VDET_WARM_LT(128, 8);
+            else VDET_WARM_LT(256, 8);
+#undef VDET_WARM_LT
             if (c->link_materialize) {
                 // every step of the warm chains is known now: write each predicted anchor's tubelet ONCE (one wave walks
                 // a chain; all of them side by side), for the tracking loop to copy (the tail of track_pick_kernel)
