@@ -1982,18 +1982,10 @@ __device__ __forceinline__ void walk_list_packed2(const WalkParams &prm, lds_mas
     nk_out = nk;
 }
 
-__global__ __launch_bounds__(256) void walk_kernel(const WalkParams prm)
+// one list (problem p) walked by one wave (w = its index in the block: its slice of the dynamic LDS)
+__device__ __forceinline__ void walk_one(const WalkParams &prm, const int p, unsigned char *smem, const int lane, const int w)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // (the wave index through readfirstlane: hipcc then knows that the problem, its list / frame pointers and every
-    //  address base below are wave-uniform -- scalar registers and saddr loads instead of 64-bit vector address math)
-    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     lds_mask_t mask = lds_mask_ptr(smem, w * prm.wave_words);
-    const int nwaves_total = gridDim.x * 4;
-    // wave-granular XCD mapping: block b -> XCD b % 8; consecutive problems share a frame
-    const int per = nwaves_total >> 3;
-    const int p = (blockIdx.x & 7) * per + (blockIdx.x >> 3) * 4 + w;
-    if (p >= prm.P) return;
     const ProblemRef pr = decode_problem(prm.mode, p, prm.B, prm.C, prm.groups);
     const int N = pr.N, rb = pr.rb;
     const uint16_t *order = prm.order + pr.obase;
@@ -2089,6 +2081,20 @@ __global__ __launch_bounds__(256) void walk_kernel(const WalkParams prm)
     if (lane == 0) prm.keep_cnt[p] = nk;
     if ((int64_t)nk > cap && lane == 0) atomicOr(prm.status, kStCap);
     if (__ballot(bad != 0) && lane == 0) atomicOr(prm.status, kStDivZero);
+}
+
+__global__ __launch_bounds__(256) void walk_kernel(const WalkParams prm)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // (the wave index through readfirstlane: hipcc then knows that the problem, its list / frame pointers and every
+    //  address base below are wave-uniform -- scalar registers and saddr loads instead of 64-bit vector address math)
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwaves_total = gridDim.x * 4;
+    // wave-granular XCD mapping: block b -> XCD b % 8; consecutive problems share a frame
+    const int per = nwaves_total >> 3;
+    const int p = (blockIdx.x & 7) * per + (blockIdx.x >> 3) * 4 + w;
+    if (p >= prm.P) return;
+    walk_one(prm, p, smem, lane, w);
 }
 
 // Caller-supplied candidate lists (vdet_nms_volume_ordered) are walked as they come: a count above B or an index >= B would

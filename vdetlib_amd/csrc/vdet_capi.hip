@@ -16,6 +16,7 @@
 #include "../../include/vdet_hip.h"
 #include "nms_kernels.hpp"
 #include "binsort_kernels.hpp"
+#include "small_kernels.hpp"
 #include "bucket_kernels.hpp"
 #include "detnms_kernels.hpp"
 #include "temporal_kernels.hpp"
@@ -142,6 +143,7 @@ struct vdet_ctx {
     bool force_general = false;   // VDET_FORCE_GENERAL=1: disable the symmetric fast kernel (tests)
     bool topk_attr_set = false;
     int link_threads = 256;       // VDET_LINK_THREADS=64|128|256: threads per link chain (A-B knob)
+    bool small_lists = true;      // VDET_SMALL_LISTS=0: frames of <= 384 boxes through the large-list sort and walk too (small_kernels.hpp; A-B knob)
     int warm_threads = 256;       // VDET_WARM_THREADS=64|128|256: threads per chain of the memo warm-up (more chains resident at once)
     bool series_serial = false;   // VDET_SERIES_SERIAL=1: one thread per tubelet series (A-B knob / tests)
     bool link_materialize = true; // VDET_LINK_MATERIALIZE=0: the tracking loop walks every tubelet itself (A-B knob / tests)
@@ -817,7 +819,24 @@ int launch_sort_walk(vdet_ctx *c, const SortWalkArgs &a, int nmax, int64_t order
     } else if (c->lists_bucketed && !a.order_in) {
         return fail(c, VDET_EHIP, "internal: bucketed lists without the packed walk");
     }
-    {
+    // frames of at most 384 boxes: one LANE per list, the frames' rows in LDS (small_kernels.hpp); the lists of irregular frames
+    // are left to the general walk (walk_rest_kernel: normally nothing)
+    const bool small_walk = c->small_lists && a.mode != 2 && nmax <= kSmallMax && wp.group_flags && !wp.ent && a.C > 0 && a.P % a.C == 0;
+    if (small_walk) {
+        const int G = a.P / a.C;
+        const int nq = nmax <= 128 ? 1 : nmax <= 256 ? 2 : 3;
+        const int nm = std::max(nmax, 1);
+        const size_t row_bytes = (size_t)nm * 4 * nq * 4;
+        const int fpw = a.C > 32 ? 1 : (int)std::max<size_t>(1, std::min<size_t>((size_t)(64 / a.C), (size_t)(44 * 1024) / row_bytes));
+        const size_t lds_bytes = (size_t)fpw * row_bytes + (size_t)64 * (4 * nq + 1) * 4;
+        const int grid = (G + fpw - 1) / fpw;
+        StageTimer tm(c, ST_WALK);
+        if (nq == 1) hipLaunchKernelGGL(small_walk_kernel<1>, dim3(grid), dim3(64), lds_bytes, c->stream, wp, G, fpw, nm);
+        else if (nq == 2) hipLaunchKernelGGL(small_walk_kernel<2>, dim3(grid), dim3(64), lds_bytes, c->stream, wp, G, fpw, nm);
+        else hipLaunchKernelGGL(small_walk_kernel<3>, dim3(grid), dim3(64), lds_bytes, c->stream, wp, G, fpw, nm);
+        if (!c->all_regular)      // (asynchronous build: not known on the host -- the kernel looks at the frames' flags)
+            hipLaunchKernelGGL(walk_rest_kernel, dim3(std::min(G, 4 * c->n_cu)), dim3(256), (size_t)wp.wave_words * 4 * 4, c->stream, wp, G);
+    } else {
         const int nblk = (((a.P + 3) / 4) + 7) & ~7;
         StageTimer tm(c, ST_WALK);
         hipLaunchKernelGGL(walk_kernel, dim3(nblk), dim3(256), (size_t)wp.wave_words * 4 * 4, c->stream, wp);
@@ -999,6 +1018,7 @@ int vdet_create(vdet_ctx **out, int device)
     if (const char *e = getenv("VDET_LINK_LPT")) c->link_lpt = atoi(e) != 0;
     if (const char *e = getenv("VDET_GRAPH_PIPE")) c->graph_pipe = atoi(e) != 0;
     if (const char *e = getenv("VDET_AUX_STREAM")) c->use_aux = atoi(e) != 0;
+    if (const char *e = getenv("VDET_SMALL_LISTS")) c->small_lists = atoi(e) != 0;
     if (const char *e = getenv("VDET_WARM_THREADS")) { const int v = atoi(e); if (v == 64 || v == 128 || v == 256) c->warm_threads = v; }
     if (const char *e = getenv("VDET_LINK_THREADS")) { const int v = atoi(e); if (v == 64 || v == 128 || v == 256) c->link_threads = v; }
     if (const char *e = getenv("VDET_DEBUG_SYNC")) c->debug_sync = atoi(e) != 0;
