@@ -724,11 +724,22 @@ int launch_sort_walk(vdet_ctx *c, const SortWalkArgs &a, int nmax, int64_t order
         const bool use_bk = c->bucket_mode > 0 && (sp.mode == 1 || sp.mode == 3) && a.topk == 0 && !a.excl && !a.order_out && !a.no_buckets &&
                             (block == 1024 || c->bucket_mode >= 2) && nmax >= 2 && nmax <= kBkMaxB && bk_lds <= c->dyn_lds_max &&
                             packed_ok && sp.npass == 4 && !(a.want_heads && c->no_lazy);
+        // frames of at most 384 boxes: one WAVE per list (small_kernels.hpp: the same stable LSD passes without a workgroup)
+        const bool use_small = c->small_lists && c->atomic_rank && a.mode != 2 && nmax <= kSmallMax && a.topk == 0 && !a.excl && sp.npass == 4 &&
+                               !use_bk && !a.nover_out;
         StageTimer tm(c, ST_SORTK);
-        if (a.mode != 2) c->last_sort_binned = use_bin && !use_bk;
+        if (a.mode != 2) c->last_sort_binned = use_bin && !use_bk && !use_small;
         if (a.mode != 2) c->last_sort_bucketed = use_bk;
         if (!a.order_out) c->lists_bucketed = use_bk;
-        if (use_bk) {
+        if (use_small) {
+            const int kpl = std::max(1, (nmax + 63) / 64);
+            const int grid = (((a.P + 3) / 4) + 7) & ~7;
+            void *args[] = {&sp};
+            const void *fn = kpl == 1 ? reinterpret_cast<const void *>(small_sort_kernel<1>) : kpl == 2 ? reinterpret_cast<const void *>(small_sort_kernel<2>)
+                           : kpl == 3 ? reinterpret_cast<const void *>(small_sort_kernel<3>) : kpl == 4 ? reinterpret_cast<const void *>(small_sort_kernel<4>)
+                           : kpl == 5 ? reinterpret_cast<const void *>(small_sort_kernel<5>) : reinterpret_cast<const void *>(small_sort_kernel<6>);
+            HIPCHK(c, hipLaunchKernel(fn, dim3(grid), dim3(256), args, 0, c->stream));
+        } else if (use_bk) {
             HIPCHK(c, c->sortctl.reserve(sizeof(BinSortCtl) + (size_t)a.P * 4));
             HIPCHK(c, hipMemsetAsync(c->sortctl.p, 0, sizeof(BinSortCtl), c->stream));
             HIPCHK(c, c->ent.reserve((size_t)a.P * a.B * 4));
@@ -828,12 +839,14 @@ int launch_sort_walk(vdet_ctx *c, const SortWalkArgs &a, int nmax, int64_t order
         const int nm = std::max(nmax, 1);
         const size_t row_bytes = (size_t)nm * 4 * nq * 4;
         const int fpw = a.C > 32 ? 1 : (int)std::max<size_t>(1, std::min<size_t>((size_t)(64 / a.C), (size_t)(44 * 1024) / row_bytes));
-        const size_t lds_bytes = (size_t)fpw * row_bytes + (size_t)64 * (4 * nq + 1) * 4;
+        const size_t lds_bytes = (size_t)fpw * row_bytes;
+        const int vec4 = a.B % 4 == 0 ? 1 : 0;       // a list's candidates four per 8-byte load
         const int grid = (G + fpw - 1) / fpw;
         StageTimer tm(c, ST_WALK);
-        if (nq == 1) hipLaunchKernelGGL(small_walk_kernel<1>, dim3(grid), dim3(64), lds_bytes, c->stream, wp, G, fpw, nm);
-        else if (nq == 2) hipLaunchKernelGGL(small_walk_kernel<2>, dim3(grid), dim3(64), lds_bytes, c->stream, wp, G, fpw, nm);
-        else hipLaunchKernelGGL(small_walk_kernel<3>, dim3(grid), dim3(64), lds_bytes, c->stream, wp, G, fpw, nm);
+#define VDET_SMALLW(NQ_, V_) hipLaunchKernelGGL((small_walk_kernel<NQ_, V_>), dim3(grid), dim3(64), lds_bytes, c->stream, wp, G, fpw, nm)
+        if (vec4) { if (nq == 1) VDET_SMALLW(1, true); else if (nq == 2) VDET_SMALLW(2, true); else VDET_SMALLW(3, true); }
+        else { if (nq == 1) VDET_SMALLW(1, false); else if (nq == 2) VDET_SMALLW(2, false); else VDET_SMALLW(3, false); }
+#undef VDET_SMALLW
         if (!c->all_regular)      // (asynchronous build: not known on the host -- the kernel looks at the frames' flags)
             hipLaunchKernelGGL(walk_rest_kernel, dim3(std::min(G, 4 * c->n_cu)), dim3(256), (size_t)wp.wave_words * 4 * 4, c->stream, wp, G);
     } else {
