@@ -477,21 +477,24 @@ def test_link_table_up_front_equals_scanning_on_demand(case):
     kw = dict(thres=0.2, max_tracks=6, link_thres=0.45, max_frames=7 if case == "max_frames" else 0)
     tb, ts = torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda()
     res = []
-    for fill in ("0", "1024"):
+    for fill, lds in (("0", "1"), ("1024", "1"), ("1024", "0")):     # scans on demand / the table from LDS-staged frames / by quads
         os.environ["VDET_LINK_FILL"] = fill
+        os.environ["VDET_LINK_FILL_LDS"] = lds
         try:
             cx = _lib.Context(torch.cuda.current_device())
         finally:
             del os.environ["VDET_LINK_FILL"]
+            del os.environ["VDET_LINK_FILL_LDS"]
         try:
             res.append(ops.track_volume(tb, ts, ctx=cx, **kw))
         except ZeroDivisionError:
             res.append(None)
         cx.close()
-    assert (res[0] is None) == (res[1] is None)
+    assert (res[0] is None) == (res[1] is None) == (res[2] is None)
     if res[0] is not None:
-        for a, b in zip(*res):
-            assert torch.equal(a.nan_to_num(-7.0), b.nan_to_num(-7.0))
+        for other in res[1:]:
+            for a, b in zip(res[0], other):
+                assert torch.equal(a.nan_to_num(-7.0), b.nan_to_num(-7.0))
 
 
 def test_coherent_videos_get_their_anchors_predicted(oracle):

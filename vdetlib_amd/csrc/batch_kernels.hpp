@@ -103,6 +103,15 @@ __global__ __launch_bounds__(256) void batch_link_fill_kernel(const BatchTrack b
                    w.group_flags, w.ix, bt.link_thres, w.memo);
 }
 
+// grid (Fmax, 2, V), block = 64 * ceil(B / 64): the same table with the neighbour frame's index staged in LDS (link_fill_frame)
+__global__ __launch_bounds__(1024) void batch_link_fill_frame_kernel(const BatchTrack bt)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char fill_smem[];
+    const VidView w = vid_view(bt, blockIdx.z);
+    if ((int)blockIdx.x >= w.F) return;
+    link_fill_frame(blockIdx.x, blockIdx.y == 0 ? 1 : -1, w.boxes, w.F, bt.B, bt.link_t32, w.group_flags, w.ix, bt.link_thres, w.memo, fill_smem);
+}
+
 // grid (C * wm, 2, V); MODE 1: memo warm-up, MODE 2: materialise the warm chains
 template <int LT, int MODE>
 __global__ __launch_bounds__(LT, (MODE == 1 && LT == 256) ? 5 : 1) void batch_link_kernel(const BatchTrack bt)

@@ -1024,6 +1024,85 @@ __global__ __launch_bounds__(256) void link_fill_kernel(const float4 *__restrict
                    link_thres, memo);
 }
 
+// The same table, one BLOCK per (frame f, direction) with frame f + dir's x-sorted index -- boxes, areas, box numbers, bucket
+// table -- staged in LDS once (<= 24 KB at B = 1 024): a node's window scan then reads LDS instead of gathering 16-byte
+// records from global memory four at a time (link_fill_node waits for every such turn: the kernel was latency-bound, 3.4 ms
+// for the 64-video batch).  One thread per node, same window, screen, arg-max and tie rule, same memo words.
+// Dynamic LDS: [B] float4 boxes, [B] float areas, [260] bucket table + (xmin, scale, wmax), [B] u16 box numbers.
+inline size_t link_fill_lds_bytes(int B) { return (size_t)B * 22 + 260 * 4 + 16; }
+
+__device__ __forceinline__ void link_fill_frame(const int f, const int dir, const float4 *__restrict__ boxes, int F, int B, float link_t32,
+                                                const uint32_t *__restrict__ group_flags, const FrameIndex &ix, double link_thres,
+                                                unsigned long long *memo, unsigned char *smem)
+{
+    const int f2 = f + dir;
+    if (f2 < 0 || f2 >= F) return;                    // (a chain stops at the video's border before it asks)
+    float4 *sxb = reinterpret_cast<float4 *>(smem);
+    float *sar = reinterpret_cast<float *>(sxb + B);
+    uint32_t *scum = reinterpret_cast<uint32_t *>(sar + B);
+    uint16_t *sxo = reinterpret_cast<uint16_t *>(scum + 260);
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const uint32_t fflags = group_flags ? group_flags[f2] : 0u;
+    const bool fastf = ix.xbox && (fflags & kFlagRegular) && link_t32 > 1e-30f;       // (block-uniform)
+    if (fastf) {
+        for (int i = tid; i < B; i += nt) {
+            const float4 x = ix.xbox[(int64_t)f2 * B + i];
+            sxb[i] = x; sar[i] = box_area(x); sxo[i] = ix.xord[(int64_t)f2 * B + i];
+        }
+        for (int i = tid; i < 260; i += nt)
+            scum[i] = i < 257 ? ix.cum[(int64_t)f2 * 257 + i] : __float_as_uint(ix.info[f2 * 4 + (i - 257)]);
+    }
+    __syncthreads();
+    const float omt = (float)(1.0 - link_thres) * 1.002f + 1.0e-6f;
+    const float inv_t = (float)(1.002 / fmax(link_thres, 1.0e-6));
+    const float t32e = link_t32 * 4.76837158203125e-7f;
+    unsigned long long *mm = memo + (int64_t)(dir > 0 ? 0 : 1) * F * B;
+    for (int j = tid; j < B; j += nt) {
+        const float4 cur = trunc4(boxes[(int64_t)f * B + j]);
+        const float carea = box_area(cur);
+        float bv = -1.0f;
+        int bi = -1;
+        if (fastf && carea > 0.0f && carea < __uint_as_float(0x7F800000u)) {
+            const float xmin = __uint_as_float(scum[257]), scale = __uint_as_float(scum[258]), wmax = __uint_as_float(scum[259]);
+            const float wc = (cur.z - cur.x) + 1.0f;
+            const float lo = cur.x - omt * fminf(wmax, wc * inv_t) - 2.0f;
+            const float hi = cur.x + omt * wc + 2.0f;
+            const int r0 = (int)scum[xbucket(fmaxf(lo, -3.0e38f), xmin, scale)];
+            const int r1 = (int)scum[xbucket(fminf(hi, 3.0e38f), xmin, scale) + 1];
+            for (int r = r0; r < r1; ++r) {
+                const float4 x = sxb[r];
+                bool border;
+                const bool pass = pred_regular(cur, carea, x, sar[r], link_t32, t32e, border);
+                if (pass || border) {
+                    const float v = link_iou(cur, carea, x);
+                    const int b = (int)sxo[r];
+                    if (v >= link_t32 && (v > bv || (v == bv && b < bi))) { bv = v; bi = b; }
+                }
+            }
+        } else {
+            // irregular frame / no index / degenerate current box: the plain arg-max (NaN never wins, lowest index on ties)
+            const float4 *fb = boxes + (int64_t)f2 * B;
+            for (int b = 0; b < B; ++b) {
+                const float v = link_iou(cur, carea, fb[b]);
+                if (v > bv) { bv = v; bi = b; }
+            }
+        }
+        const bool linked = bi >= 0 && bv >= link_t32;
+        __hip_atomic_store(&mm[(int64_t)f * B + j],
+                           kMemoValid | ((unsigned long long)(linked ? bi + 1 : 0) << 32) | (linked ? __float_as_uint(bv) : 0u),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// grid (F, 2), block = 64 * ceil(B / 64) threads (<= 1 024), dynamic LDS link_fill_lds_bytes(B)
+__global__ __launch_bounds__(1024) void link_fill_frame_kernel(const float4 *__restrict__ boxes, int F, int B, float link_t32,
+                                                               const uint32_t *__restrict__ group_flags, const FrameIndex ix, double link_thres,
+                                                               unsigned long long *memo)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char fill_smem[];
+    link_fill_frame(blockIdx.x, blockIdx.y == 0 ? 1 : -1, boxes, F, B, link_t32, group_flags, ix, link_thres, memo, fill_smem);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Likely anchors of a class, for warming the link memo: the best `m` detections of the class in the
 // global order of vdet/track.py:200 (score descending, flat index ascending) that score >= thres --

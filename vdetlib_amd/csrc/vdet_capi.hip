@@ -143,6 +143,8 @@ struct vdet_ctx {
     bool force_general = false;   // VDET_FORCE_GENERAL=1: disable the symmetric fast kernel (tests)
     bool topk_attr_set = false;
     int link_threads = 256;       // VDET_LINK_THREADS=64|128|256: threads per link chain (A-B knob)
+    bool link_fill_lds = true;    // VDET_LINK_FILL_LDS=0: the link table by link_fill_kernel (quads gathering from global memory) instead of
+                                  // link_fill_frame_kernel (one block per frame and direction, the neighbour frame's index in LDS)
     bool small_lists = true;      // VDET_SMALL_LISTS=0: frames of <= 384 boxes through the large-list sort and walk too (small_kernels.hpp; A-B knob)
     int warm_threads = 256;       // VDET_WARM_THREADS=64|128|256: threads per chain of the memo warm-up (more chains resident at once)
     bool series_serial = false;   // VDET_SERIES_SERIAL=1: one thread per tubelet series (A-B knob / tests)
@@ -1031,6 +1033,7 @@ int vdet_create(vdet_ctx **out, int device)
     if (const char *e = getenv("VDET_LINK_LPT")) c->link_lpt = atoi(e) != 0;
     if (const char *e = getenv("VDET_GRAPH_PIPE")) c->graph_pipe = atoi(e) != 0;
     if (const char *e = getenv("VDET_AUX_STREAM")) c->use_aux = atoi(e) != 0;
+    if (const char *e = getenv("VDET_LINK_FILL_LDS")) c->link_fill_lds = atoi(e) != 0;
     if (const char *e = getenv("VDET_SMALL_LISTS")) c->small_lists = atoi(e) != 0;
     if (const char *e = getenv("VDET_WARM_THREADS")) { const int v = atoi(e); if (v == 64 || v == 128 || v == 256) c->warm_threads = v; }
     if (const char *e = getenv("VDET_LINK_THREADS")) { const int v = atoi(e); if (v == 64 || v == 128 || v == 256) c->link_threads = v; }
@@ -1684,6 +1687,11 @@ int vdet_nms_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scor
         const bool filled = c->link_fill > 0 && B <= c->link_fill && w_ix.xbox != nullptr && max_tracks > 0;
         if (filled) {
             StageTimer tm(c, ST_TLINK);
+            if (c->link_fill_lds && B <= 1024)
+                hipLaunchKernelGGL(link_fill_frame_kernel, dim3((unsigned)F, 2), dim3((unsigned)(64 * ((B + 63) / 64))), link_fill_lds_bytes((int)B), ws,
+                                   reinterpret_cast<const float4 *>(d_boxes), (int)F, (int)B, link_t32, w_flags, w_ix, link_thres,
+                                   c->linkmemo.as<unsigned long long>());
+            else
             hipLaunchKernelGGL(link_fill_kernel, dim3((unsigned)((F * B * kFillLanes + 255) / 256), 2), dim3(256), 0, ws, reinterpret_cast<const float4 *>(d_boxes),
                                (int)F, (int)B, link_t32, w_flags, w_ix, link_thres, c->linkmemo.as<unsigned long long>());
         }
@@ -1969,6 +1977,10 @@ int vdet_video_batch(vdet_ctx *c, const float *d_boxes, const float *d_scores, c
         if (c->link_fill > 0 && B <= c->link_fill && have_ix) {
             // the whole link table of every video: no chain ever scans, whatever its anchor -- so nothing is predicted or
             // materialised either (VDET_BATCH_CHAINS=1 keeps the predicted chains: measured below)
+            if (c->link_fill_lds && B <= 1024)
+                hipLaunchKernelGGL(batch_link_fill_frame_kernel, dim3((unsigned)Fmax, 2, (unsigned)V), dim3((unsigned)(64 * ((B + 63) / 64))),
+                                   link_fill_lds_bytes((int)B), c->stream, bt);
+            else
             hipLaunchKernelGGL(batch_link_fill_kernel, dim3((unsigned)((Fmax * B * kFillLanes + 255) / 256), 2, (unsigned)V), dim3(256), 0, c->stream, bt);
             if (c->batch_chains) {
                 hipLaunchKernelGGL(batch_warm_anchors_kernel, dim3((unsigned)C, (unsigned)V), dim3(256), 0, c->stream, bt);
