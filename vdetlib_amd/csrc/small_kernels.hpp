@@ -1,26 +1,28 @@
 // small_kernels.hpp -- (round 4) frames of at most 384 proposals: the ILSVRC-VID shape (<= 300 per frame, BASELINE configs[0]
 // and [4]) and every other small problem of utils/nms.pyx:17-68 / vdet/video_det.py:89-99.
 //
-// The walk of nms_kernels.hpp is built for lists of ~10 000 candidates: one WAVE per list, eight survivors per pass of vector
-// code.  On a batch of 64 VID-shaped videos (972 000 lists of <= 300 candidates) it costs ~2 400 instructions per list and was
-// 4.3 of 20.5 ms (profiles/r04_vid_batch_kernel_stats.csv).  A small list does not need a wave:
+// The per-list kernels of nms_kernels.hpp are built for lists of ~10 000 candidates: a 256-thread LSD sort (22 workgroup
+// barriers per list) and a walk with one WAVE per list, eight survivors per pass of vector code.  On a batch of 64 VID-shaped
+// videos (972 000 lists of <= 300 candidates) they were 3.7 + 4.3 of 20.3 ms (profiles/r04_vid_batch_kernel_stats.csv before
+// this file): latency per list, not work.  Here:
 //
+//   small_sort_kernel   the same stable LSD passes run by ONE WAVE per list: no workgroup barrier, no cross-wave scan, four
+//                       times the lists resident (3.7 -> 2.2 ms).
 //   small_walk_kernel   ONE LANE per list.  A wave takes the lists of one frame (C > 32) or of several (64 / C frames); the
 //                       frames' suppression ROWS (bit v of row u <=> u suppresses v) are built in LDS from the adjacency
 //                       lists once and serve all their classes.  Every lane runs the reference's loop (utils/nms.pyx:33-66) on
 //                       its own list: next candidate, test its bit in the lane's dead mask (registers), and -- if it is
 //                       clear -- keep it and OR its row into the mask (the row: three 16-byte LDS reads, requested a step
-//                       ahead).  ~50 instructions per step of 64 lists instead of ~8 per candidate of one.
+//                       ahead).  ~60 instructions per step of 64 lists instead of ~2 400 per list (4.3 -> 1.7 ms).
 //   walk_rest_kernel    what small_walk_kernel leaves: the lists of irregular frames (NaN / degenerate boxes: zero-union
 //                       tags, asymmetric rows), through the general walk, one wave per list.
 //
-// Results are identical to the large-list walk's (tests run both: VDET_SMALL_LISTS=0).
-//   small_sort_kernel   the LSD radix sort of a list run by ONE WAVE (no workgroup barriers, four times the lists resident).
+// Results are identical to the large-list kernels' (tests/test_small_gpu.py runs both: VDET_SMALL_LISTS=0).
 //
 // Measured and dropped in the same round: ONE WAVE per list sorting it by counting (every lane counts, for each of its <= 6
-// keys, the keys before it: N^2 / 64 compare + add-with-carry pairs per lane) -- 11.5 ms against the LSD kernel's 3.7 on that
-// batch (a wave64 instruction takes four cycles: 3 500 of them per list are 6 ms of pure issue), and the first small walk,
-// one block per frame with a scalar loop over the alive candidates of one list per wave (7.6 ms against 4.3).
+// keys, the keys before it: N^2 / 64 subtract-with-borrow + add-with-carry pairs per lane) -- 11.5 ms against the LSD kernel's
+// 3.7 on that batch (a wave64 instruction takes four cycles: 3 500 of them per list are 6 ms of pure issue), and the first small
+// walk, one block per frame with a scalar loop over the alive candidates of one list per wave (7.6 ms against 4.3).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
