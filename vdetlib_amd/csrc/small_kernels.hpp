@@ -87,15 +87,58 @@ __global__ __launch_bounds__(256) void small_sort_kernel(const SortParams prm)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
         uint32_t e[KPL], rk[KPL];
+        if (pass < 3) {
 #pragma unroll
-        for (int c = 0; c < KPL; ++c) {
-            const int q = 64 * c + lane;
-            const bool valid = q < N;
-            const uint32_t i = valid ? (uint32_t)sidx[w][cur][q] : 0u;
-            const uint32_t d = valid ? ((skey[w][i] >> shift) & 255u) : 0u;
-            e[c] = i | (d << 16);
-            rk[c] = 0u;
-            if (valid) rk[c] = __hip_atomic_fetch_add((lds_u32_t *)(hist + d), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            for (int c = 0; c < KPL; ++c) {
+                const int q = 64 * c + lane;
+                const bool valid = q < N;
+                const uint32_t i = valid ? (uint32_t)sidx[w][cur][q] : 0u;
+                const uint32_t d = valid ? ((skey[w][i] >> shift) & 255u) : 0u;
+                e[c] = i | (d << 16);
+                rk[c] = 0u;
+                if (valid) rk[c] = __hip_atomic_fetch_add((lds_u32_t *)(hist + d), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+        } else {
+            // the top byte (sign + exponent bits) takes a handful of values -- 64 lanes on 2-3 counters serialise in the LDS
+            // (profiles/r04_pmc_vid_sq2.csv: two thirds of this kernel's LDS cycles were bank conflicts).  Up to three digits
+            // seen at the head of the list are counted in registers instead: their lanes rank themselves by ballot (chunks in
+            // order, lanes in order: the same stable rank), their totals reach the counters once, at the end of the pass
+            uint32_t dg[3] = {0x100u, 0x100u, 0x100u}, dc[3] = {0u, 0u, 0u};
+#pragma unroll
+            for (int c = 0; c < KPL; ++c) {
+                const int q = 64 * c + lane;
+                const bool valid = q < N;
+                const uint32_t i = valid ? (uint32_t)sidx[w][cur][q] : 0u;
+                const uint32_t d = valid ? ((skey[w][i] >> shift) & 255u) : 0x1FFu;
+                e[c] = i | ((d & 255u) << 16);
+                if (c == 0) {     // (wave-uniform) the digits of the first lanes that differ
+                    unsigned long long rest = __ballot(valid);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        if (rest) {
+                            dg[k] = (uint32_t)__builtin_amdgcn_readlane((int)d, __ffsll((unsigned long long)rest) - 1);
+                            rest &= ~__ballot(d == dg[k]);
+                        }
+                    }
+                }
+                rk[c] = 0u;
+                bool taken = false;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const unsigned long long m = __ballot(valid && d == dg[k]);
+                    if ((m >> lane) & 1ull) {
+                        rk[c] = dc[k] + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                        taken = true;
+                    }
+                    dc[k] += (uint32_t)__popcll(m);
+                }
+                if (valid && !taken) rk[c] = __hip_atomic_fetch_add((lds_u32_t *)(hist + d), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+            {
+                const uint32_t dd = lane == 0 ? dg[0] : lane == 1 ? dg[1] : dg[2], cc = lane == 0 ? dc[0] : lane == 1 ? dc[1] : dc[2];
+                if (lane < 3 && dd < 256u)
+                    __hip_atomic_fetch_add((lds_u32_t *)(hist + dd), cc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
