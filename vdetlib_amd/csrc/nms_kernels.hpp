@@ -751,7 +751,10 @@ constexpr int kAdjRows = 128;
 constexpr int kAdjBatch = VDET_ADJ_BATCH;   // bit-matrix words loaded per memory round trip (a row's window is ~42 words)
 constexpr int kAdjStage = 16384;     // u16 entries staged in LDS per block (32 KB)
 
-__global__ __launch_bounds__(kAdjRows) void adj_build_kernel(const float4 *__restrict__ boxes,
+// ROWS = rows per block: kAdjRows (two blocks per 256-row tile), or kRowsPerTile on small frames (one block per tile: a third
+// fewer blocks for frames of 257..384 boxes -- there the kernel is a cost per BLOCK)
+template <int ROWS>
+__global__ __launch_bounds__(ROWS) void adj_build_kernel(const float4 *__restrict__ boxes,
                                                         const GroupDesc *__restrict__ groups,
                                                         const TileDesc *__restrict__ tiles,
                                                         const uint64_t *__restrict__ bits,
@@ -768,11 +771,11 @@ __global__ __launch_bounds__(kAdjRows) void adj_build_kernel(const float4 *__res
     __shared__ uint32_t sscan[8];
     __shared__ unsigned long long sbase;
     __shared__ __attribute__((aligned(16))) uint16_t sstage[kAdjStage];
-    const TileDesc td = tiles[blockIdx.x >> 1];
+    const TileDesc td = tiles[ROWS == kAdjRows ? (blockIdx.x >> 1) : blockIdx.x];
     const GroupDesc gd = groups[td.group];
     const int B = gd.nbox;
     const int tid = threadIdx.x;
-    const int v = td.row_tile * kRowsPerTile + (blockIdx.x & 1) * kAdjRows + tid;
+    const int v = td.row_tile * kRowsPerTile + (ROWS == kAdjRows ? (int)(blockIdx.x & 1) * kAdjRows : 0) + tid;
     const int W = (B + 63) >> 6;
     const uint64_t *col = bits + gd.bits_off + bit_word(B, v, 0);      // word c of my row: col[c * 64]
     // regular groups were evaluated in x1-rank space (iou_bits_sym_kernel): translate back
@@ -794,7 +797,7 @@ __global__ __launch_bounds__(kAdjRows) void adj_build_kernel(const float4 *__res
     }
     if (tr) {
         const float2 *rt = reach_table + reach_slot(gd, td.group);
-        for (int i = tid; i < W; i += kAdjRows) srt[i] = rt[i];
+        for (int i = tid; i < W; i += ROWS) srt[i] = rt[i];
         __syncthreads();
     }
     const int wr = __builtin_amdgcn_readfirstlane(v >> 6);     // my word-row (one per wave: 64 aligned rows)
@@ -870,7 +873,7 @@ __global__ __launch_bounds__(kAdjRows) void adj_build_kernel(const float4 *__res
         for (int k = 0; k < wv; ++k) carry += sscan[k];
         incl += carry;
     }
-    if (tid == kAdjRows - 1) { sscan[4] = incl; sbase = atomicAdd(pool_used, (unsigned long long)incl); }
+    if (tid == ROWS - 1) { sscan[4] = incl; sbase = atomicAdd(pool_used, (unsigned long long)incl); }
     __syncthreads();
     const unsigned long long base = sbase;
     const uint32_t tile_total = sscan[4];
@@ -971,14 +974,14 @@ __global__ __launch_bounds__(kAdjRows) void adj_build_kernel(const float4 *__res
         uint4 *d4 = reinterpret_cast<uint4 *>(adj + base);
         const uint32_t n8 = tile_total >> 3;
         if (tr) {   // (zero-union entries only exist on irregular frames, which have no x-index: tr == null)
-            for (uint32_t i = tid; i < n8; i += kAdjRows) {
+            for (uint32_t i = tid; i < n8; i += ROWS) {
                 const uint4 e = s4[i];
                 const uint32_t a0 = tr[e.x & 0xFFFFu], a1 = tr[e.x >> 16], a2 = tr[e.y & 0xFFFFu], a3 = tr[e.y >> 16];
                 const uint32_t a4 = tr[e.z & 0xFFFFu], a5 = tr[e.z >> 16], a6 = tr[e.w & 0xFFFFu], a7 = tr[e.w >> 16];
                 d4[i] = make_uint4(a0 | (a1 << 16), a2 | (a3 << 16), a4 | (a5 << 16), a6 | (a7 << 16));
             }
         } else {
-            for (uint32_t i = tid; i < n8; i += kAdjRows) d4[i] = s4[i];
+            for (uint32_t i = tid; i < n8; i += ROWS) d4[i] = s4[i];
         }
     }
 }

@@ -542,7 +542,9 @@ int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32, doub
             }
             {
                 StageTimer tm(c, ST_ADJ);
-                hipLaunchKernelGGL(adj_build_kernel, dim3(2 * nt), dim3(kAdjRows), 0, s_k2, d_boxes,
+                const bool k2_tile = pl.nmax <= 384;      // small frames: one block per tile
+                hipLaunchKernelGGL(k2_tile ? adj_build_kernel<kRowsPerTile> : adj_build_kernel<kAdjRows>, dim3(k2_tile ? nt : 2 * nt),
+                                   dim3(k2_tile ? kRowsPerTile : kAdjRows), 0, s_k2, d_boxes,
                                    c->groups.as<GroupDesc>(), c->tiles.as<TileDesc>() + bt.first,
                                    bits_b, c->rowz.as<uint32_t>(), c->rowmeta.as<uint2>(),
                                    c->adj.as<uint16_t>(), &c->d_cnt->pool_used, pool_cap,
