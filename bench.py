@@ -48,6 +48,23 @@ def synth_video_cuda(torch, seed, F, B, C, device, kind="rand"):
     return boxes, scores
 
 
+def synth_video_reference_stream(torch, seed, F, B, C, device):
+    """BASELINE.md section 3 / SURVEY 8(d): the HOST generator `np.random.RandomState(1000 * config + video)` -- exactly
+    tests/synth.video(seed, F, B, C): integer boxes, scores ((rank + 0.5) / B as f32) tie-free per (frame, class), so the
+    build's visiting order is the reference's (`scores.argsort()[::-1]` has no ties to break, utils/nms.pyx:25).  The uniform
+    draws come from the host stream frame by frame; only the per-column ranking (argsort of argsort) runs on the device."""
+    import numpy as np
+    import synth
+    rng = np.random.RandomState(seed)
+    boxes = np.stack([synth.boxes_1(rng, B, False) for _ in range(F)], 0)
+    scores = torch.empty((F, B, C), dtype=torch.float32, device=device)
+    for f in range(F):
+        r = torch.from_numpy(rng.rand(B, C)).to(device)                         # same stream as rng.rand(F, B, C)
+        ranks = torch.argsort(torch.argsort(r, dim=0), dim=0)
+        scores[f] = ((ranks.to(torch.float64) + 0.5) / B).to(torch.float32)
+    return torch.from_numpy(boxes).to(device).contiguous(), scores
+
+
 def synth_vid_batch(torch, dev, V=64, B=300, C=30, seed=777):
     """V VID-shaped synthetic videos concatenated along F: boxes [F,B,4], scores [F,B,C], frame offsets [V+1]"""
     import numpy as np

@@ -38,3 +38,17 @@ def test_monkey_patching_is_seen_through_both_names():
         assert b.imread("x") == "patched"
     finally:
         b.imread = old
+
+
+def test_real_modules_keep_their_own_spec():
+    """importing through the alias must not rewrite the real module's __spec__ (reload / relative imports / package paths)"""
+    import vdetlib.utils.timer as a
+    import vdetlib_amd.utils.timer as b
+    import vdetlib_amd.utils as pkg
+    import vdetlib.utils                                                               # noqa: F401
+    assert a is b and b.__spec__.name == "vdetlib_amd.utils.timer" and b.__package__ == b.__spec__.parent
+    assert pkg.__spec__.name == "vdetlib_amd.utils" and list(pkg.__spec__.submodule_search_locations)
+    assert importlib.reload(b) is b
+    import vdetlib
+    with pytest.raises(AttributeError):
+        vdetlib.no_such_submodule

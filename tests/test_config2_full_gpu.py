@@ -1,10 +1,10 @@
 """-m gpu: BASELINE configs[1] + [2] at FULL size -- one video of 300 frames x 10 000 boxes x 200 classes
-through the benchmarked calls (vdet_volume_pass, vdet_nms_track_volume, vdet_rescore_tracks) -- checked
-against the oracle on samples that cover every structural boundary of the device path: the four
-bit-matrix batches (32 frames incl. 0 / 84 / 85 / 170 / 299 x ALL 200 classes of NMS survivors, all host threads),
-box tiles at both ends and in the middle of the volume pass (12 % of the boxes x all 300 frames x all classes of both
-temporal outputs), and ALL TEN tubelets + their re-scoring of six classes -- among them, when the video has one, a
-class whose anchors the memo warm-up did not predict -- with the oracle's per-class pipeline on one host process each."""
+through the benchmarked calls (vdet_volume_pass, vdet_nms_track_volume, vdet_rescore_tracks) -- checked against the
+oracle over the WHOLE video (round 5): the NMS survivors of all 300 frames x 200 classes (60 000 lists, all host
+threads), both temporal outputs on every box, and ALL TEN tubelets + their re-scoring of 24 classes -- among them, when
+the video has them, classes whose anchors the memo warm-up did not predict -- with the oracle's per-class pipeline on one
+host process each.  A second full video comes from BASELINE.md section 3's host generator (RandomState(1000 * 2 + 0),
+tie-free scores: the reference's own visiting order)."""
 import os
 import sys
 
@@ -39,28 +39,38 @@ def full_run():
     cx.close()
 
 
-def test_full_volume_nms_survivors_sampled_frames(full_run, oracle):
-    r = full_run
-    # first / last frame, both sides of the bit-matrix batch borders, and every tenth frame: 32 frames x 200 classes
-    frames = sorted(set([0, 84, 85, 170, 299] + list(range(5, F, 11))))
-    assert len(frames) >= 30
-    hb = r['boxes'][frames].cpu().numpy()
-    hs = r['scores'][frames].contiguous().cpu().numpy()
+def _check_nms_all_frames(r, oracle, chunk=50):
+    """utils/nms.pyx:17-68 for every (frame, class) of the video: kept lists + counts against oracle.nms_volume"""
     nthr = max(1, len(os.sched_getaffinity(0)))
-    widx, wcnt = oracle.nms_volume(hb, hs, 0.3, cap=2048, threads=nthr)
-    gcnt = r['keep_cnt'][frames].cpu().numpy()
-    gidx = r['keep_idx'][frames].cpu().numpy()
-    assert np.array_equal(gcnt, wcnt)
-    assert np.array_equal(gidx, widx)
-    assert 1000 < gcnt.mean() < 2048
+    total = 0
+    for f0 in range(0, F, chunk):
+        f1 = min(F, f0 + chunk)
+        hb = r['boxes'][f0:f1].cpu().numpy()
+        hs = r['scores'][f0:f1].contiguous().cpu().numpy()
+        widx, wcnt = oracle.nms_volume(hb, hs, 0.3, cap=2048, threads=nthr)
+        gcnt = r['keep_cnt'][f0:f1].cpu().numpy()
+        gidx = r['keep_idx'][f0:f1].cpu().numpy()
+        assert np.array_equal(gcnt, wcnt), f0
+        assert np.array_equal(gidx, widx), f0
+        total += int(gcnt.sum())
+    return total / (F * C)
 
 
-def test_full_volume_temporal_outputs_sampled_tiles(full_run, oracle):
+def test_full_volume_nms_survivors_all_frames(full_run, oracle):
+    """all 300 frames x 200 classes = 60 000 lists of 10 000 candidates (both sides of every bit-matrix batch border)"""
+    mean = _check_nms_all_frames(full_run, oracle)
+    assert 1000 < mean < 2048
+
+
+def test_full_volume_temporal_outputs_all_boxes(full_run, oracle):
+    """vdet/tubelet_cls.py:386-414 as the [F,B,C] streaming pass: every box of the volume, in chunks of 1 000 boxes (every
+    32-box tile of the pass incl. the ragged last one)"""
     r = full_run
-    for b0, b1 in ((0, 400), (4800, 5210), (B - 400, B)):        # 1 210 boxes (12 %): dozens of 32-box tiles incl. the ragged last one
+    for b0 in range(0, B, 1000):
+        b1 = min(B, b0 + 1000)
         hs = r['scores'][:, b0:b1].contiguous().cpu().numpy()
-        assert np.array_equal(r['pooled'][:, b0:b1].cpu().numpy(), oracle.temporal_maxpool(hs, 3))
-        # (the volume pass and the oracle do the same f32 operations in the same order)
+        assert np.array_equal(r['pooled'][:, b0:b1].cpu().numpy(), oracle.temporal_maxpool(hs, 3)), b0
+        # (the volume pass and the oracle do the same f32 operations in the same order; 1e-5 is north_star's tolerance)
         np.testing.assert_allclose(r['conv'][:, b0:b1].cpu().numpy(), oracle.temporal_conv(hs, TAPS, 0.0, 0.0), rtol=0, atol=1e-6)
 
 
@@ -85,8 +95,8 @@ def _classes_with_unpredicted_anchors(r, m=16):
     return [int(c) for c in torch.nonzero(~hit.all(dim=1)).flatten().tolist()]
 
 
-def test_full_volume_all_tubelets_six_classes(full_run, tmp_path):
-    """vdet/track.py:189-252 + vdet/tubelet_cls.py:493-535, :284-303, :386-414 at full size: ALL ten tubelets of six
+def test_full_volume_all_tubelets_24_classes(full_run, tmp_path):
+    """vdet/track.py:189-252 + vdet/tubelet_cls.py:493-535, :284-303, :386-414 at full size: ALL ten tubelets of 24
     classes -- anchors, rows, spatial max-pool / regressed boxes, completion, temporal max-pool -- against
     oracle.rescored_tubelets (lists pruned several times, warm-anchor mispredictions, materialised-chain copies:
     everything the first two tracks never exercise)."""
@@ -96,7 +106,8 @@ def test_full_volume_all_tubelets_six_classes(full_run, tmp_path):
     assert (nt_dev == 10).all()                  # 3 M U(0,1) scores per class: ten anchors above 0.9 always exist
     T = 10
     missed = _classes_with_unpredicted_anchors(r)
-    classes = (missed[:2] + [c for c in (0, 41, 99, 137, 163, 199) if c not in missed[:2]])[:6]
+    spread = [0, 199] + list(range(7, C, 9))
+    classes = (missed[:6] + [c for c in spread if c not in missed[:6]])[:24]
     hb = r['boxes'].cpu().numpy()
     cols = {c: r['scores'][:, :, c].contiguous().cpu().numpy() for c in classes}
     opts = dict(nms_thres=0.3, thres=0.9, max_tracks=T, link_thres=0.5, pool_thres=0.7, window=3)
@@ -148,17 +159,15 @@ def test_full_volume_size_independent_properties(full_run):
             assert bool((torch.trunc(r['boxes'][f]) == row[None]).all(dim=1).any())
 
 
-def test_full_volume_fast_paths_equal_the_plain_ones(full_run, monkeypatch):
-    """All 200 classes x 10 tracks of the full video: the link memo + warm-up and the graph-neighbour re-scoring (the
-    benchmarked paths) against the round-1 kernels they replace (every link step scans its window, every tubelet box
-    scans its window), which the oracle tests above and the golden tests pin."""
+def test_full_volume_fallback_paths_equal_the_default(full_run, monkeypatch):
+    """All 200 classes x 10 tracks of the full video through the library's fallback paths -- eager track_det_nms of every
+    crossed list (the irregular-frame path), the LSD radix sort (the path of tied / thresholded columns) -- against the
+    default paths, which the oracle tests above pin."""
     import torch
     from vdetlib_amd import ops, _lib
     r = full_run
-    monkeypatch.setenv("VDET_LINK_MEMO", "0")
-    monkeypatch.setenv("VDET_RESCORE_ADJ", "0")
-    monkeypatch.setenv("VDET_WALK_CAREFUL", "1")
-    monkeypatch.setenv("VDET_TRACK_LOOP", "0")
+    monkeypatch.setenv("VDET_NO_LAZY", "1")
+    monkeypatch.setenv("VDET_BINSORT", "0")
     cx = _lib.Context(torch.cuda.current_device())
     cx.set_cache(True)
     keep_idx, keep_cnt, tracks, anchors, ntracks = ops.nms_track_volume(
@@ -168,6 +177,44 @@ def test_full_volume_fast_paths_equal_the_plain_ones(full_run, monkeypatch):
                        ("anchors", anchors, r['anchors']), ("tracks", tracks, r['tracks']), ("det", det, r['det']),
                        ("tpool", tpool, r['tpool']), ("tboxes", tboxes, r['tboxes'])):
         assert torch.equal(a.nan_to_num(-7.0), b.nan_to_num(-7.0)), name
+    cx.close()
+
+
+def test_full_volume_reference_generator_inputs(oracle, tmp_path):
+    """BASELINE.md section 3's host generator at full size: RandomState(1000 * config + video) = RandomState(2000), integer
+    boxes, scores tie-free per (frame, class) -- on such lists the build's order IS the reference's (its argsort has no
+    ties to break, utils/nms.pyx:25).  NMS survivors of every 7th frame x all classes, tubelets + re-scoring of 4 classes."""
+    import torch
+    import oracle_pool
+    from vdetlib_amd import ops, _lib
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    dev = torch.device("cuda", torch.cuda.current_device())
+    boxes, scores = bench.synth_video_reference_stream(torch, 1000 * 2 + 0, F, B, C, dev)
+    srt = torch.sort(scores[::37].transpose(1, 2), dim=2).values           # tie-free columns (sampled frames)
+    assert bool((srt[..., 1:] > srt[..., :-1]).all())
+    del srt
+    cx = _lib.Context(dev.index)
+    cx.set_cache(True)
+    keep_idx, keep_cnt, tracks, anchors, ntracks = ops.nms_track_volume(
+        boxes, scores, nms_thres=0.3, thres=0.9, max_tracks=10, link_thres=0.5, cap=2048, ctx=cx)
+    det, tpool, tboxes = ops.rescore_tracks(tracks, ntracks, boxes, scores, overlap_thres=0.7, window=3, ctx=cx)
+    frames = list(range(0, F, 7))
+    nthr = max(1, len(os.sched_getaffinity(0)))
+    widx, wcnt = oracle.nms_volume(boxes[frames].cpu().numpy(), scores[frames].contiguous().cpu().numpy(), 0.3, cap=2048, threads=nthr)
+    assert np.array_equal(keep_cnt[frames].cpu().numpy(), wcnt) and np.array_equal(keep_idx[frames].cpu().numpy(), widx)
+    classes = [3, 77, 150, 199]
+    hb = boxes.cpu().numpy()
+    cols = {c: scores[:, :, c].contiguous().cpu().numpy() for c in classes}
+    want = oracle_pool.rescored_tubelets_per_class(hb, cols, dict(nms_thres=0.3, thres=0.9, max_tracks=10, link_thres=0.5, pool_thres=0.7,
+                                                                  window=3), tmp_path)
+    for c in classes:
+        wt, wn, wpool, wbx, wdet = want[c]
+        assert int(ntracks[c]) == wn, c
+        assert np.array_equal(tracks[c, :wn].cpu().numpy(), wt[:wn], equal_nan=True), c
+        has = ~np.isnan(wt[:wn, :, 0])
+        np.testing.assert_allclose(tpool[c, :wn].cpu().numpy()[has], wpool[:wn][has], rtol=0, atol=1e-9)
+        assert np.array_equal(tboxes[c, :wn].cpu().numpy()[has], wbx[:wn][has])
     cx.close()
 
 

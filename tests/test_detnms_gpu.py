@@ -83,6 +83,24 @@ def test_det_nms_volume_vs_oracle(oracle, cfg):
         _check_frame(oracle, f, S, BX, out, -np.inf if thr is None else thr, cfg['k'], 0.3)
 
 
+def test_det_nms_tied_scores_beyond_the_cut(oracle):
+    """quantised scores (many ties, more candidates than topk): after the cut the rows are argsort(-score)[:k] with equal
+    scores by ASCENDING box index (vdet/video_det.py:93-97, stable), the NMS of those rows visits ties by descending row"""
+    import torch
+    from vdetlib_amd import ops
+    rng = np.random.RandomState(5190)
+    F, B, K = 3, 400, 5
+    base = np.stack([synth.boxes_1(rng, B, False) for _ in range(F)], 0)
+    BX = np.round(base[:, :, None, :] + rng.uniform(-12, 12, (F, B, K, 4))).astype(np.float32)
+    BX[..., 2:] = np.maximum(BX[..., 2:], BX[..., :2])
+    S = (np.floor(rng.rand(F, B, K) * 12) / 12).astype(np.float32)          # 12 levels: runs of ~33 equal scores
+    for k in (100, 37, 128):
+        out = [t.cpu().numpy() for t in ops.det_nms_volume(torch.from_numpy(BX).cuda(), torch.from_numpy(S).cuda(),
+                                                           score_thresh=0.05, topk=k, nms_thresh=0.3)]
+        for f in range(F):
+            _check_frame(oracle, f, S, BX, out, 0.05, k, 0.3)
+
+
 def test_det_nms_zero_union_raises_like_the_reference(oracle):
     """two identical zero-area boxes at the top of a class: the reference divides by a zero union (ZeroDivisionError)"""
     import torch

@@ -10,9 +10,34 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(scope="module")
-def cnms():
+def cnms1():
     from vdetlib_amd.utils import cython_nms
     return cython_nms
+
+
+@pytest.fixture(scope="module", params=["single_launch", "general"])
+def cnms(request):
+    """the drop-in module twice: calls of <= 1 024 rows as ONE launch (csrc/fused_kernels.hpp, the default) and -- on a
+    context created under VDET_NO_FUSED=1 -- through the general kernel chain that larger inputs take"""
+    import os
+    from vdetlib_amd.utils import cython_nms
+    from vdetlib_amd import _lib
+    if request.param == "single_launch":
+        yield cython_nms
+        return
+    os.environ["VDET_NO_FUSED"] = "1"
+    try:
+        cx = _lib.Context(-1)
+    finally:
+        del os.environ["VDET_NO_FUSED"]
+    old = _lib._ctxs.get(-1)
+    _lib._ctxs[-1] = cx
+    yield cython_nms
+    if old is None:
+        del _lib._ctxs[-1]
+    else:
+        _lib._ctxs[-1] = old
+    cx.close()
 
 
 def test_nms_golden(cnms, nms_golden):
@@ -170,7 +195,7 @@ def test_track_det_nms_random(cnms, oracle):
     assert cnms.track_det_nms(np.zeros((0, 5), np.float32), d, 0.3) == oracle.vid_nms(d, 0.3)
 
 
-def test_batched_graph_build(cnms, oracle, monkeypatch):
+def test_batched_graph_build(cnms1, oracle, monkeypatch):
     """Same results when the bit-matrix scratch is split into many batches."""
     import ctypes
     from vdetlib_amd import _lib
@@ -184,10 +209,10 @@ def test_batched_graph_build(cnms, oracle, monkeypatch):
     ctx.close()
 
 
-def test_nms_size_limits(cnms):
+def test_nms_size_limits(cnms1):
     d = np.zeros((40000, 5), np.float32)
     with pytest.raises(ValueError):
-        cnms.nms(d, 0.3)
+        cnms1.nms(d, 0.3)
 
 
 def test_iou_f64(oracle, nms_golden):
@@ -210,7 +235,8 @@ def test_iou_f64(oracle, nms_golden):
 
 
 @pytest.mark.parametrize("n", [17000, 20000, 32767])
-def test_nms_large_single_problem(cnms, oracle, n):
+def test_nms_large_single_problem(cnms1, oracle, n):
+    cnms = cnms1
     """Beyond the in-LDS sort (~18k boxes) the host entry points fall back to a global bitonic sort;
     the u16 index limit is 32767."""
     d = synth.dets5(5000 + n, n, degenerate=n // 3, kind='randn')

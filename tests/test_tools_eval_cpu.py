@@ -165,3 +165,14 @@ def test_gen_vid_proto_file_cli(tmp_path, capsys):
     assert gen.main(["other", str(frames), str(out)]) == 0          # resume rule: nothing is redone
     assert out.read_bytes() == before
     assert "already exists" in capsys.readouterr().out
+
+
+def test_bench_reference_stream_generator_is_synth_video():
+    """bench.synth_video_reference_stream (host RandomState draws, ranking on the device) == tests/synth.video, the
+    BASELINE.md section 3 generator, value for value"""
+    import torch
+    import bench
+    import synth
+    b, s = bench.synth_video_reference_stream(torch, 2000, 3, 57, 5, torch.device("cpu"))
+    wb, ws = synth.video(2000, 3, 57, 5)
+    assert np.array_equal(b.numpy(), wb) and np.array_equal(s.numpy(), ws)

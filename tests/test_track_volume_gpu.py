@@ -340,13 +340,12 @@ def test_track_volume_random_sweep(oracle, seed):
     assert np.array_equal(kc.cpu().numpy(), wcnt) and np.array_equal(ki.cpu().numpy(), widx)
 
 
-@pytest.mark.parametrize("knob", ["VDET_FORCE_GENERAL", "VDET_NO_INDEX", "VDET_NO_TRANSPOSE", "VDET_NO_LAZY",
-                                  "VDET_WAVE_TRANSPOSE=0", "VDET_ATOMIC_RANK=0", "VDET_LINK_MEMO=0", "VDET_LINK_THREADS=64",
-                                  "VDET_LINK_THREADS=128", "VDET_LINK_WARM=0", "VDET_LINK_MAXB=16", "VDET_LINK_U16=0", "VDET_LINK_LPT=0", "VDET_GRAPH_PIPE=1", "VDET_AUX_STREAM=1", "VDET_WALK_CAREFUL=1", "VDET_WALK_PACKED=0", "VDET_WALK_PACKED=2", "VDET_SERIES_SERIAL=1", "VDET_LINK_MATERIALIZE=0", "VDET_RESCORE_ADJ=0", "VDET_TRACK_LOOP=0", "VDET_BINSORT=0", "VDET_LINK_COHERENT=0", "VDET_WARM_THREADS=64", "VDET_WARM_THREADS=128"])
+@pytest.mark.parametrize("knob", ["VDET_FORCE_GENERAL", "VDET_NO_INDEX", "VDET_NO_LAZY", "VDET_WAVE_TRANSPOSE=0", "VDET_ATOMIC_RANK=0",
+                                  "VDET_BINSORT=0", "VDET_SMALL_LISTS=0"])
 def test_alternative_kernel_paths_agree(monkeypatch, knob):
-    """Every A/B knob selects a different kernel path for the same result (general predicate kernel,
-    no x-index, strided key reads, eager track_det_nms, ballot transposition in K1s, ballot ranks in
-    the sort): NMS survivors, tubelets and re-scored tubelets must be bit-identical to the default."""
+    """Every diagnostic switch forces a FALLBACK path the library takes on some inputs / devices anyway (general predicate
+    kernel, no x-index, eager track_det_nms, ballot transposition in K1s, ballot ranks in the sort, the LSD sort, the
+    large-list kernels): NMS survivors, tubelets and re-scored tubelets must be bit-identical to the default."""
     import torch
     from vdetlib_amd import ops, _lib
     boxes, scores = _fused_case(61, 12, 1300, 6)
@@ -371,7 +370,7 @@ def test_link_compact_index_on_mixed_frames(oracle, monkeypatch, B):
     """Frames of integer pixel coordinates are scanned through the compact u16 index (two candidates per load, groups at
     even positions: odd B makes every second frame start on a pad), the others through the float4 index -- in one video:
     fractional frames, a coordinate of exactly 65535 (still u16) and of 65536 (not), a -0.0 (not).  Tubelets identical to
-    the oracle's and to VDET_LINK_U16=0."""
+    the oracle's."""
     import torch
     from vdetlib_amd import ops, _lib
     F, C = 11, 3
@@ -386,36 +385,30 @@ def test_link_compact_index_on_mixed_frames(oracle, monkeypatch, B):
     kw = dict(nms_thres=0.3, thres=0.0, max_tracks=5, link_thres=0.4)
     cx = _lib.Context(torch.cuda.current_device())
     got = ops.track_volume(tb, ts, ctx=cx, **kw)
-    monkeypatch.setenv("VDET_LINK_U16", "0")
-    cf = _lib.Context(torch.cuda.current_device())
-    ref = ops.track_volume(tb, ts, ctx=cf, **kw)
-    for a, b in zip(got, ref):
-        assert np.array_equal(a.cpu().numpy(), b.cpu().numpy(), equal_nan=True)
     tr, an, nt = (x.cpu().numpy() for x in got)
     for c in range(C):
         wt, wa, wn = oracle.greedy_track_volume(boxes, scores[:, :, c], 0.3, 0.0, 5, 0.4, 0)
         assert nt[c] == wn and np.array_equal(an[c, :wn], wa[:wn]), c
         assert np.array_equal(tr[c, :wn], wt[:wn], equal_nan=True), c
-    cx.close(); cf.close()
+    cx.close()
 
 
 @pytest.mark.parametrize("irregular", [False, True, 2])
-def test_pipelined_graph_build(monkeypatch, oracle, irregular):
-    """VDET_GRAPH_PIPE=1 with a bit-matrix budget that cuts the video into many batches: K2 of batch i runs on the context's
-    second stream next to K1s of batch i+1 (two bit-matrix buffers, events both ways).  Several videos through one context;
-    survivors and tubelets identical to the single-stream build and to the oracle."""
+def test_graph_build_in_many_batches(monkeypatch, oracle, irregular):
+    """VDET_BITS_BUDGET_MB=1: a bit-matrix budget that cuts the video into many batches (K1s / K1 / K2 per batch, one
+    bit-matrix buffer reused).  Several videos through one context; survivors and tubelets identical to the one-batch build
+    and to the oracle."""
     import torch
     from vdetlib_amd import ops, _lib
     kw = dict(nms_thres=0.3, thres=0.2, max_tracks=3, link_thres=0.5)
     plain = _lib.Context(torch.cuda.current_device())
-    monkeypatch.setenv("VDET_GRAPH_PIPE", "1")
     monkeypatch.setenv("VDET_BITS_BUDGET_MB", "1")
-    piped = _lib.Context(torch.cuda.current_device())
+    cut = _lib.Context(torch.cuda.current_device())
     for seed in (71, 72, 73):
         boxes, scores = _fused_case(seed, 17, 1300, 4, irregular)
         tb, ts = torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda()
         res = []
-        for cx in (plain, piped):
+        for cx in (plain, cut):
             try:
                 res.append(ops.nms_track_volume(tb, ts, ctx=cx, **kw))
             except ZeroDivisionError:           # (a degenerate box met its twin: the reference raises, so do both builds)
@@ -427,81 +420,69 @@ def test_pipelined_graph_build(monkeypatch, oracle, irregular):
             assert np.array_equal(a.cpu().numpy(), b.cpu().numpy(), equal_nan=True), seed
         widx, wcnt = oracle.nms_volume(boxes, scores, 0.3)
         assert np.array_equal(res[1][1].cpu().numpy(), wcnt) and np.array_equal(res[1][0].cpu().numpy(), widx)
-    plain.close(); piped.close()
+    plain.close(); cut.close()
 
 
 def test_link_memo_shares_steps_across_chains(oracle):
-    """Coherent proposals, several classes: chains of different classes / tracks run through the same nodes, so the
-    link memo serves a large share of the steps (vdet_query 4 / 5) -- with tubelets identical to the oracle's.  Frames
-    this small get their whole link table up front (link_fill_kernel): then NO step is ever scanned; VDET_LINK_FILL=0
-    keeps the warm-up + scan-on-miss scheme of large frames."""
-    import os
+    """Coherent proposals, several classes, frames too large for the up-front link table (> 1 024 proposals): chains of
+    different classes / tracks run through the same nodes, so the link memo serves a large share of the steps
+    (vdet_query 4 / 5; 6 / 7 for the warm-up) -- with tubelets identical to the oracle's."""
     import torch
     from vdetlib_amd import ops, _lib
-    boxes, scores = synth.coherent_video(77, 40, 300, 6)
+    boxes, scores = synth.coherent_video(77, 30, 1100, 6)
     tb, ts = torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda()
-    os.environ["VDET_LINK_FILL"] = "0"
-    try:
-        cx = _lib.Context(torch.cuda.current_device())
-    finally:
-        del os.environ["VDET_LINK_FILL"]
+    cx = _lib.Context(torch.cuda.current_device())
     tr, an, nt = ops.track_volume(tb, ts, thres=0.0, max_tracks=8, ctx=cx)
     # steps found in the memo / scanned, by the tracking loop (4, 5) and by the warm-up of the predicted anchors (6, 7);
     # tubelets of predicted anchors are copied from the materialised warm chains, so the loop may have nothing left to do
     hits, misses = cx.query(4) + cx.query(6), cx.query(5) + cx.query(7)
     assert misses > 0
-    assert hits > 0          # 48 chains on 300 coherent proposals do meet
+    assert hits > 0          # 48 chains on coherent proposals do meet
     for c in (0, 5):
         wt, wa, wn = oracle.greedy_track_volume(boxes, scores[:, :, c], 0.3, 0.0, 8, 0.5, 0)
         assert int(nt[c]) == wn and np.array_equal(tr[c, :wn].cpu().numpy(), wt[:wn], equal_nan=True)
     cx.close()
-    cf = _lib.Context(torch.cuda.current_device())          # default: the whole table first
-    tr2, an2, nt2 = ops.track_volume(tb, ts, thres=0.0, max_tracks=8, ctx=cf)
-    assert cf.query(5) + cf.query(7) == 0                    # nothing was scanned by a chain
-    assert torch.equal(nt, nt2) and torch.equal(an, an2) and torch.equal(tr.nan_to_num(-7.0), tr2.nan_to_num(-7.0))
-    cf.close()
 
 
-@pytest.mark.parametrize("case", ["frac", "irregular", "max_frames"])
-def test_link_table_up_front_equals_scanning_on_demand(case):
-    """link_fill_kernel (every node's next() at once) against the chains' own window scans on fractional boxes (the int
-    truncation of the current box matters), on a video with irregular frames (plain arg-max over all boxes) and with a
-    tubelet length limit"""
-    import os
+@pytest.mark.parametrize("case", ["plain", "frac", "irregular", "max_frames"])
+def test_link_table_up_front(oracle, case):
+    """frames of <= 1 024 proposals: link_fill_frame_kernel computes every node's next() at once and NO chain ever scans
+    (vdet_query 5 / 7 == 0) -- on fractional boxes (the int truncation of the current box matters), on a video with
+    irregular frames (plain arg-max over all boxes) and with a tubelet length limit; tubelets identical to the oracle's"""
     import torch
     from vdetlib_amd import ops, _lib
     boxes, scores = synth.coherent_video(91, 24, 260, 4, jitter=4, frac=(case == "frac"))
     if case == "irregular":
         boxes[5, 7, 0] = np.nan
         boxes[11, 3] = np.array([50, 60, 49, 90], np.float32)        # zero width
-    kw = dict(thres=0.2, max_tracks=6, link_thres=0.45, max_frames=7 if case == "max_frames" else 0)
+    mf = 7 if case == "max_frames" else 0
+    kw = dict(thres=0.2, max_tracks=6, link_thres=0.45, max_frames=mf)
     tb, ts = torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda()
-    res = []
-    for fill, lds in (("0", "1"), ("1024", "1"), ("1024", "0")):     # scans on demand / the table from LDS-staged frames / by quads
-        os.environ["VDET_LINK_FILL"] = fill
-        os.environ["VDET_LINK_FILL_LDS"] = lds
+    cx = _lib.Context(torch.cuda.current_device())
+    try:
+        got = ops.track_volume(tb, ts, ctx=cx, **kw)
+    except ZeroDivisionError:
+        got = None
+    if got is not None:
+        assert cx.query(5) + cx.query(7) == 0                    # nothing was scanned by a chain
+    for c in range(4):
         try:
-            cx = _lib.Context(torch.cuda.current_device())
-        finally:
-            del os.environ["VDET_LINK_FILL"]
-            del os.environ["VDET_LINK_FILL_LDS"]
-        try:
-            res.append(ops.track_volume(tb, ts, ctx=cx, **kw))
+            want = oracle.greedy_track_volume(boxes, scores[:, :, c], 0.3, 0.2, 6, 0.45, mf)
         except ZeroDivisionError:
-            res.append(None)
-        cx.close()
-    assert (res[0] is None) == (res[1] is None) == (res[2] is None)
-    if res[0] is not None:
-        for other in res[1:]:
-            for a, b in zip(res[0], other):
-                assert torch.equal(a.nan_to_num(-7.0), b.nan_to_num(-7.0))
+            want = None
+        if got is None or want is None:
+            continue                                             # (the by-class error rule is test_fused_*'s subject)
+        wt, wa, wn = want
+        assert int(got[2][c]) == wn, (case, c)
+        assert np.array_equal(got[1][c, :wn].cpu().numpy(), wa[:wn]), (case, c)
+        assert np.array_equal(got[0][c, :wn].cpu().numpy(), wt[:wn], equal_nan=True), (case, c)
+    cx.close()
 
 
 def test_coherent_videos_get_their_anchors_predicted(oracle):
     """proposals that persist over the frames (large frames: no up-front link table): the raw best detections of a class are
     one object in every frame; the extra warm-anchor slots predict the OTHER objects' anchors the way the loop will pick them,
-    so the tracking loop scans (almost) nothing itself -- with tubelets identical to the oracle's and to VDET_LINK_COHERENT=0"""
-    import os
+    so the tracking loop scans (almost) nothing itself -- with tubelets identical to the oracle's"""
     import torch
     from vdetlib_amd import ops, _lib
     rng = np.random.RandomState(5)
@@ -515,20 +496,12 @@ def test_coherent_videos_get_their_anchors_predicted(oracle):
     scores = (obj[None] + 0.05 * rng.rand(F, B, C)).astype(np.float32)
     tb, ts = torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda()
     kw = dict(nms_thres=0.3, thres=0.5, max_tracks=10, link_thres=0.5)
-    res, scanned = [], []
-    for knob in ("0", "1"):
-        os.environ["VDET_LINK_COHERENT"] = knob
-        try:
-            cx = _lib.Context(torch.cuda.current_device())
-        finally:
-            del os.environ["VDET_LINK_COHERENT"]
-        res.append(ops.track_volume(tb, ts, ctx=cx, **kw))
-        scanned.append(cx.query(5))                      # link steps the tracking LOOP had to scan itself
-        cx.close()
-    for a, b in zip(*res):
-        assert torch.equal(a.nan_to_num(-7.0), b.nan_to_num(-7.0))
-    assert scanned[0] > 0 and scanned[1] < scanned[0] // 2, scanned      # the predicted anchors' chains were warmed up front
-    tr, an, nt = [t.cpu().numpy() for t in res[1]]
+    cx = _lib.Context(torch.cuda.current_device())
+    res = ops.track_volume(tb, ts, ctx=cx, **kw)
+    loop_scanned, warm_scanned = cx.query(5), cx.query(7)        # link steps the tracking LOOP / the warm-up scanned
+    cx.close()
+    assert warm_scanned > 0 and loop_scanned < warm_scanned, (loop_scanned, warm_scanned)      # most scans happen in the chip-filling warm-up
+    tr, an, nt = [t.cpu().numpy() for t in res]
     for c in range(C):
         wt, wa, wn = oracle.greedy_track_volume(boxes, scores[:, :, c], 0.3, 0.5, 10, 0.5, 0)
         assert nt[c] == wn and np.array_equal(an[c, :wn], wa[:wn]) and np.array_equal(tr[c, :wn], wt[:wn], equal_nan=True)

@@ -266,17 +266,16 @@ def test_nms_volume_chains_stacks_hubs(torch_cuda, oracle, seed, t):
 
 
 def test_packed_walk_random_sweep(torch_cuda, monkeypatch):
-    """Sixteen / eight candidates per pass (walk_list_packed2 / walk_list_packed) against one survivor at a time (VDET_WALK_PACKED=0) on 150 random
+    """The packed walk of regular frames (eight candidates per pass over the K1s graph) against the general path -- the
+    all-pairs predicate kernel and one survivor at a time, what irregular frames take (VDET_FORCE_GENERAL=1) -- on 150 random
     volumes: frame sizes around the 64 / 128 / 256 boundaries, dense clusters (long lists, many in-group suppressions),
     integral / fractional boxes, tied scores, thresholds 0.05 .. 0.99, with and without a score threshold."""
     from vdetlib_amd import ops, _lib
     torch = torch_cuda
-    monkeypatch.setenv("VDET_WALK_PACKED", "0")
+    monkeypatch.setenv("VDET_FORCE_GENERAL", "1")
     cx0 = _lib.Context(torch.cuda.current_device())
-    monkeypatch.setenv("VDET_WALK_PACKED", "2")
-    cx8 = _lib.Context(torch.cuda.current_device())      # sixteen candidates per pass (walk_list_packed2)
-    monkeypatch.delenv("VDET_WALK_PACKED")
-    cx1 = _lib.Context(torch.cuda.current_device())      # the default: eight (walk_list_packed)
+    monkeypatch.delenv("VDET_FORCE_GENERAL")
+    cx1 = _lib.Context(torch.cuda.current_device())      # the default
     rng = np.random.RandomState(4242)
     for it in range(150):
         B = int(rng.choice([2, 3, 7, 63, 64, 65, 127, 128, 129, 255, 256, 257, 500, 1000, 2049]))
@@ -297,9 +296,7 @@ def test_packed_walk_random_sweep(torch_cuda, monkeypatch):
         st = None if rng.randint(2) else float(rng.uniform(0, 0.5))
         i0, c0 = ops.nms_volume(tb, ts, t, score_thresh=st, ctx=cx0)
         i1, c1 = ops.nms_volume(tb, ts, t, score_thresh=st, ctx=cx1)
-        i8, c8 = ops.nms_volume(tb, ts, t, score_thresh=st, ctx=cx8)
         assert torch.equal(c0, c1) and torch.equal(i0, i1), (it, B, F, C, t, kind)
-        assert torch.equal(c0, c8) and torch.equal(i0, i8), (it, B, F, C, t, kind)
 
 
 @pytest.mark.parametrize("kind", ["int", "frac"])
@@ -318,3 +315,30 @@ def test_dense_frames_whose_slabs_miss_the_k2_stage(torch_cuda, oracle, kind):
     scores = rng.rand(F, B, C).astype(np.float32)
     for t in (0.1, 0.3, 0.6):
         _check_volume(torch_cuda, oracle, boxes, scores, t)
+
+
+def test_cache_survives_another_geometry_in_between(torch_cuda, oracle):
+    """vdet_set_cache(1): nms_volume(A) -> det_nms_volume / argsort_volume on ANOTHER geometry (they rewrite the context's
+    group table) -> nms_volume(A) again must rebuild, not walk A's lists with the other geometry's groups"""
+    torch = torch_cuda
+    from vdetlib_amd import ops, _lib
+    cx = _lib.Context(0)
+    cx.set_cache(True)
+    try:
+        bA, sA = synth.video(4101, 6, 500, 4)
+        tbA, tsA = torch.from_numpy(bA).cuda(), torch.from_numpy(sA).cuda()
+        wantA = oracle.nms_volume(bA, sA, 0.3, cap=500)
+        for other in ("det", "argsort"):
+            i1, c1 = ops.nms_volume(tbA, tsA, 0.3, ctx=cx)
+            assert np.array_equal(i1.cpu().numpy(), wantA[0]) and np.array_equal(c1.cpu().numpy(), wantA[1])
+            bB, sB = synth.video(4102, 9, 333, 3)
+            if other == "det":
+                BX = torch.from_numpy(np.repeat(bB[:, :, None, :], 3, axis=2).copy()).cuda()
+                ops.det_nms_volume(BX, torch.from_numpy(sB).cuda(), score_thresh=0.05, topk=50, nms_thresh=0.3, ctx=cx)
+            else:
+                ops.argsort_volume(torch.from_numpy(sB).cuda(), ctx=cx)
+            i2, c2 = ops.nms_volume(tbA, tsA, 0.3, ctx=cx)
+            assert np.array_equal(c2.cpu().numpy(), wantA[1]), other
+            assert np.array_equal(i2.cpu().numpy(), wantA[0]), other
+    finally:
+        cx.close()

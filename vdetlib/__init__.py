@@ -33,9 +33,17 @@ class _AliasFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
         return importlib.util.spec_from_loader(fullname, self, is_package=spec.submodule_search_locations is not None)
 
     def create_module(self, spec):
-        return importlib.import_module(_REAL + spec.name[len(_PREFIX):])
+        module = importlib.import_module(_REAL + spec.name[len(_PREFIX):])
+        # importlib assigns module.__spec__ = <alias spec> after this returns; the real module must keep its own spec
+        # (importlib.reload, __package__ == __spec__.parent, the package's submodule_search_locations): restored below
+        spec.loader_state = getattr(module, "__spec__", None)
+        return module
 
     def exec_module(self, module):
+        alias = getattr(module, "__spec__", None)
+        real = getattr(alias, "loader_state", None)
+        if real is not None:
+            module.__spec__ = real
         return None
 
 
@@ -46,5 +54,7 @@ def __getattr__(name):
     # ``import vdetlib; vdetlib.utils`` and ``from vdetlib import utils``
     try:
         return importlib.import_module(_PREFIX + name)
-    except ImportError:
-        raise AttributeError(name)
+    except ModuleNotFoundError as e:
+        if e.name in (_PREFIX + name, _REAL + name):     # only "there is no such submodule"; a missing dependency propagates
+            raise AttributeError(name)
+        raise

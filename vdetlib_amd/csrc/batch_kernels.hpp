@@ -88,19 +88,7 @@ __device__ __forceinline__ VidView vid_view(const BatchTrack &bt, const int v)
 __global__ __launch_bounds__(256) void batch_warm_anchors_kernel(const BatchTrack bt)
 {
     const VidView w = vid_view(bt, blockIdx.y);
-    track_warm_anchors_body(blockIdx.x, w.keys, w.lists, w.cnt, w.F, bt.B, bt.C, w.scores, bt.thres, bt.wm, w.warm, BucketLists{nullptr, nullptr}, WarmExtra{nullptr, 0.f, 0, 0});
-}
-
-// grid (ceil(Fmax * B * kFillLanes / 256), 2, V): the whole link table of every video (link_fill_node)
-__global__ __launch_bounds__(256) void batch_link_fill_kernel(const BatchTrack bt)
-{
-    const VidView w = vid_view(bt, blockIdx.z);
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t n = t / kFillLanes;
-    if (n >= (int64_t)w.F * bt.B) return;
-    const int f = (int)(n / bt.B);
-    link_fill_node(f, (int)(n - (int64_t)f * bt.B), blockIdx.y == 0 ? 1 : -1, (int)(t & (kFillLanes - 1)), w.boxes, w.F, bt.B, bt.link_t32,
-                   w.group_flags, w.ix, bt.link_thres, w.memo);
+    track_warm_anchors_body(blockIdx.x, w.keys, w.lists, w.cnt, w.F, bt.B, bt.C, w.scores, bt.thres, bt.wm, w.warm, WarmExtra{nullptr, 0.f, 0, 0});
 }
 
 // grid (Fmax, 2, V), block = 64 * ceil(B / 64): the same table with the neighbour frame's index staged in LDS (link_fill_frame)
@@ -215,8 +203,20 @@ __global__ __launch_bounds__(256) void batch_rescore_series_kernel(const BatchTr
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char series_smem[];
     const VidView w = vid_view(bt, blockIdx.y);
+    if (w.F > kSeriesWaveMaxF) return;       // (a long video: batch_rescore_series_long_kernel)
     const int64_t o = (int64_t)bt.C * bt.T * w.f0;
     rescore_series_wave_body(blockIdx.x, series_smem, sc + o, out2 + o, w.ntracks, w.F, bt.C, bt.T, window, err, stride_bytes);
+}
+
+// ... of the videos with more than kSeriesWaveMaxF frames (the LDS stage of the wave form does not hold their series): one
+// thread per series, like the single-video entry point's rescore_series_kernel.  grid (ceil(C * T / 64), V), 64 threads
+__global__ __launch_bounds__(64) void batch_rescore_series_long_kernel(const BatchTrack bt, double *__restrict__ sc, double *__restrict__ out2,
+                                                                       int window, int *__restrict__ err)
+{
+    const VidView w = vid_view(bt, blockIdx.y);
+    if (w.F <= kSeriesWaveMaxF) return;
+    const int64_t o = (int64_t)bt.C * bt.T * w.f0;
+    rescore_series_serial_body(blockIdx.x * 64 + threadIdx.x, sc + o, out2 + o, w.ntracks, w.F, bt.C, bt.T, window, err);
 }
 
 }  // namespace vdet

@@ -41,6 +41,7 @@ __global__ __launch_bounds__(256) void det_nms_kernel(const DetNmsParams prm)
 {
     __shared__ float4 sbox[4][kDetMax];
     __shared__ int sidx[4][kDetMax];
+    __shared__ uint32_t skey[4][kDetMax];
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int p = blockIdx.x * 4 + w;
     if (p >= prm.F * prm.K) return;
@@ -67,11 +68,15 @@ __global__ __launch_bounds__(256) void det_nms_kernel(const DetNmsParams prm)
             sc[h] = prm.scores[e];
             sbox[w][q] = bx[h];
             sidx[w][q] = id[h];
+            skey[w][q] = score_key(sc[h]);
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
-    // row position of candidate q in the reference's array: its rank by box index, or q itself after the cut
+    // row position of candidate q in the reference's array: its rank by box index, or -- after the cut -- its position in
+    // argsort(-score)[:k] (vdet/video_det.py:93-97; stable: equal scores by ASCENDING box index).  The list holds a run of
+    // equal scores [a, b) by DESCENDING index (the order the NMS of those rows visits them: ties by descending row), so
+    // inside a run the row positions are mirrored: row = a + (b - 1 - q)
     int row[2] = {lane, lane + 64};
     if (by_index) {
         row[0] = row[1] = 0;
@@ -79,6 +84,18 @@ __global__ __launch_bounds__(256) void det_nms_kernel(const DetNmsParams prm)
             const int v = sidx[w][q];
             row[0] += v < id[0] ? 1 : 0;
             row[1] += v < id[1] ? 1 : 0;
+        }
+    } else {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int q = lane + 64 * h;
+            if (q < M) {
+                const uint32_t k = skey[w][q];
+                int a = q, b = q + 1;
+                while (a > 0 && skey[w][a - 1] == k) --a;
+                while (b < M && skey[w][b] == k) ++b;
+                row[h] = a + (b - 1 - q);
+            }
         }
     }
     const int64_t obase = (int64_t)p * prm.topk;

@@ -87,14 +87,6 @@ __device__ __forceinline__ void lds_only_barrier()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-// bucketed list entries (bucket_kernels.hpp): {ord : 16 | 0x3FFF ^ box index : 14 | first of its bucket : 1} -- the flag sits
-// below the index, so comparing two entries as integers never looks at it (two entries differ in ord or index)
-constexpr uint32_t kBkIdxMask = 0x3FFFu;
-constexpr uint32_t kBkFlag = 1u;
-__device__ __forceinline__ int bucket_entry_index(uint32_t e) { return (int)(kBkIdxMask ^ ((e >> 1) & kBkIdxMask)); }
-// two DIFFERENT entries of one bucket whose order their values do not decide: equal ord
-__device__ __forceinline__ bool bucket_entries_tied(uint32_t a, uint32_t b) { return ((a ^ b) >> 15) == 0u && ((a ^ b) >> 1) != 0u; }
-
 // status bits latched by kernels into ctx->d_status
 constexpr int kStCap = 1;       // survivors > cap
 constexpr int kStDivZero = 2;   // evaluated zero-union pair
@@ -1011,7 +1003,6 @@ struct SortParams {
     uint16_t *order;          // mode 0/1: [P,B]; mode 2: flat [Ntot] at the group's box_off
     int32_t *ncand;           // [P]
     int lds_idxa_off, lds_idxb_off, lds_base_off;   // dynamic-LDS carve, multiples of 16
-    int npass;                // 4 (debug knob VDET_SORT_PASSES: fewer passes = timing experiments only)
     int topk;                 // > 0: only the topk best candidates stay candidates (vdet/video_det.py:93-95)
     int32_t *nover;           // [P] or null: candidates BEFORE the topk cut (vdet/video_det.py:93 tests len(cls_scores) > max_per_image)
 };
@@ -1139,7 +1130,7 @@ __device__ __forceinline__ void lsd_sort_problem(const SortParams &prm, const in
     const int nchunks = (N + 63) >> 6;
     const int c0 = w * CPW;                      // host guarantees NW * CPW >= nchunks
 
-    for (int pass = 0; pass < prm.npass; ++pass) {
+    for (int pass = 0; pass < 4; ++pass) {
         const int shift = (pass & 1) * 8;
         if (pass == 2) {                       // every gather of the low halves is done (barrier at the end of pass 1)
 #pragma unroll
@@ -1406,15 +1397,9 @@ struct WalkParams {
     int mask_words;           // u32 words of one wave's dead mask
     const uint32_t *group_flags;   // kFlagRegular per group (the K1s path ran), or null
     int wave_words;           // u32 words of LDS per wave (mask + the packed walk's ring)
-    int packed;               // regular frames take walk_list_packed (1) / walk_list_packed2 (2: sixteen candidates per pass)
+    int packed;               // regular frames take walk_list_packed (eight candidates per pass)
     const WalkMeta *wmeta;    // per box: coordinates + list (adj_build_kernel), and the graph's threshold: the packed walk
     float t32;                // tests the members of a group against each other geometrically
-    // bucketed lists (round 4, bucket_kernels.hpp); ent == null: every list is a sorted `order` row
-    const uint32_t *ent;      // [P,B] entries, bucket by bucket
-    const int32_t *nsb;       // [P] < 0: this list is a sorted `order` row after all (LSD fallback)
-    const uint32_t *bk_raw;   // [P,B] what the buckets were cut from: sortable keys, or float32 scores (bk_floats)
-    int bk_floats;
-    int dbg;                  // VDET_WALK_DBG (timing experiments only; results invalid): 1 no ranking of the alive lanes, 2 no equal-key check
 };
 
 // LDS words through which the lanes of one wave talk to each other (the walks' dead masks): every
@@ -1506,45 +1491,9 @@ __device__ __forceinline__ void walk_group(lds_mask_t mask, const uint16_t *__re
 }
 
 
-// REGULAR frames (finite boxes, positive areas; graph built by iou_bits_sym_kernel): the suppression graph is
-// SYMMETRIC and has no zero-union tags.  Then a candidate that was alive when its chunk started is a survivor iff
-// its dead bit is still clear when the chunk is done -- a later survivor of the chunk can not set it (if j
-// suppressed i, i would have suppressed j) -- so the chunk's survivors are read off the mask once per chunk
-// instead of being book-kept per survivor, a suppressed candidate costs no branch (its list length is zeroed with
-// a scalar select), and the long-list test is hoisted out per chunk (LONG).  The walk issues as many SALU as VALU
-// instructions (profiles/r02_pmc_sq2.csv: the scalar unit is the busier one); this form drops ~6 of the ~15 scalar
-// instructions per survivor.
-template <bool LONG>
-__device__ __forceinline__ void walk_group_regular(lds_mask_t mask, const uint16_t *__restrict__ adj, int lane, int c,
-                                                   uint32_t off, int deg, const int (&ls)[kWalkGrp], int ng,
-                                                   const uint32_t (&pre)[kWalkGrp])
-{
-    // (measured and rejected: one look at the mask per GROUP + testing in registers whether an earlier member's list
-    //  contains a later member -- no LDS round trip on the chain, but 12 half-rate compares per group: 6.0 vs 4.6 ms)
-#pragma unroll
-    for (int k = 0; k < kWalkGrp; ++k) {
-        if (k >= ng) break;
-        const int cu = __builtin_amdgcn_readlane(c, ls[k]);
-        const uint32_t dead = __builtin_amdgcn_readfirstlane((mask[cu >> 5] >> (cu & 31)) & 1u);
-        int d = __builtin_amdgcn_readlane(deg, ls[k]);
-        d = dead ? 0 : d;                                  // (scalar select: no branch for a suppressed candidate)
-        if (2 * lane < d) {
-            const uint32_t e0 = pre[k] & 0xFFFFu, e1 = pre[k] >> 16;
-            lds_or(mask, e0 >> 5, 1u << (e0 & 31));
-            lds_or(mask, e1 >> 5, 1u << (e1 & 31));
-        }
-        if (LONG && d > 128) {   // rare: long lists
-            const uint32_t o = __builtin_amdgcn_readlane(off, ls[k]);
-            for (int e0 = 128; e0 < d; e0 += 64) {
-                const uint32_t e = adj[o + min(e0 + lane, d - 1)];
-                if (e0 + lane < d) lds_or(mask, e >> 5, 1u << (e & 31));
-            }
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
-// The PACKED walk of a regular frame's list (round 2).  The walk above spends ~50 instructions per survivor, half of
+// The PACKED walk of a REGULAR frame's list (finite boxes, positive areas; graph built by iou_bits_sym_kernel: symmetric,
+// no zero-union tags).  The general walk (walk_group, below in walk_one) spends ~50 instructions per survivor, half of
 // them scalar (one survivor at a time: broadcast its id, look at its bit, select its length, mask the lanes), and
 // the scalar unit is its bottleneck.  Here EIGHT alive candidates are handled by one pass of vector code, 8 lanes
 // each: a lane loads 16 entries (32 B) of its member's adjacency list -- once the member is known to survive -- and ORs
@@ -1720,271 +1669,6 @@ __device__ __forceinline__ void walk_list_packed(const WalkParams &prm, lds_mask
     nk_out = nk;
 }
 
-// ------------------------------------------------------------------------------------------------
-// The packed walk over a BUCKETED list (round 4; bucket_kernels.hpp): the list arrives cut into score-ordered buckets of a
-// few entries {ord : 16 | 0x3FFF ^ index : 14 | first of its bucket : 1} in arrival order, laid out so that every aligned
-// chunk of 64 entries holds whole buckets.  Same passes over the same chunks as walk_list_packed; the lanes whose box is
-// still alive rank themselves by (bucket inside the chunk, ord) -- a loop of lane broadcasts over the alive lanes only:
-// ~1 400 of a list's 10 000 entries are ever ranked -- and enter the ring of alive candidates at head + rank instead of
-// head + lane prefix.  Everything behind the ring is walk_list_packed's.
-// Two alive entries of a bucket with equal ord (equal keys, or two keys of a thin histogram bin that interpolate to the
-// same 1/8192 rank) are not ordered by their entry values: the pass then ranks its alive lanes by the full keys.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void walk_list_bucketed(const WalkParams &prm, lds_mask_t mask, const int lane, const int rb,
-                                                   const uint32_t *__restrict__ ent, const uint32_t *__restrict__ raw, const int ncand,
-                                                   int32_t *__restrict__ out, const int64_t cap, int &nk_out)
-{
-    lds_mask_t ring = mask + prm.mask_words;
-    lds_f4_t ringb = (lds_f4_t)ring;                              // slot s: words 8s .. 8s+3 = meta, float4 2s+1 = box
-    const WalkMeta *__restrict__ wmeta = prm.wmeta + rb;
-    const float t32 = prm.t32;
-    int qh = 0, qn = 0, nk = 0;                                   // ring head, queued candidates, survivors (wave-uniform)
-    const int last = max(ncand - 1, 0);
-    uint32_t e_cur = ent[(uint32_t)min(lane, last)];
-    uint32_t e_nxt = ent[(uint32_t)min(64 + lane, last)];
-    uint2 m_cur = make_uint2(0u, 0u);
-    float4 b_cur = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (lane < ncand) {                                           // chunk 0: everything is alive
-        const WalkMeta *wm = wmeta + (uint32_t)bucket_entry_index(e_cur);
-        b_cur = wm->box; const uint4 rw = wm->row; m_cur = make_uint2(rw.x, rw.y);
-    }
-    for (int q0 = 0; q0 < ncand; q0 += 64) {
-        const uint32_t e = e_cur;
-        const int c = bucket_entry_index(e);
-        const uint32_t e_nn = ent[(uint32_t)min(q0 + 128 + lane, last)];
-        const int c_nxt = bucket_entry_index(e_nxt);
-        uint2 m_nxt = make_uint2(0u, 0u);
-        float4 b_nxt = make_float4(0.f, 0.f, 0.f, 0.f);
-        if ((q0 + 64 + lane) < ncand && !((mask[c_nxt >> 5] >> (c_nxt & 31)) & 1u)) {
-            const WalkMeta *wm = wmeta + (uint32_t)c_nxt;
-            b_nxt = wm->box; const uint4 rw = wm->row; m_nxt = make_uint2(rw.x, rw.y);
-        }
-        const bool valid = (q0 + lane) < ncand;
-        const bool alive = valid && !((mask[c >> 5] >> (c & 31)) & 1u);
-        const unsigned long long am = __ballot(alive);
-        const int na = __popcll(am);
-        if (na) {                                                 // (scalar branch)
-            uint32_t rank = 0u, key = 0u;
-            // a chunk of one-entry buckets (the head of the list, ordered by bucket_kernel; ordered buckets elsewhere): lane order
-            const unsigned long long fm = __ballot(valid && (e & kBkFlag) != 0u);
-            const bool exact = fm == __ballot(valid);
-            if (exact || (prm.dbg & 1)) {
-                rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));
-            } else if (na > 1) {
-                // rank key: buckets of a chunk in lane order, entries of a bucket by ord
-                const uint32_t bid = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u)) +
-                                     ((e & kBkFlag) ? 1u : 0u);
-                key = (bid << 16) | (e >> 15);
-                unsigned long long t = am;
-                while (t) {                                       // two alive lanes per turn
-                    const int l0 = __ffsll((unsigned long long)t) - 1;
-                    t &= t - 1;
-                    const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)key, l0);
-                    uint32_t k1 = 0xFFFFFFFFu;
-                    if (t) {
-                        const int l1 = __ffsll((unsigned long long)t) - 1;
-                        t &= t - 1;
-                        k1 = (uint32_t)__builtin_amdgcn_readlane((int)key, l1);
-                    }
-                    rank += (k0 < key ? 1u : 0u) + (k1 < key ? 1u : 0u);
-                }
-            }
-            const int slot0 = qh + qn;
-            if (alive) {
-                const int s = ring_wrap(slot0 + (int)rank);
-                ring[8 * s] = (uint32_t)c;
-                ring[8 * s + 1] = m_cur.x;
-                ring[8 * s + 2] = m_cur.y;
-                lds_f4v bv; bv.x = b_cur.x; bv.y = b_cur.y; bv.z = b_cur.z; bv.w = b_cur.w;
-                ringb[2 * s + 1] = bv;
-            }
-            if (na > 1 && !exact && !(prm.dbg & 3)) {
-                // equal keys share a slot: does the slot hold what this lane wrote?  (the wave's LDS queue is in order)
-                const bool clash = alive && ring[8 * ring_wrap(slot0 + (int)rank)] != (uint32_t)c;
-                const unsigned long long cm = __ballot(clash);
-                if (cm != 0ull) {                                 // rare: rank the alive lanes by their full keys
-                    uint32_t ikf = 0u;
-                    if (alive) {
-                        const uint32_t r = raw[(uint32_t)c];
-                        ikf = ~(prm.bk_floats ? score_key(__uint_as_float(r)) : r);
-                    }
-                    uint32_t rank2 = 0u;
-                    unsigned long long t = am;
-                    while (t) {
-                        const int l = __ffsll((unsigned long long)t) - 1;
-                        t &= t - 1;
-                        const uint32_t kl = (uint32_t)__builtin_amdgcn_readlane((int)key, l);
-                        const uint32_t il = (uint32_t)__builtin_amdgcn_readlane((int)ikf, l);
-                        const int cl = __builtin_amdgcn_readlane(c, l);
-                        rank2 += (kl < key || (kl == key && (il < ikf || (il == ikf && cl > c)))) ? 1u : 0u;
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    if (alive) {
-                        const int s = ring_wrap(slot0 + (int)rank2);
-                        ring[8 * s] = (uint32_t)c;
-                        ring[8 * s + 1] = m_cur.x;
-                        ring[8 * s + 2] = m_cur.y;
-                        lds_f4v bv; bv.x = b_cur.x; bv.y = b_cur.y; bv.z = b_cur.z; bv.w = b_cur.w;
-                        ringb[2 * s + 1] = bv;
-                    }
-                }
-            }
-            qn += na;
-        }
-        walk_ring_drain(prm, mask, ring, ringb, lane, t32, q0 + 64 >= ncand, qh, qn, nk, out, cap);
-        e_cur = e_nxt; e_nxt = e_nn; m_cur = m_nxt; b_cur = b_nxt;
-    }
-    nk_out = nk;
-}
-
-// ------------------------------------------------------------------------------------------------
-// SIXTEEN candidates per pass (round 3).  The packed walk above is bound by its chain of dependent steps: every
-// group of 8 waits one L2 round trip for its survivors' lists before the next group can look at the dead mask
-// (~175 groups x ~2 us per (frame, class) problem at 8 waves per SIMD -- the hardware's limit -- is the kernel's
-// 3 ms).  The same argument that makes a group legal makes TWO groups legal at once: whether a survivor of the first
-// eight (A) suppresses a member of the next eight (B) is a property of their two boxes, so lane (i, j) also evaluates
-// pair (A_i, B_j) and (B_i, B_j), three ballots give the 16 x 16 conflict matrix, and B's members need not wait for
-// A's lists to land in the mask.  All sixteen lists are requested together: one round trip per sixteen candidates.
-// Same survivors in the same order as walk_list_packed (VDET_WALK_PACKED=1 selects it; tested against each other
-// and against the one-at-a-time walk).
-// ------------------------------------------------------------------------------------------------
-constexpr int kPackRing2 = 88;                 // >= 15 left over + 64 of a chunk
-__device__ __forceinline__ int ring_wrap2(int s) { return s >= kPackRing2 ? s - kPackRing2 : s; }
-
-__device__ __forceinline__ void walk_list_packed2(const WalkParams &prm, lds_mask_t mask, const int lane, const int rb,
-                                                  const uint16_t *__restrict__ order, const int ncand,
-                                                  int32_t *__restrict__ out, const int64_t cap, int &nk_out)
-{
-    lds_mask_t ring = mask + prm.mask_words;
-    lds_f4_t ringb = (lds_f4_t)ring;                              // slot s: words 8s .. 8s+3 = meta, float4 2s+1 = box
-    const WalkMeta *__restrict__ wmeta = prm.wmeta + rb;
-    const float t32 = prm.t32;
-    const int k = lane >> 3, sub = lane & 7;
-    constexpr unsigned long long M = 0x0101010101010101ull;
-    int qh = 0, qn = 0, nk = 0;                                   // ring head, queued candidates, survivors (wave-uniform)
-    const int last = max(ncand - 1, 0);
-    int c_cur = (int)order[(uint32_t)min(lane, last)];
-    int c_nxt = (int)order[(uint32_t)min(64 + lane, last)];
-    uint2 m_cur = make_uint2(0u, 0u);
-    float4 b_cur = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (lane < ncand) {                                           // chunk 0: everything is alive
-        const WalkMeta *wm = wmeta + (uint32_t)c_cur;
-        b_cur = wm->box; const uint4 rw = wm->row; m_cur = make_uint2(rw.x, rw.y);
-    }
-    // the survivors' lists of one group -> dead bits (see walk_list_packed: aligned 16-byte pieces, whole pieces applied)
-    auto apply = [&](const AdjVec &a0, const AdjVec &a1, bool has0, bool has1, uint32_t off, int deg) {
-        if (has0) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const uint32_t d = a0.v[t];
-                lds_or_pair(mask, d);
-            }
-        }
-        if (__ballot(has1) != 0ull) {
-            if (has1) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const uint32_t d = a1.v[t];
-                    lds_or_pair(mask, d);
-                }
-            }
-            unsigned long long lg = __ballot(sub == 0 && deg > 128);
-            while (lg) {                                             // rare: long lists
-                const int l = __ffsll((unsigned long long)lg) - 1;
-                lg &= lg - 1;
-                const uint32_t o = __builtin_amdgcn_readlane(off, l);
-                const int dl = __builtin_amdgcn_readlane(deg, l);
-                for (int e0 = 128; e0 < dl; e0 += 64) {
-                    const uint32_t e = prm.adj[o + min(e0 + lane, dl - 1)];
-                    if (e0 + lane < dl) lds_or(mask, (int)(e >> 5), 1u << (e & 31u));
-                }
-            }
-        }
-    };
-    for (int q0 = 0; q0 < ncand; q0 += 64) {
-        const int c = c_cur;
-        const int c_nn = (int)order[(uint32_t)min(q0 + 128 + lane, last)];
-        uint2 m_nxt = make_uint2(0u, 0u);
-        float4 b_nxt = make_float4(0.f, 0.f, 0.f, 0.f);
-        if ((q0 + 64 + lane) < ncand && !((mask[c_nxt >> 5] >> (c_nxt & 31)) & 1u)) {
-            const WalkMeta *wm = wmeta + (uint32_t)c_nxt;
-            b_nxt = wm->box; const uint4 rw = wm->row; m_nxt = make_uint2(rw.x, rw.y);
-        }
-        const bool alive = (q0 + lane) < ncand && !((mask[c >> 5] >> (c & 31)) & 1u);
-        const unsigned long long am = __ballot(alive);
-        if (alive) {
-            const int s = ring_wrap2(qh + qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u)));
-            ring[8 * s] = (uint32_t)c;
-            ring[8 * s + 1] = m_cur.x;
-            ring[8 * s + 2] = m_cur.y;
-            lds_f4v bv; bv.x = b_cur.x; bv.y = b_cur.y; bv.z = b_cur.z; bv.w = b_cur.w;
-            ringb[2 * s + 1] = bv;
-        }
-        qn += __popcll(am);
-        const bool flush = q0 + 64 >= ncand;
-        while (qn >= 16 || (flush && qn > 0)) {
-            const int nga = min(8, qn), ngb = min(8, qn - nga);
-            const int sa = ring_wrap2(qh + k), sb = ring_wrap2(qh + 8 + k);
-            const bool va = k < nga, vb = k < ngb;
-            const int cma = va ? (int)ring[8 * sa] : 0, cmb = vb ? (int)ring[8 * sb] : 0;
-            const lds_f4v via = ringb[2 * sa + 1], vja = ringb[2 * ring_wrap2(qh + sub) + 1];
-            const lds_f4v vib = ringb[2 * sb + 1], vjb = ringb[2 * ring_wrap2(qh + 8 + sub) + 1];
-            const float4 bia = make_float4(via.x, via.y, via.z, via.w), bja = make_float4(vja.x, vja.y, vja.z, vja.w);
-            const float4 bib = make_float4(vib.x, vib.y, vib.z, vib.w), bjb = make_float4(vjb.x, vjb.y, vjb.z, vjb.w);
-            const bool livea = va && !((mask[cma >> 5] >> (cma & 31)) & 1u);
-            const bool liveb = vb && !((mask[cmb >> 5] >> (cmb & 31)) & 1u);
-            const unsigned long long lma = __ballot(livea), lmb = __ballot(liveb);
-            const float aia = box_area(bia), aja = box_area(bja), aib = box_area(bib), ajb = box_area(bjb);
-            const bool haa = (pair_pred(bia, aia, bja, aja, t32) & 1u) != 0u;      // A_k suppresses A_sub
-            const bool hab = (pair_pred(bia, aia, bjb, ajb, t32) & 1u) != 0u;      // A_k suppresses B_sub
-            const bool hbb = (pair_pred(bib, aib, bjb, ajb, t32) & 1u) != 0u;      // B_k suppresses B_sub
-            const bool suba = ((lma >> (8 * sub)) & 1ull) != 0ull, subb = ((lmb >> (8 * sub)) & 1ull) != 0ull;
-            const unsigned long long caa = __ballot(haa && k < sub && livea && suba);
-            const unsigned long long cab = __ballot(hab && livea && subb);
-            const unsigned long long cbb = __ballot(hbb && k < sub && liveb && subb);
-            unsigned long long sva = lma & M, svb = lmb & M;           // bit 8k <=> member k survives
-            if (caa | cab | cbb) {
-                unsigned long long s1 = 0ull, s2 = 0ull;
-                for (int j = 0; j < 8; ++j) {
-                    const unsigned long long col = (caa >> j) & M;           // bit 8i <=> A_i suppresses A_j
-                    if (((lma >> (8 * j)) & 1ull) && !(col & s1)) s1 |= 1ull << (8 * j);
-                }
-                for (int j = 0; j < 8; ++j) {
-                    const unsigned long long ca = (cab >> j) & M, cb = (cbb >> j) & M;
-                    if (((lmb >> (8 * j)) & 1ull) && !(ca & s1) && !(cb & s2)) s2 |= 1ull << (8 * j);
-                }
-                sva = s1; svb = s2;
-            }
-            const bool sura = (sva >> (lane & 56)) & 1ull, surb = (svb >> (lane & 56)) & 1ull;
-            if (sva | svb) {
-                const int na = __popcll(sva);
-                const int posa = nk + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(sva >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sva, 0u));
-                const int posb = nk + na + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(svb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)svb, 0u));
-                if (sura && sub == 0 && (int64_t)posa < cap) out[(uint32_t)posa] = cma;
-                if (surb && sub == 0 && (int64_t)posb < cap) out[(uint32_t)posb] = cmb;
-                nk += na + __popcll(svb);
-                // all sixteen lists are requested before the first one is applied
-                const uint32_t offa = sura ? ring[8 * sa + 1] : 0u, offb = surb ? ring[8 * sb + 1] : 0u;
-                const int dega = sura ? (int)ring[8 * sa + 2] : 0, degb = surb ? (int)ring[8 * sb + 2] : 0;
-                const AdjVec *pa = reinterpret_cast<const AdjVec *>(prm.adj + offa);
-                const AdjVec *pb = reinterpret_cast<const AdjVec *>(prm.adj + offb);
-                const bool a_has0 = 8 * sub < dega, a_has1 = 64 + 8 * sub < dega;
-                const bool b_has0 = 8 * sub < degb, b_has1 = 64 + 8 * sub < degb;
-                const AdjVec a0 = pa[a_has0 ? sub : 0];
-                const AdjVec a1 = pa[a_has1 ? 8 + sub : 0];
-                const AdjVec b0 = pb[b_has0 ? sub : 0];
-                const AdjVec b1 = pb[b_has1 ? 8 + sub : 0];
-                apply(a0, a1, a_has0, a_has1, offa, dega);
-                apply(b0, b1, b_has0, b_has1, offb, degb);
-            }
-            qh = ring_wrap2(qh + nga + ngb);
-            qn -= nga + ngb;
-        }
-        c_cur = c_nxt; c_nxt = c_nn; m_cur = m_nxt; b_cur = b_nxt;
-    }
-    nk_out = nk;
-}
-
 // one list (problem p) walked by one wave (w = its index in the block: its slice of the dynamic LDS)
 __device__ __forceinline__ void walk_one(const WalkParams &prm, const int p, unsigned char *smem, const int lane, const int w)
 {
@@ -2011,10 +1695,7 @@ __device__ __forceinline__ void walk_one(const WalkParams &prm, const int p, uns
     int nk = 0;
     int bad = 0;
     if (regular && prm.packed && N >= 2) {     // (singleton groups have no graph: adj_build_kernel never saw them)
-        if (prm.ent && prm.nsb[p] >= 0)
-            walk_list_bucketed(prm, mask, lane, rb, prm.ent + pr.obase, prm.bk_raw + pr.obase, ncand, out, cap, nk);
-        else if (prm.packed == 2) walk_list_packed2(prm, mask, lane, rb, order, ncand, out, cap, nk);
-        else walk_list_packed(prm, mask, lane, rb, order, ncand, out, cap, nk);
+        walk_list_packed(prm, mask, lane, rb, order, ncand, out, cap, nk);
         if (lane == 0) prm.keep_cnt[p] = nk;
         if ((int64_t)nk > cap && lane == 0) atomicOr(prm.status, kStCap);
         return;
@@ -2045,7 +1726,6 @@ __device__ __forceinline__ void walk_one(const WalkParams &prm, const int p, uns
         unsigned long long kept_lanes = 0ull;
         const uint32_t off = m_cur.x;
         const int deg = (int)m_cur.y;
-        const bool any_long = regular && __ballot(alive && deg > 128) != 0ull;
         while (am) {
             int ls[kWalkGrp];
             int ng = 0;
@@ -2065,14 +1745,9 @@ __device__ __forceinline__ void walk_one(const WalkParams &prm, const int p, uns
                 const int d = __builtin_amdgcn_readlane(deg, ls[k]);
                 pre[k] = adjw[(o >> 1) + min(lane, (max(d, 1) - 1) >> 1)];
             }
-            if (regular) {
-                if (any_long) walk_group_regular<true>(mask, prm.adj, lane, c, off, deg, ls, ng, pre);
-                else walk_group_regular<false>(mask, prm.adj, lane, c, off, deg, ls, ng, pre);
-            } else if (has_z) walk_group<true>(mask, prm.adj, lane, c, off, deg, ls, ng, pre, kept_lanes, bad);
+            if (has_z) walk_group<true>(mask, prm.adj, lane, c, off, deg, ls, ng, pre, kept_lanes, bad);
             else walk_group<false>(mask, prm.adj, lane, c, off, deg, ls, ng, pre, kept_lanes, bad);
         }
-        if (regular)    // the chunk's survivors: alive when it started, bit still clear now (see walk_group_regular)
-            kept_lanes = __ballot(alive && !((mask[c >> 5] >> (c & 31)) & 1u));
         if (kept_lanes) {   // the chunk's survivors, in lane (= descending score) order, with one compacting store
             const int pos = nk + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(kept_lanes >> 32),
                                                                __builtin_amdgcn_mbcnt_lo((uint32_t)kept_lanes, 0u));

@@ -48,59 +48,6 @@ __device__ __forceinline__ bool at_or_before(uint32_t k, int flat, uint32_t ka, 
 // (score desc, flat index asc) == the stable descending sort of vdet/track.py:200.
 // keys: [F*C, B] sortable keys (transpose_keys_kernel);  lists: [F*C, B] u16;  cnt: [F*C].
 // ------------------------------------------------------------------------------------------------
-// Bucketed lists (round 4, bucket_kernels.hpp): a (frame, class) list may arrive as score-ordered BUCKETS of a few
-// entries {ord : 16 | 0x3FFF ^ index : 14 | first of its bucket : 1} instead of a sorted u16 row.  The tracking kernels
-// only ever read the HEAD of a list, one entry after the other, so the u16 row `lists[p]` is materialised lazily:
-// bucket_kernel wrote its first buckets in exact order, nsb[p] = entries in exact order so far, and whoever is about to
-// read a position behind that orders the next bucket first (one thread per list -- lists are only ever touched by the
-// thread that owns their frame).  nsb[p] < 0: the row is a fully sorted list (LSD kernel).  ent == null: all rows are.
-struct BucketLists {
-    const uint32_t *ent;        // [P,B]
-    int32_t *nsb;               // [P]
-};
-
-// entries of list p known to be in exact order in its u16 row (n = the list's length)
-__device__ __forceinline__ int bucket_sorted_len(const BucketLists &bl, int p, int n)
-{
-    if (!bl.ent) return n;
-    const int st = bl.nsb[p];
-    return st < 0 ? n : st;
-}
-
-// order the next bucket of list p (n entries) into its u16 row l; kk = the list's sortable keys (larger = earlier).
-// Returns the new sorted length.  Rank by counting: a bucket is at most 32 entries, one cache line.
-__device__ __noinline__ int bucket_extend(const BucketLists &bl, int p, int B, uint16_t *l, const uint32_t *kk, int n)
-{
-    const int s = bl.nsb[p];
-    const uint32_t *e = bl.ent + (int64_t)p * B;
-    int t = s + 1;
-    while (t < n && !(e[t] & kBkFlag)) ++t;              // the bucket is [s, t)
-    for (int i = s; i < t; ++i) {
-        const uint32_t ei = e[i];
-        const int xi = bucket_entry_index(ei);
-        int rank = 0;
-        for (int j = s; j < t; ++j) {
-            const uint32_t ej = e[j];
-            bool before = (ej >> 1) < (ei >> 1);          // (the flag bit does not take part)
-            if (bucket_entries_tied(ej, ei)) {            // equal ord, another entry: the full keys decide (ties: higher index first)
-                const int xj = bucket_entry_index(ej);
-                const uint32_t ki = kk[xi], kj = kk[xj];
-                before = kj > ki || (kj == ki && xj > xi);
-            }
-            rank += before ? 1 : 0;
-        }
-        l[s + rank] = (uint16_t)xi;
-    }
-    bl.nsb[p] = t;
-    return t;
-}
-
-// make position x of list p readable (x < n)
-__device__ __forceinline__ void bucket_need(const BucketLists &bl, int p, int B, uint16_t *l, const uint32_t *kk, int n, int &upto, int x)
-{
-    while (x >= upto && upto < n) upto = bucket_extend(bl, p, B, l, kk, n);
-}
-
 // Lazy lists (regular frames: finite boxes with positive areas, so no union can be zero and skipping
 // the evaluation of a pair can not hide a ZeroDivisionError).  The only thing ever read from a
 // (frame, class) list is its best live entry, at most once per track -- so track_det_nms
@@ -121,7 +68,6 @@ struct LazyLists {
     int32_t *t1;                    // [F*C] 0: no track crossed the list yet, else first track + 1
     int32_t *head, *nkp, *pos;      // [F*C]
     float t32;
-    BucketLists bk;                 // how far each u16 row is materialised (ent == null: everywhere)
 };
 
 __device__ __forceinline__ bool lazy_dead(const LazyLists &lz, int f, int e, int F, int B, int c, int max_tracks, int nt)
@@ -183,7 +129,6 @@ __device__ __forceinline__ void track_pick_body(const int c, const uint32_t *__r
         const int n = cnt[p];
         uint16_t *l = lists + (int64_t)p * B;
         const uint32_t *kk = keys + (int64_t)p * B;
-        int upto = bucket_sorted_len(lz.bk, p, n);     // l[0 .. upto) is in exact order; bucket_need extends it
         int t1 = 0;
         if (lz.group_flags && (lz.group_flags[f] & kFlagRegular)) {
             t1 = lz.t1[p];
@@ -198,7 +143,6 @@ __device__ __forceinline__ void track_pick_body(const int c, const uint32_t *__r
             int q = 0;
             for (;;) {
                 if (q >= n) break;
-                bucket_need(lz.bk, p, B, l, kk, n, upto, q);
                 if (!at_or_before(kk[l[q]], f * B + l[q], s.last_key, s.last_flat)) break;
                 ++q;
             }
@@ -207,7 +151,6 @@ __device__ __forceinline__ void track_pick_body(const int c, const uint32_t *__r
             const uint32_t k0 = kk[l[q]];
             int best = l[q];
             for (int r = q + 1; r < n; ++r) {
-                bucket_need(lz.bk, p, B, l, kk, n, upto, r);
                 if (kk[l[r]] != k0) break;
                 if (!at_or_before(k0, f * B + l[r], s.last_key, s.last_flat)) best = l[r];
             }
@@ -224,7 +167,6 @@ __device__ __forceinline__ void track_pick_body(const int c, const uint32_t *__r
             if (h >= np) {                      // extend the kept prefix by one entry
                 bool got = false;
                 while (ps < n && !got) {
-                    bucket_need(lz.bk, p, B, l, kk, n, upto, ps);
                     got = lazy_examine(lz, l, f, B, t1b, t1area, np, ps);
                 }
                 if (!got) break;                // list exhausted
@@ -243,7 +185,6 @@ __device__ __forceinline__ void track_pick_body(const int c, const uint32_t *__r
             for (;;) {
                 if (r >= np) {
                     if (ps >= n) break;
-                    bucket_need(lz.bk, p, B, l, kk, n, upto, ps);
                     if (kk[l[ps]] != k0) break;
                     lazy_examine(lz, l, f, B, t1b, t1area, np, ps);
                     continue;
@@ -317,15 +258,6 @@ __device__ __forceinline__ void track_pick_body(const int c, const uint32_t *__r
     if (tid == 0) st[c].resolved = 1;
 }
 
-__global__ __launch_bounds__(256) void track_pick_kernel(const uint32_t *__restrict__ keys, uint16_t *lists,
-                                                         const int32_t *__restrict__ cnt, int F, int B, int C,
-                                                         const float *__restrict__ scores, double thres, int max_tracks,
-                                                         TrackState *__restrict__ st, float *__restrict__ anchors,
-                                                         const LazyLists lz, const ResolveArgs rv)
-{
-    track_pick_body(blockIdx.x, keys, lists, cnt, F, B, C, scores, thres, max_tracks, st, anchors, lz, rv);
-}
-
 // IoU of the current track box (as the "i" box) with a proposal (as "j"), utils/nms.pyx arithmetic
 __device__ __forceinline__ float link_iou(float4 cur, float carea, float4 b)
 {
@@ -352,7 +284,7 @@ __device__ __forceinline__ float4 trunc4(float4 b)   // int(cor) of utils/protoc
 // buffered LDS slot, every thread finishes the reduction redundantly.  The step is a serial chain
 // executed by every wave, so a SMALL block wins: with 1024 threads the replicated serial part cost
 // ~7 us per frame (measured), the x-window leaves only ~2 000 candidates per frame anyway.
-// LT = threads per chain (template parameter; 256 by default, VDET_LINK_THREADS selects 64 / 128 for A-B runs)
+// LT = threads per chain (template parameter)
 
 // One batch of the x-window scan of track_link_kernel: WB boxes per thread starting at rank rb0.
 // All loads are issued before the first use (a load inside the ballot-branching loop body is waited
@@ -422,183 +354,6 @@ __device__ __forceinline__ void link_scan16(const uint4 *__restrict__ xb2, const
     }
 }
 
-template <int LT>
-__global__ __launch_bounds__(LT) void track_link_kernel(const float4 *__restrict__ boxes, int F, int B, int max_tracks,
-                                                          float link_t32, int reach, const TrackState *__restrict__ st,
-                                                          float *__restrict__ tracks,
-                                                          const uint32_t *__restrict__ group_flags,
-                                                          const FrameIndex ix, double link_thres)
-{
-    __shared__ float sv[2][LT / 64];
-    __shared__ int si[2][LT / 64];
-    __shared__ float4 sb[2][LT / 64];          // the winning box travels with its score: no dependent global load
-    __shared__ uint32_t scum[2][260];     // next frame's bucket table + (xmin, scale, wmax), prefetched
-    static_assert(LT % 64 == 0 && LT >= 64 && LT <= 1024, "whole waves");
-    constexpr int NPF = (260 + LT - 1) / LT;   // table entries prefetched per thread
-
-    const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int dir = blockIdx.y == 0 ? 1 : -1;
-    const TrackState s = st[c];
-    if (!s.active) return;
-    float *trk = tracks + ((int64_t)c * max_tracks + s.ntracks) * F * 5;
-    const float qnan = __uint_as_float(0x7FC00000u);
-    // my half of the track starts empty
-    if (dir > 0) { for (int i = s.anchor_frame * 5 + tid; i < F * 5; i += LT) trk[i] = qnan; }
-    else { for (int i = tid; i < s.anchor_frame * 5; i += LT) trk[i] = qnan; }
-    __syncthreads();
-    const float4 anchor = trunc4(boxes[(int64_t)s.anchor_frame * B + s.anchor_box]);
-    if (dir > 0 && tid == 0) {
-        float *r = trk + (int64_t)s.anchor_frame * 5;
-        r[0] = anchor.x; r[1] = anchor.y; r[2] = anchor.z; r[3] = anchor.w; r[4] = 1.0f;
-    }
-    float4 cur = anchor;
-    if (ix.xbox) {   // bucket table of the first frame to visit (parity 1 = step 1)
-        const int f1 = min(max(s.anchor_frame + dir, 0), F - 1);
-        for (int i = tid; i < 260; i += LT)
-            scum[1][i] = i < 257 ? ix.cum[(int64_t)f1 * 257 + i] : __float_as_uint(ix.info[f1 * 4 + (i - 257)]);
-        __syncthreads();
-    }
-    // software pipeline: the NEXT frame's boxes do not depend on this frame's result, so they are
-    // loaded (up to LB per thread) before this frame's reduction / barrier
-    constexpr int LB = 8;                                // fallback path (no index): first 8*LT boxes from registers
-    const bool use_ix = ix.xbox != nullptr;              // kernel-uniform
-    float4 nb[LB];
-#pragma unroll
-    for (int i = 0; i < LB; ++i) nb[i] = anchor;
-    if (!use_ix) {
-        const int f1 = s.anchor_frame + dir;
-        const float4 *fb1 = boxes + (int64_t)min(max(f1, 0), F - 1) * B;
-#pragma unroll
-        for (int i = 0; i < LB; ++i) nb[i] = fb1[min(tid + i * LT, B - 1)];
-    }
-    const float omt = (float)(1.0 - link_thres) * 1.002f + 1.0e-6f;     // (1 - link_thres), rounded up
-    const float inv_t = (float)(1.002 / fmax(link_thres, 1.0e-6));         // 1 / link_thres, rounded up
-#define LINK_DPP_STEP(CTRL, ROWMASK) { \
-        const float v2 = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(-1.0f), __float_as_int(bv), CTRL, ROWMASK, 0xf, false)); \
-        const int i2 = __builtin_amdgcn_update_dpp(-1, bi, CTRL, ROWMASK, 0xf, false); \
-        if (i2 >= 0 && (bi < 0 || v2 > bv || (v2 == bv && i2 < bi))) { bv = v2; bi = i2; } }
-#define LSCAN(W) link_scan<W, LT>(xb, xo, rb0, r1, B, tid, cur, carea, link_t32, t32e, bv, bi, bb);
-    for (int step = 1; step <= reach; ++step) {
-        const int f = s.anchor_frame + dir * step;
-        if (f < 0 || f >= F) break;
-        const int par = step & 1;
-        const float carea = box_area(cur);
-        const float4 *fb = boxes + (int64_t)f * B;
-        float bv = -1.0f;
-        int bi = -1;
-        float4 bb = cur;
-        // Regular frame (finite boxes, positive areas) and a regular current box: only candidates
-        // with IoU >= link_t32 can be linked, and that test is exact WITHOUT a divide
-        // (pred_regular); the IEEE quotient is computed only in the rare wave iteration where some
-        // lane passes.  Same result as the plain argmax below.
-        const bool fast = group_flags && (group_flags[f] & kFlagRegular) && link_t32 > 1e-30f &&
-                          carea > 0.0f && carea < __uint_as_float(0x7F800000u);
-        const float t32e = link_t32 * 4.76837158203125e-7f;
-        // prefetch the bucket table of the next frame (whatever path this step takes): the loads are
-        // issued here, together with the box loads below, and stored to the other parity slot only
-        // after the boxes were processed (the slot is read after this step's barrier; it was last
-        // read one full step ago)
-        uint32_t pf[NPF];
-#pragma unroll
-        for (int j = 0; j < NPF; ++j) pf[j] = 0u;
-        if (use_ix) {
-            const int f2 = min(max(f + dir, 0), F - 1);
-#pragma unroll
-            for (int j = 0; j < NPF; ++j) {
-                const int i = tid + j * LT;          // entries 0..256: cum, 257..259: xmin / scale / wmax
-                pf[j] = i < 257 ? ix.cum[(int64_t)f2 * 257 + i] : __float_as_uint(ix.info[f2 * 4 + min(i - 257, 2)]);
-            }
-        }
-        if (fast && use_ix) {
-            // indexed frame: only the x-window that can reach IoU >= link_thres is read
-            int r0, r1;
-            {   // window from the LDS copy of this frame's table (prefetched during the previous step)
-                const float xmin = __uint_as_float(scum[par][257]), scale = __uint_as_float(scum[par][258]);
-                const float wmax = __uint_as_float(scum[par][259]);
-                const float wc = (cur.z - cur.x) + 1.0f;
-                // (f32 with slack instead of f64: the window only has to be a superset)
-                const float lo = cur.x - omt * fminf(wmax, wc * inv_t) - 2.0f;   // partners to the left are at most wc / t wide (xwindow)
-                const float hi = cur.x + omt * wc + 2.0f;
-                r0 = (int)scum[par][xbucket(fmaxf(lo, -3.0e38f), xmin, scale)];
-                r1 = (int)scum[par][xbucket(fminf(hi, 3.0e38f), xmin, scale) + 1];
-            }
-            const float4 *xb = ix.xbox + (int64_t)f * B;
-            const uint16_t *xo = ix.xord + (int64_t)f * B;
-            // batches of WB boxes per thread (link_scan): a typical window (~2 400 boxes) goes in ONE
-            // batch of 16 per thread = one memory round trip per frame step; registers are free here
-            // (400 blocks on 256 CUs: occupancy is irrelevant)
-            int rb0 = r0;
-            while (r1 - rb0 > 16 * LT) { LSCAN(16) rb0 += 16 * LT; }
-            const int nb = (r1 - rb0 + LT - 1) / LT;          // loads per thread still needed (wave-uniform)
-            if (nb > 12) { LSCAN(16) } else if (nb > 8) { LSCAN(12) } else if (nb > 4) { LSCAN(8) } else if (nb > 0) { LSCAN(4) }
-        } else if (use_ix) {
-            // irregular frame while an index exists: plain scan, no prefetch
-            for (int b = tid; b < B; b += LT) {
-                const float4 x = fb[b];
-                const float v = link_iou(cur, carea, x);
-                if (v > bv) { bv = v; bi = b; bb = x; }
-            }
-        } else
-#pragma unroll
-        for (int i = 0; i < LB; ++i) {
-            const int b = tid + i * LT;
-            if (fast) {
-                bool border;
-                const bool pass = pred_regular(cur, carea, nb[i], box_area(nb[i]), link_t32, t32e, border);
-                if (__ballot((pass || border) && b < B)) {
-                    const float v = link_iou(cur, carea, nb[i]);
-                    if (b < B && v >= link_t32 && v > bv) { bv = v; bi = b; bb = nb[i]; }
-                }
-            } else {
-                const float v = link_iou(cur, carea, nb[i]);
-                if (b < B && v > bv) { bv = v; bi = b; bb = nb[i]; }     // NaN never wins; lowest index on ties
-            }
-        }
-        if (!use_ix)
-            for (int b = tid + LB * LT; b < B; b += LT) {
-                const float4 x = fb[b];
-                const float v = link_iou(cur, carea, x);
-                if (v > bv) { bv = v; bi = b; bb = x; }
-            }
-        if (use_ix) {
-#pragma unroll
-            for (int j = 0; j < NPF; ++j)
-                if (tid + j * LT < 260) scum[par ^ 1][tid + j * LT] = pf[j];
-        }
-        const int my_bi = bi;
-        if (!use_ix) {   // prefetch frame f + dir
-            const int f2 = f + dir;
-            const float4 *fb2 = boxes + (int64_t)min(max(f2, 0), F - 1) * B;
-#pragma unroll
-            for (int i = 0; i < LB; ++i) nb[i] = fb2[min(tid + i * LT, B - 1)];
-        }
-        // wave argmax on the DPP network (row_shr 1/2/4/8, row_bcast 15/31: the result lands in lane 63);
-        // six ds_bpermute rounds cost ~1 800 cycles of this serial chain, measured
-        LINK_DPP_STEP(0x111, 0xf) LINK_DPP_STEP(0x112, 0xf) LINK_DPP_STEP(0x114, 0xf) LINK_DPP_STEP(0x118, 0xf)
-        LINK_DPP_STEP(0x142, 0xa) LINK_DPP_STEP(0x143, 0xc)
-        bv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bv), 63));
-        bi = __builtin_amdgcn_readlane(bi, 63);
-        if (lane == 0) { sv[par][w] = bv; si[par][w] = bi; }
-        if (bi >= 0 && my_bi == bi) sb[par][w] = bb;     // exactly one lane of the wave owns the winner
-        __syncthreads();
-        float best = sv[par][0];
-        int bidx = si[par][0];
-        int bw = 0;
-#pragma unroll
-        for (int k = 1; k < LT / 64; ++k) {
-            const float v2 = sv[par][k];
-            const int i2 = si[par][k];
-            if (i2 >= 0 && (bidx < 0 || v2 > best || (v2 == best && i2 < bidx))) { best = v2; bidx = i2; bw = k; }
-        }
-        if (bidx < 0 || !(best >= link_t32)) break;
-        cur = trunc4(sb[par][bw]);
-        if (tid == 0) {
-            float *r = trk + (int64_t)f * 5;
-            r[0] = cur.x; r[1] = cur.y; r[2] = cur.z; r[3] = cur.w; r[4] = best;
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // The same tracker with a LINK MEMO.  One link step is a pure function of the node it starts from:
 //     next(f, j, dir) = argmax_k IoU(trunc(box[f][j]), box[f + dir][k])   (>= link_thres, first index on ties)
@@ -630,6 +385,12 @@ __device__ __forceinline__ unsigned long long memo_load(const unsigned long long
 //         the warm-up, when every step of these chains is known -- the tracking loop then COPIES a predicted anchor's
 //         tubelet (the tail of track_pick_kernel) instead of walking its ~300 dependent steps again, track after track
 // chain = the class (MODE 0) or the warm-chain slot (MODE 1 / 2); dir = +1 / -1
+// (helpers of the window scans below)
+#define LINK_DPP_STEP(CTRL, ROWMASK) { \
+        const float v2 = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(-1.0f), __float_as_int(bv), CTRL, ROWMASK, 0xf, false)); \
+        const int i2 = __builtin_amdgcn_update_dpp(-1, bi, CTRL, ROWMASK, 0xf, false); \
+        if (i2 >= 0 && (bi < 0 || v2 > bv || (v2 == bv && i2 < bi))) { bv = v2; bi = i2; } }
+#define LSCAN(W) link_scan<W, LT>(xb, xo, rb0, r1, B, tid, cur, carea, link_t32, t32e, bv, bi, bb);
 template <int LT, int MODE, int MAXB>
 __device__ __forceinline__ void track_link_memo_body(const int chain, const int dir, const float4 *__restrict__ boxes, int F, int B, int max_tracks,
                                                      float link_t32, int reach, const TrackState *__restrict__ st,
@@ -937,92 +698,7 @@ __global__ __launch_bounds__(1024) void warm_order_kernel(const int32_t *__restr
 // inside the tracking loop (on coherent videos the warm-up predicted one chain per class and the loop scanned the rest).
 // The values are the ones a scan would publish, so the memo-driven kernels are unchanged.
 // ------------------------------------------------------------------------------------------------
-// kFillLanes lanes share a node: lane `sub` takes every kFillLanes-th candidate of the window, a quad reduction (DPP) picks the
-// winner -- trip counts of the lanes of a wave are more even than with one whole window each, and a quad reads 64 contiguous
-// bytes of the x-sorted index per turn.
-constexpr int kFillLanes = 4;
-
-__device__ __forceinline__ void link_fill_node(const int f, const int j, const int dir, const int sub, const float4 *__restrict__ boxes, int F, int B,
-                                               float link_t32, const uint32_t *__restrict__ group_flags, const FrameIndex &ix,
-                                               double link_thres, unsigned long long *memo)
-{
-    const int f2 = f + dir;
-    if (f2 < 0 || f2 >= F) return;                    // (a chain stops at the video's border before it asks)
-    const float4 cur = trunc4(boxes[(int64_t)f * B + j]);
-    const float carea = box_area(cur);
-    const uint32_t fflags = group_flags ? group_flags[f2] : 0u;
-    const bool fast = ix.xbox && (fflags & kFlagRegular) && link_t32 > 1e-30f && carea > 0.0f && carea < __uint_as_float(0x7F800000u);
-    float bv = -1.0f;
-    int bi = -1;
-    if (fast) {
-        const float omt = (float)(1.0 - link_thres) * 1.002f + 1.0e-6f;
-        const float inv_t = (float)(1.002 / fmax(link_thres, 1.0e-6));
-        const float t32e = link_t32 * 4.76837158203125e-7f;
-        const float xmin = ix.info[f2 * 4], scale = ix.info[f2 * 4 + 1], wmax = ix.info[f2 * 4 + 2];
-        const float wc = (cur.z - cur.x) + 1.0f;
-        const float lo = cur.x - omt * fminf(wmax, wc * inv_t) - 2.0f;
-        const float hi = cur.x + omt * wc + 2.0f;
-        const uint32_t *cum = ix.cum + (int64_t)f2 * 257;
-        const int r0 = (int)cum[xbucket(fmaxf(lo, -3.0e38f), xmin, scale)];
-        const int r1 = (int)cum[xbucket(fminf(hi, 3.0e38f), xmin, scale) + 1];
-        const float4 *xb = ix.xbox + (int64_t)f2 * B;
-        const uint16_t *xo = ix.xord + (int64_t)f2 * B;
-        // four candidates per turn, every load issued before the first use (a load that is waited for right away costs a full
-        // memory latency per candidate: measured, the kernel took the same 4.35 ms with one lane per node and with four)
-        for (int r = r0 + sub; r < r1; r += 4 * kFillLanes) {
-            float4 x[4];
-            uint16_t xi[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) x[t] = xb[min(r + t * kFillLanes, B - 1)];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) xi[t] = xo[min(r + t * kFillLanes, B - 1)];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                bool border;
-                const bool pass = pred_regular(cur, carea, x[t], box_area(x[t]), link_t32, t32e, border);
-                if ((pass || border) && r + t * kFillLanes < r1) {
-                    const float v = link_iou(cur, carea, x[t]);
-                    const int b = (int)xi[t];
-                    if (v >= link_t32 && (v > bv || (v == bv && b < bi))) { bv = v; bi = b; }
-                }
-            }
-        }
-    } else {
-        // irregular frame / no index / degenerate current box: the plain arg-max (NaN never wins, lowest index on ties)
-        const float4 *fb = boxes + (int64_t)f2 * B;
-        for (int b = sub; b < B; b += kFillLanes) {
-            const float v = link_iou(cur, carea, fb[b]);
-            if (v > bv) { bv = v; bi = b; }
-        }
-    }
-    // the quad's winner: highest IoU, lowest index on ties (a lane without a candidate holds bi = -1, bv = -1)
-#pragma unroll
-    for (int st = 0; st < 2; ++st) {
-        const float ov = __int_as_float(st == 0 ? __builtin_amdgcn_mov_dpp(__float_as_int(bv), 0xB1, 0xf, 0xf, true)
-                                                : __builtin_amdgcn_mov_dpp(__float_as_int(bv), 0x4E, 0xf, 0xf, true));
-        const int oi = st == 0 ? __builtin_amdgcn_mov_dpp(bi, 0xB1, 0xf, 0xf, true) : __builtin_amdgcn_mov_dpp(bi, 0x4E, 0xf, 0xf, true);
-        if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
-    }
-    if (sub != 0) return;
-    const bool linked = bi >= 0 && bv >= link_t32;
-    unsigned long long *mm = memo + (int64_t)(dir > 0 ? 0 : 1) * F * B;
-    __hip_atomic_store(&mm[(int64_t)f * B + j],
-                       kMemoValid | ((unsigned long long)(linked ? bi + 1 : 0) << 32) | (linked ? __float_as_uint(bv) : 0u),
-                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// grid (ceil(F * B * kFillLanes / 256), 2)
-__global__ __launch_bounds__(256) void link_fill_kernel(const float4 *__restrict__ boxes, int F, int B, float link_t32,
-                                                        const uint32_t *__restrict__ group_flags, const FrameIndex ix, double link_thres,
-                                                        unsigned long long *memo)
-{
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t n = t / kFillLanes;
-    if (n >= (int64_t)F * B) return;
-    const int f = (int)(n / B);
-    link_fill_node(f, (int)(n - (int64_t)f * B), blockIdx.y == 0 ? 1 : -1, (int)(t & (kFillLanes - 1)), boxes, F, B, link_t32, group_flags, ix,
-                   link_thres, memo);
-}
+constexpr int kLinkFillMax = 1024;      // frames of up to this many proposals get their whole link table up front
 
 // The same table, one BLOCK per (frame f, direction) with frame f + dir's x-sorted index -- boxes, areas, box numbers, bucket
 // table -- staged in LDS once (<= 24 KB at B = 1 024): a node's window scan then reads LDS instead of gathering 16-byte
@@ -1133,7 +809,7 @@ constexpr int kWarmMax = 32;
 __device__ __forceinline__ void track_warm_anchors_body(const int c, const uint32_t *__restrict__ keys, uint16_t *lists,
                                                         const int32_t *__restrict__ cnt, int F, int B, int C,
                                                         const float *__restrict__ scores, double thres, int m,
-                                                        int32_t *__restrict__ warm, const BucketLists &bkl, const WarmExtra &wx)
+                                                        int32_t *__restrict__ warm, const WarmExtra &wx)
 {
     __shared__ uint32_t sk[256];
     __shared__ int sf[256];
@@ -1151,10 +827,6 @@ __device__ __forceinline__ void track_warm_anchors_body(const int c, const uint3
         for (int f = tid; f < F; f += 256) {
             const int p = f * C + c;
             const int n = min(cnt[p], 2);
-            if (k == 0 && bkl.ent && n > 0) {    // bucketed list: its first two entries in exact order (normally they already are)
-                int upto = bucket_sorted_len(bkl, p, cnt[p]);
-                bucket_need(bkl, p, B, lists + (int64_t)p * B, keys + (int64_t)p * B, cnt[p], upto, n - 1);
-            }
             for (int q = 0; q < n; ++q) {
                 const int e = lists[(int64_t)p * B + q];
                 const uint32_t kk = keys[(int64_t)p * B + e];
@@ -1223,9 +895,7 @@ __device__ __forceinline__ void track_warm_anchors_body(const int c, const uint3
             const int p = f * C + c;
             const int n = min(cnt[p], 64);                       // (prediction only: the head of the list is plenty)
             uint16_t *l = lists + (int64_t)p * B;
-            int upto = bucket_sorted_len(bkl, p, cnt[p]);
             while (pos[h] < n) {
-                bucket_need(bkl, p, B, l, keys + (int64_t)p * B, cnt[p], upto, pos[h]);
                 const int e = l[pos[h]];
                 const float4 bx = wx.boxes[(int64_t)f * B + e];
                 const float ar = box_area(bx);
@@ -1273,9 +943,9 @@ __device__ __forceinline__ void track_warm_anchors_body(const int c, const uint3
 __global__ __launch_bounds__(256) void track_warm_anchors_kernel(const uint32_t *__restrict__ keys, uint16_t *lists,
                                                                  const int32_t *__restrict__ cnt, int F, int B, int C,
                                                                  const float *__restrict__ scores, double thres, int m,
-                                                                 int32_t *__restrict__ warm, const BucketLists bk, const WarmExtra wx)
+                                                                 int32_t *__restrict__ warm, const WarmExtra wx)
 {
-    track_warm_anchors_body(blockIdx.x, keys, lists, cnt, F, B, C, scores, thres, m, warm, bk, wx);
+    track_warm_anchors_body(blockIdx.x, keys, lists, cnt, F, B, C, scores, thres, m, warm, wx);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1455,28 +1125,7 @@ __device__ __forceinline__ void track_suppress_list(const SuppressParams &prm, l
 
 // grid-stride over the lists (4 waves per block, one list each): a video whose frames are all regular
 // has nothing to do here when the pick maintains the lists lazily -- every block leaves after one load
-__global__ __launch_bounds__(256) void track_suppress_kernel(const SuppressParams prm)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    if (prm.lazy && prm.group_flags && *prm.n_irregular == 0) return;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    lds_mask_t mask = lds_mask_ptr(smem, w * prm.mask_words);
-    const int P = prm.F * prm.C;
-    for (int p = blockIdx.x * 4 + w; p < P; p += gridDim.x * 4) {
-        track_suppress_list(prm, mask, lane, p);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // the mask is reused by the next list
-    }
-}
-
 // close the iteration: count the finished track
-__global__ void track_commit_kernel(TrackState *__restrict__ st, int C, int32_t *__restrict__ ntracks_out)
-{
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    if (st[c].active) st[c].ntracks += 1;
-    ntracks_out[c] = st[c].ntracks;
-}
-
 __global__ void track_init_kernel(TrackState *__restrict__ st, int C)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1493,7 +1142,7 @@ __global__ void track_init_kernel(TrackState *__restrict__ st, int C)
 // pick -> (copy | link forward, link backward) -> suppress (irregular frames only) -> commit for all max_tracks
 // iterations without returning to the host queue: 1 launch instead of 4 per track, and no block waits for the
 // slowest class of its iteration.  Same device functions as the per-iteration kernels, in the same order per class:
-// bit-identical results (VDET_TRACK_LOOP=0 selects the per-iteration launches; tested against each other).
+// bit-identical results.
 // block = 256; dynamic LDS = 4 dead masks of sp.mask_words words (track_suppress_list).
 // ------------------------------------------------------------------------------------------------
 struct LoopArgs {
@@ -1784,11 +1433,10 @@ __global__ __launch_bounds__(256) void rescore_adj_kernel(const float *__restric
 
 // one thread per (class, track): completion over the track's boxes (its non-NaN frames, in order),
 // then the centred temporal max-pool of window w (w == 1: none) into out2.
-__global__ void rescore_series_kernel(double *__restrict__ sc, double *__restrict__ out2,
-                                      const int32_t *__restrict__ ntracks, int F, int C, int T, int window,
-                                      int *__restrict__ err)
+__device__ __forceinline__ void rescore_series_serial_body(const int ct, double *__restrict__ sc, double *__restrict__ out2,
+                                                           const int32_t *__restrict__ ntracks, int F, int C, int T, int window,
+                                                           int *__restrict__ err)
 {
-    const int ct = blockIdx.x * blockDim.x + threadIdx.x;
     if (ct >= C * T) return;
     const int c = ct / T, t = ct - c * T;
     double *s = sc + (int64_t)ct * F;
@@ -1828,6 +1476,14 @@ __global__ void rescore_series_kernel(double *__restrict__ sc, double *__restric
         }
         o[a + i] = m;
     }
+}
+
+// (videos of more than kSeriesWaveMaxF frames: the wave form's LDS stage does not hold the series)
+__global__ void rescore_series_kernel(double *__restrict__ sc, double *__restrict__ out2,
+                                      const int32_t *__restrict__ ntracks, int F, int C, int T, int window,
+                                      int *__restrict__ err)
+{
+    rescore_series_serial_body(blockIdx.x * blockDim.x + threadIdx.x, sc, out2, ntracks, F, C, T, window, err);
 }
 
 // The same, one WAVE per series (F <= kSeriesWaveMaxF): the series sits in LDS, a lane owns every 64th frame.  A missing

@@ -17,8 +17,8 @@
 #include "nms_kernels.hpp"
 #include "binsort_kernels.hpp"
 #include "small_kernels.hpp"
-#include "bucket_kernels.hpp"
 #include "detnms_kernels.hpp"
+#include "fused_kernels.hpp"
 #include "temporal_kernels.hpp"
 #include "tubelet_kernels.hpp"
 #include "track_kernels.hpp"
@@ -123,9 +123,15 @@ struct vdet_ctx {
     bool index_valid = false; const void *index_boxes = nullptr; int64_t index_F = 0, index_B = 0;
     bool all_regular = false;     // last graph build: every frame regular
     bool wave_transpose = false;  // wave_transpose64 verified on this device (vdet_create); VDET_WAVE_TRANSPOSE=0 disables
-    bool debug_sync = false;      // VDET_DEBUG_SYNC=1: synchronise + report after every tracking kernel
-    bool no_lazy = false;         // VDET_NO_LAZY=1: eager track_det_nms of every crossed list (tests / A-B)
-    bool no_index = false;        // VDET_NO_INDEX=1: disable the x-sorted proposal index (tests / A-B)
+    // Diagnostic switches (read once at vdet_create; DESIGN.md "Knobs").  Each forces a FALLBACK path the library takes anyway
+    // on some inputs or devices, so that the tests can run it on every input: no tuning variants live here.
+    bool no_lazy = false;         // VDET_NO_LAZY=1: eager track_det_nms of every crossed list (the irregular-frame path)
+    bool no_index = false;        // VDET_NO_INDEX=1: no x-sorted proposal index (the path of frames too large for it)
+    bool force_general = false;   // VDET_FORCE_GENERAL=1: the general predicate kernel K1 on every frame (the irregular-frame path)
+    bool atomic_rank = false;     // LDS returning atomics serve same-address lanes in lane order (probed; VDET_ATOMIC_RANK=0: ballot match)
+    bool small_lists = true;      // VDET_SMALL_LISTS=0: frames of <= 384 boxes through the large-list sort and walk too (small_kernels.hpp)
+    bool no_fused = false;        // VDET_NO_FUSED=1: the host-buffer calls of <= 1 024 rows through the general kernel chain too (the path of larger inputs)
+    bool binsort = true;          // VDET_BINSORT=0: the LSD radix kernel (the fallback of tied / thresholded columns) for every column
     const std::vector<GroupDesc> *host_groups = nullptr;   // group table of the call in flight (mode 2)
     bool sym_built = false;       // the last graph build ran K0 + frame index + K1s (regular-frame fast path)
     // volume geometry whose group / tile / pair tables are resident in c->groups / c->tiles / c->pairs
@@ -138,80 +144,25 @@ struct vdet_ctx {
     long long n_host_syncs = 0;   // hipStreamSynchronize calls made by this context so far
     bool async_enabled = false;
     unsigned long long pool_hint = 0;   // adjacency entries used by the largest graph built so far
-    bool atomic_rank = false;     // LDS returning atomics serve same-address lanes in lane order (probed)
-    bool no_transpose = false;    // VDET_NO_TRANSPOSE=1 (tests / A-B)
-    bool force_general = false;   // VDET_FORCE_GENERAL=1: disable the symmetric fast kernel (tests)
     bool topk_attr_set = false;
-    int link_threads = 256;       // VDET_LINK_THREADS=64|128|256: threads per link chain (A-B knob)
-    bool link_fill_lds = true;    // VDET_LINK_FILL_LDS=0: the link table by link_fill_kernel (quads gathering from global memory) instead of
-                                  // link_fill_frame_kernel (one block per frame and direction, the neighbour frame's index in LDS)
-    bool small_lists = true;      // VDET_SMALL_LISTS=0: frames of <= 384 boxes through the large-list sort and walk too (small_kernels.hpp; A-B knob)
-    int warm_threads = 256;       // VDET_WARM_THREADS=64|128|256: threads per chain of the memo warm-up (more chains resident at once)
-    bool series_serial = false;   // VDET_SERIES_SERIAL=1: one thread per tubelet series (A-B knob / tests)
-    bool link_materialize = true; // VDET_LINK_MATERIALIZE=0: the tracking loop walks every tubelet itself (A-B knob / tests)
-    int walk_packed = 1;          // VDET_WALK_PACKED=0: regular frames walk one survivor at a time; 1 (default): eight candidates per pass;
-                                  // 2: sixteen (walk_list_packed2: measured 3.09 vs 2.96 ms -- the walk is bound by L1 / LDS throughput, not by
-                                  // its chain of round trips) (A-B knob / tests)
     float gt32 = 0.f;             // threshold of the last graph build (the packed walk's in-group test)
     bool wmeta_built = false;     // ... which also wrote the packed walk's records (WalkMeta) of the regular frames
-    bool walk_careful = false;    // VDET_WALK_CAREFUL=1: per-survivor bookkeeping also on regular frames (A-B knob / tests)
-    bool link_memo = true;        // VDET_LINK_MEMO=0: every link step scans (A-B knob / tests)
-    bool track_loop = true;       // VDET_TRACK_LOOP=0: four launches per track (pick / link / suppress / commit) instead of one persistent
-                                  // block per class for the whole tracking loop (A-B knob / tests)
-    bool binsort = true;          // untied volume columns by the equalised counting sort (binsort_kernels.hpp); VDET_BINSORT=0: the LSD radix
-                                  // kernel.  Bit-identical.  Round 4, once every key of a thread is requested before the first is used:
-                                  // 2.31 vs 2.90 ms per c2 video (both were 3.2-3.3 before), so on
     bool last_sort_binned = false;   // the last per-(frame, class) sort went through binsort_kernel (vdet_query 9)
     DevBuf vidtab;                // batched videos: {first frame, frames} per video
-    std::vector<VidDesc> h_vids;
+    std::vector<VidDesc> h_vids, h_vids_stage;   // the resident table (empty: none) / the source of the copy in flight
     DevBuf segtab;                // batched videos: per-frame {first, one past last} frame of its video
     std::vector<int2> h_seg;
     std::vector<int64_t> h_seg_off;   // the offsets h_seg / segtab were built from
     DevBuf sortctl;               // binsort_kernel's work counter + the list of problems it handed to the LSD kernel
-    // round 4: per-(frame, class) lists cut into score-ordered buckets instead of sorted (bucket_kernels.hpp)
-    int bucket_mode = 0;          // VDET_BUCKETS=1: volumes of more than 1024 boxes per frame whose regular frames take the packed walk get
-                                  // their lists cut into score-ordered buckets (bucket_kernels.hpp) instead of sorted; 2: every volume
-                                  // the kernel can take (tests); 0 (default): always the LSD sort.  Bit-identical results; measured at the
-                                  // LSD path's speed one video at a time (bucket kernel 2.14 + walk 3.95 ms vs sort 3.18 + walk 2.94)
-                                  // and 0.5 ms per step SLOWER with 4 videos in flight, so off
-    int bk_dbg = 0, walk_dbg = 0; // VDET_BK_DBG / VDET_WALK_DBG: timing experiments (results invalid)
-    int bucket_head = kBkHead;    // VDET_BUCKET_HEAD: leading buckets of every list put in exact order by bucket_kernel (A-B knob)
-    int bucket_block = 512;       // VDET_BUCKET_BLOCK=1024: 1 024 threads x 10 keys per list at B <= 10 240 (A-B knob)
-    bool lists_bucketed = false;  // the context's lists (c->order / c->ncand) are bucketed: c->ent / c->bst / c->nsb describe them
-    bool last_sort_bucketed = false;   // the last per-(frame, class) sort went through bucket_kernel (vdet_query 10 / 11)
-    const uint32_t *bk_raw = nullptr;  // what the buckets were cut from (keys or float scores), for the consumers' tie fallback
-    int bk_floats = 0;
-    DevBuf ent, nsb;
     DevBuf nover;                 // vdet_det_nms_volume: candidates per list before the topk cut
     DevBuf ordncand;              // vdet_nms_volume_ordered: the caller's counts after check_order_kernel
-    // second stream of the context: the memo warm-up runs on it, next to the NMS walk of the same video
-    hipStream_t aux_stream = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    std::vector<hipEvent_t> ev_pipe;   // graph build: K1s of batch i+1 next to K2 of batch i (two events per batch)
-    bool graph_pipe = false;      // VDET_GRAPH_PIPE=1: K2 of batch i on the second stream next to K1s of batch i+1 (two bit-matrix
-                                  // buffers).  A LATENCY option: one video at a time 13.7 -> 13.3 ms, with VDET_AUX_STREAM=1 13.0; with
-                                  // several videos in flight the step gets 0.15 ms slower (more queues taking turns), hence off
-    bool use_aux = false;         // VDET_AUX_STREAM=1: warm-up next to the walk on a second stream (A-B knob; measured: no gain,
-                                  // 19.2 vs 19.7 ms one video at a time, 17.9 vs 16.9 with 3 in flight -- more streams than hardware queues)
-    bool link_lpt = true;         // VDET_LINK_LPT=0: the warm-up's chains in launch order instead of longest first (A-B knob)
-    bool link_u16 = true;         // VDET_LINK_U16=0: the LINK window scans read the float4 index on every frame (A-B knob)
-    int link_maxb = 8;            // VDET_LINK_MAXB=8|16: boxes per thread and batch in the warm-up's window scans (A-B knob)
-    bool batch_chains = false;    // VDET_BATCH_CHAINS=1: batched small videos with the link table up front still predict + materialise chains (A-B knob)
-    bool link_coherent = true;    // extra warm-anchor slots for coherent videos (track_warm_anchors_body; VDET_LINK_COHERENT=0: none).  The
-                                  // predictor stops at max_tracks distinct objects, so the number of scanned link steps stays what it was
-                                  // (656 k on the coherent config-2 video) but they move from the loop's serial scans into the chip-filling
-                                  // warm-up: that video alone 18.8 -> 15.6 ms, with 4 in flight 14.0 -> 13.8; independent frames unchanged
-                                  // (their raw candidates do not repeat each other: the extra slots stay empty).  Before the stop -- 1.04 M
-                                  // steps scanned -- it was a latency option only (4 in flight 15.4 -> 17.1)
-    int link_fill = 1024;         // VDET_LINK_FILL=b: frames of up to b proposals get their WHOLE link table computed up front (link_fill_kernel:
-                                  // every chain is pointer chasing afterwards, no anchor prediction, no warm-up scans); 0: never (A-B knob / tests)
-    int link_warm = -1;           // VDET_LINK_WARM=m: chains warmed per class (-1: max_tracks + 2; 0: none)
     DevBuf linkmemo, linkstats, linkwarm, linkorder, linkchains, linknodes, tracknode, rtodo;
     // which proposal every row of the last tracking call's tracks is (written by the link kernels; vdet_rescore_tracks
     // then finds a tubelet box's overlapping detections among that proposal's graph neighbours)
     struct NodeKey { const void *tracks = nullptr, *boxes = nullptr; int64_t F = 0, B = 0, C = 0; int T = 0; double nms_thres = 0; } nodekey;
     bool nodes_valid = false;
-    bool rescore_adj = true;      // VDET_RESCORE_ADJ=0: always scan the x-window (A-B knob)
+    // single-launch drop-in calls (vdet_nms_f32 / vdet_track_det_nms_f32 on <= kFusedMax rows): host-mapped staging
+    void *fused_in = nullptr, *fused_out = nullptr;
     size_t dyn_lds_max = 0;
 };
 
@@ -345,10 +296,9 @@ int build_frame_index(vdet_ctx *c, const float4 *d_boxes, int64_t ntot, int64_t 
     HIPCHK(c, c->xord.reserve((size_t)ntot * 2));
     HIPCHK(c, c->xncand.reserve((size_t)G * 4));
     HIPCHK(c, c->xbox.reserve((size_t)ntot * 16));
-    if (c->link_u16) {      // compact copy for frames of integer pixel coordinates (kFlagU16): every group at an even position
-        HIPCHK(c, c->xbox16.reserve((size_t)(ntot + G + 4) * 8));
-        HIPCHK(c, c->xord16.reserve((size_t)(ntot + G + 4) * 2));
-    }
+    // compact copy for frames of integer pixel coordinates (kFlagU16): every group at an even position
+    HIPCHK(c, c->xbox16.reserve((size_t)(ntot + G + 4) * 8));
+    HIPCHK(c, c->xord16.reserve((size_t)(ntot + G + 4) * 2));
     HIPCHK(c, c->xcum.reserve((size_t)G * 257 * 4));
     HIPCHK(c, c->xinfo.reserve((size_t)G * 16));
     StageTimer tm(c, ST_OTHER);
@@ -358,8 +308,7 @@ int build_frame_index(vdet_ctx *c, const float4 *d_boxes, int64_t ntot, int64_t 
     if (rc) return rc;
     hipLaunchKernelGGL(frame_index_kernel, dim3((unsigned)G), dim3(256), 0, c->stream, d_boxes, c->groups.as<GroupDesc>(),
                        c->xord.as<uint16_t>(), c->xbox.as<float4>(), c->xcum.as<uint32_t>(), c->xinfo.as<float>(),
-                       c->gflags.as<uint32_t>(), c->link_u16 ? c->xbox16.as<uint2>() : (uint2 *)nullptr,
-                       c->link_u16 ? c->xord16.as<uint16_t>() : (uint16_t *)nullptr);
+                       c->gflags.as<uint32_t>(), c->xbox16.as<uint2>(), c->xord16.as<uint16_t>());
     HIPCHK(c, hipGetLastError());
     c->index_valid = true; c->index_boxes = d_boxes; c->index_F = G; c->index_B = ntot;
     return VDET_OK;
@@ -368,7 +317,7 @@ int build_frame_index(vdet_ctx *c, const float4 *d_boxes, int64_t ntot, int64_t 
 FrameIndex frame_index_of(vdet_ctx *c)
 {
     return FrameIndex{c->xbox.as<float4>(), c->xord.as<uint16_t>(), c->xcum.as<uint32_t>(), c->xinfo.as<float>(),
-                      c->link_u16 ? c->xbox16.as<uint2>() : nullptr, c->link_u16 ? c->xord16.as<uint16_t>() : nullptr, 0};
+                      c->xbox16.as<uint2>(), c->xord16.as<uint16_t>(), 0};
 }
 
 // The plan of a regular volume (one group of B boxes per frame).  Built on the host once per geometry
@@ -378,6 +327,9 @@ NmsPlan &volume_plan(vdet_ctx *c, int64_t F, int64_t B)
 {
     if (c->vplan_F == F && c->vplan_B == B && c->vplan_budget == c->bits_budget && !c->vplan.groups.empty()) return c->vplan;
     (void)host_sync(c);     // (rare: geometry change) copies from the old tables may be in flight
+    // the resident group / tile / pair tables are about to describe another geometry: whatever the cache holds (graph, sorted
+    // lists, x-index, recorded track nodes) was built -- and is decoded -- with the old tables
+    c->graph_valid = c->lists_valid = c->index_valid = c->nodes_valid = false;
     c->vplan = NmsPlan();
     c->vplan.groups.resize((size_t)F);
     for (int64_t f = 0; f < F; ++f) c->vplan.groups[(size_t)f] = {(int32_t)(f * B), (int32_t)B, 0};
@@ -413,10 +365,7 @@ int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32, doub
     c->nodes_valid = false;      // the adjacency lists the recorded track nodes point into are rewritten
     HIPCHK(c, c->groups.reserve(G * sizeof(GroupDesc)));
     HIPCHK(c, c->tiles.reserve(std::max<size_t>(pl.tiles.size(), 1) * sizeof(TileDesc)));
-    // (two buffers when the batches are pipelined: K2 of batch i reads one while K1s of batch i+1 fills the other)
-    const bool pipe = c->graph_pipe && !c->timing && pl.batch_tiles.size() > 1;
-    const size_t bits_stride = std::max<size_t>(pl.bits_words_max, 1);
-    HIPCHK(c, c->bits.reserve(bits_stride * 8 * (pipe ? 2 : 1)));
+    HIPCHK(c, c->bits.reserve(std::max<size_t>(pl.bits_words_max, 1) * 8));
     HIPCHK(c, c->rowz.reserve((size_t)pl.ntot * 4));
     HIPCHK(c, c->rowmeta.reserve((size_t)pl.ntot * 8));
     HIPCHK(c, c->groupz.reserve(G * 4));
@@ -463,7 +412,7 @@ int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32, doub
         const bool use_sym = t32 > 1e-30f && t32 < INFINITY && !c->force_general &&
                              (size_t)8 * pl.nmax + 24 * 1024 <= c->max_lds;
         c->sym_built = use_sym;
-        c->wmeta_built = use_sym && c->walk_packed;
+        c->wmeta_built = use_sym;
         if (c->wmeta_built) HIPCHK(c, c->wmeta.reserve((size_t)pl.ntot * sizeof(WalkMeta)));
         if (use_sym) {
             {
@@ -485,28 +434,12 @@ int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32, doub
         } else {
             c->index_valid = false;      // gflags / the x-index describe some earlier boxes
         }
-        hipStream_t s_main = c->stream, s_k2 = c->stream;
-        if (pipe) {
-            if (!c->aux_stream) {
-                HIPCHK(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
-                HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-                HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
-            }
-            while (c->ev_pipe.size() < 2 * pl.batch_tiles.size()) {
-                hipEvent_t e;
-                HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-                c->ev_pipe.push_back(e);
-            }
-            s_k2 = c->aux_stream;
-        }
-        int last_k2 = -1;
         for (size_t bi = 0; bi < pl.batch_tiles.size(); ++bi) {
             const auto bt = pl.batch_tiles[bi];
             const auto bp = pl.batch_pairs[bi];
             const int nt = bt.second - bt.first;
             if (nt <= 0) continue;
-            uint64_t *bits_b = c->bits.as<uint64_t>() + (pipe ? (bi & 1) * bits_stride : 0);
-            if (pipe && bi >= 2) HIPCHK(c, hipStreamWaitEvent(s_main, c->ev_pipe[2 * (bi - 2) + 1], 0));   // this buffer's K2 is done
+            uint64_t *bits_b = c->bits.as<uint64_t>();
             if (use_sym && bp.second > bp.first) {
                 StageTimer tm(c, ST_IOU_BITS);
                 if (c->wave_transpose)
@@ -536,15 +469,11 @@ int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32, doub
                                    bits_b, c->rowz.as<uint32_t>(), c->groupz.as<uint32_t>(),
                                    use_sym ? c->gflags.as<uint32_t>() : (const uint32_t *)nullptr);
             }
-            if (pipe) {
-                HIPCHK(c, hipEventRecord(c->ev_pipe[2 * bi], s_main));
-                HIPCHK(c, hipStreamWaitEvent(s_k2, c->ev_pipe[2 * bi], 0));
-            }
             {
                 StageTimer tm(c, ST_ADJ);
                 const bool k2_tile = pl.nmax <= 384;      // small frames: one block per tile
                 hipLaunchKernelGGL(k2_tile ? adj_build_kernel<kRowsPerTile> : adj_build_kernel<kAdjRows>, dim3(k2_tile ? nt : 2 * nt),
-                                   dim3(k2_tile ? kRowsPerTile : kAdjRows), 0, s_k2, d_boxes,
+                                   dim3(k2_tile ? kRowsPerTile : kAdjRows), 0, c->stream, d_boxes,
                                    c->groups.as<GroupDesc>(), c->tiles.as<TileDesc>() + bt.first,
                                    bits_b, c->rowz.as<uint32_t>(), c->rowmeta.as<uint2>(),
                                    c->adj.as<uint16_t>(), &c->d_cnt->pool_used, pool_cap,
@@ -554,12 +483,7 @@ int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32, doub
                                    c->wmeta_built ? c->wmeta.as<WalkMeta>() : (WalkMeta *)nullptr,
                                    use_sym ? c->reachtab.as<float2>() : (const float2 *)nullptr);
             }
-            if (pipe) {
-                HIPCHK(c, hipEventRecord(c->ev_pipe[2 * bi + 1], s_k2));
-                last_k2 = (int)bi;
-            }
         }
-        if (pipe && last_k2 >= 0) HIPCHK(c, hipStreamWaitEvent(s_main, c->ev_pipe[2 * last_k2 + 1], 0));   // (the second stream is in order)
         HIPCHK(c, hipGetLastError());
         if (async) {
             c->all_regular = false;      // not known on the host: the tracking loop asks the device (n_irregular)
@@ -596,8 +520,6 @@ struct SortWalkArgs {
     float thr;
     int topk = 0;
     int32_t *nover_out = nullptr; // candidates of every list before the topk cut
-    bool want_heads = false;      // bucketed lists: also write the exact head of every list (the tracking kernels read it)
-    bool no_buckets = false;      // the caller's kernels only take sorted rows
     int32_t *keep_idx;
     int32_t *keep_cnt;
     int64_t cap;
@@ -630,11 +552,6 @@ int launch_sort_walk(vdet_ctx *c, const SortWalkArgs &a, int nmax, int64_t order
         std::vector<const void *> fns;
         for (const Variant &v : variants) { fns.push_back(v.fn[0]); fns.push_back(v.fn[1]); fns.push_back(v.fn_list[0]); fns.push_back(v.fn_list[1]); }
         fns.push_back(reinterpret_cast<const void *>(walk_kernel));
-        for (const void *fn : {reinterpret_cast<const void *>(bucket_kernel<512, 8, false>), reinterpret_cast<const void *>(bucket_kernel<512, 8, true>),
-                               reinterpret_cast<const void *>(bucket_kernel<512, 20, false>), reinterpret_cast<const void *>(bucket_kernel<512, 20, true>),
-                               reinterpret_cast<const void *>(bucket_kernel<1024, 16, false>), reinterpret_cast<const void *>(bucket_kernel<1024, 16, true>),
-                               reinterpret_cast<const void *>(bucket_kernel<1024, 10, false>), reinterpret_cast<const void *>(bucket_kernel<1024, 10, true>)})
-            fns.push_back(fn);
         for (const void *fn : {reinterpret_cast<const void *>(binsort_kernel<8, false>), reinterpret_cast<const void *>(binsort_kernel<8, true>),
                                reinterpret_cast<const void *>(binsort_kernel<20, false>), reinterpret_cast<const void *>(binsort_kernel<20, true>),
                                reinterpret_cast<const void *>(binsort_kernel<36, false>), reinterpret_cast<const void *>(binsort_kernel<36, true>)})
@@ -655,7 +572,7 @@ int launch_sort_walk(vdet_ctx *c, const SortWalkArgs &a, int nmax, int64_t order
     SortParams sp{};
     sp.mode = a.mode; sp.P = a.P; sp.B = a.B; sp.C = a.C;
     sp.scores = a.scores; sp.keys = a.keys; sp.excl = a.excl; sp.use_thr = a.use_thr; sp.thr = a.thr;
-    if (a.mode == 0 && !a.keys && !c->no_transpose && !a.walk_only) {
+    if (a.mode == 0 && !a.keys && !a.walk_only) {
         // class-innermost volume: one coalesced transpose to [F,C,B] keys, then the sort reads rows
         const int64_t F = a.P / a.C;
         const bool have_keys = c->cache_enabled && c->keys_valid && c->keysrc.scores == a.scores && c->keysrc.F == F &&
@@ -677,10 +594,8 @@ int launch_sort_walk(vdet_ctx *c, const SortWalkArgs &a, int nmax, int64_t order
     sp.groups = c->groups.as<GroupDesc>();
     sp.order = a.order_out ? a.order_out : c->order.as<uint16_t>();
     sp.ncand = a.order_out ? a.ncand_out : c->ncand.as<int32_t>();
-    sp.npass = 4;
     sp.topk = a.topk;
     sp.nover = a.nover_out;
-    if (const char *e = getenv("VDET_SORT_PASSES")) sp.npass = atoi(e);
     const size_t keysB = r16((size_t)2 * std::max(nmax, 1));     // 16 key bits at a time (see sort_kernel)
     const size_t idxB = r16((size_t)2 * std::max(nmax, 1));
     sp.lds_idxa_off = (int)keysB;
@@ -688,7 +603,6 @@ int launch_sort_walk(vdet_ctx *c, const SortWalkArgs &a, int nmax, int64_t order
     sp.lds_base_off = (int)(keysB + 2 * idxB);
     const size_t lds = keysB + 2 * idxB + (size_t)4 * (nw * 256 + 256 + 4);
     const bool big = !var || lds > c->dyn_lds_max;
-    if (!a.walk_only && !a.order_out) c->lists_bucketed = false;      // (set again below if bucket_kernel cuts the context's lists)
     if (big && a.mode != 2)
         return fail(c, VDET_EINVAL, "a frame with %d boxes needs %zu B of LDS for the in-LDS sort; the limit is %zu B "
                                     "(about 18000 boxes per frame)", nmax, lds, c->dyn_lds_max);
@@ -720,21 +634,11 @@ int launch_sort_walk(vdet_ctx *c, const SortWalkArgs &a, int nmax, int64_t order
         // (threshold / top-k / exclusion lists change ncand: those go to the LSD kernel; a NaN inside an otherwise plain list is
         //  caught per list on the device, binsort_kernels.hpp phase 1)
         const bool use_bin = c->binsort && (sp.mode == 1 || sp.mode == 3) && a.topk == 0 && !a.use_thr && !a.excl && block == 1024 &&
-                             nmax <= 512 * bin_cpw && bin_lds + 4096 <= c->dyn_lds_max && sp.npass == 4;
-        // round 4: cut the lists into score-ordered buckets instead of sorting them (bucket_kernels.hpp) wherever the packed
-        // walk of regular frames will consume them; what the kernel cannot take lands on the same fail list
-        const size_t bk_lds = bucket_lds_bytes(std::max(nmax, 1));
-        const bool packed_ok = c->sym_built && !c->walk_careful && c->walk_packed == 1 && c->wmeta_built;
-        const bool use_bk = c->bucket_mode > 0 && (sp.mode == 1 || sp.mode == 3) && a.topk == 0 && !a.excl && !a.order_out && !a.no_buckets &&
-                            (block == 1024 || c->bucket_mode >= 2) && nmax >= 2 && nmax <= kBkMaxB && bk_lds <= c->dyn_lds_max &&
-                            packed_ok && sp.npass == 4 && !(a.want_heads && c->no_lazy);
+                             nmax <= 512 * bin_cpw && bin_lds + 4096 <= c->dyn_lds_max;
         // frames of at most 384 boxes: one WAVE per list (small_kernels.hpp: the same stable LSD passes without a workgroup)
-        const bool use_small = c->small_lists && c->atomic_rank && a.mode != 2 && nmax <= kSmallMax && a.topk == 0 && !a.excl && sp.npass == 4 &&
-                               !use_bk && !a.nover_out;
+        const bool use_small = c->small_lists && c->atomic_rank && a.mode != 2 && nmax <= kSmallMax && a.topk == 0 && !a.excl && !a.nover_out;
         StageTimer tm(c, ST_SORTK);
-        if (a.mode != 2) c->last_sort_binned = use_bin && !use_bk && !use_small;
-        if (a.mode != 2) c->last_sort_bucketed = use_bk;
-        if (!a.order_out) c->lists_bucketed = use_bk;
+        if (a.mode != 2) c->last_sort_binned = use_bin && !use_small;
         if (use_small) {
             const int kpl = std::max(1, (nmax + 63) / 64);
             const int grid = (((a.P + 3) / 4) + 7) & ~7;
@@ -743,42 +647,6 @@ int launch_sort_walk(vdet_ctx *c, const SortWalkArgs &a, int nmax, int64_t order
                            : kpl == 3 ? reinterpret_cast<const void *>(small_sort_kernel<3>) : kpl == 4 ? reinterpret_cast<const void *>(small_sort_kernel<4>)
                            : kpl == 5 ? reinterpret_cast<const void *>(small_sort_kernel<5>) : reinterpret_cast<const void *>(small_sort_kernel<6>);
             HIPCHK(c, hipLaunchKernel(fn, dim3(grid), dim3(256), args, 0, c->stream));
-        } else if (use_bk) {
-            HIPCHK(c, c->sortctl.reserve(sizeof(BinSortCtl) + (size_t)a.P * 4));
-            HIPCHK(c, hipMemsetAsync(c->sortctl.p, 0, sizeof(BinSortCtl), c->stream));
-            HIPCHK(c, c->ent.reserve((size_t)a.P * a.B * 4));
-            HIPCHK(c, c->nsb.reserve((size_t)a.P * 4));
-            BucketParams bp{};
-            const bool floats = sp.keys == nullptr;
-            bp.raw = floats ? reinterpret_cast<const uint32_t *>(sp.scores) : sp.keys;
-            bp.P = a.P; bp.B = a.B; bp.C = a.C;
-            bp.use_thr = floats ? sp.use_thr : 0; bp.thr = sp.thr;
-            bp.groups = sp.groups;
-            bp.group_flags = c->gflags.as<uint32_t>();
-            bp.ent = c->ent.as<uint32_t>();
-            bp.ncand = sp.ncand; bp.nsb = c->nsb.as<int32_t>();
-            bp.order = a.want_heads ? sp.order : nullptr;
-            bp.fail_list = reinterpret_cast<int32_t *>(c->sortctl.as<char>() + sizeof(BinSortCtl));
-            bp.nfail = &c->sortctl.as<BinSortCtl>()->nfail;
-            bp.dbg = c->bk_dbg;
-            bp.head = c->bucket_head;
-            c->bk_raw = bp.raw; c->bk_floats = floats ? 1 : 0;
-#define VDET_BKK(BL, KP) (floats ? reinterpret_cast<const void *>(bucket_kernel<BL, KP, true>) : reinterpret_cast<const void *>(bucket_kernel<BL, KP, false>))
-            const bool wide = c->bucket_block == 1024 && nmax > 4096 && nmax <= 10240;     // VDET_BUCKET_BLOCK=1024 (A-B knob)
-            const void *bfn = wide ? VDET_BKK(1024, 10) : nmax <= 4096 ? VDET_BKK(512, 8) : nmax <= 10240 ? VDET_BKK(512, 20) : VDET_BKK(1024, 16);
-            const int bblock = (wide || nmax > 10240) ? 1024 : 512;
-#undef VDET_BKK
-            void *bargs[] = {&bp};
-            // persistent workgroups (the next list's keys are requested while the current one is cut): as many as are resident
-            const int per_cu = 2 * (bk_lds + 512) <= c->max_lds ? 2 : 1;
-            const int bgrid = std::max(8, (per_cu * c->n_cu) & ~7);
-            HIPCHK(c, hipLaunchKernel(bfn, dim3(bgrid), dim3(bblock), bargs, bk_lds, c->stream));
-            const int32_t *fl = bp.fail_list;
-            const int *fc = bp.nfail;
-            void *largs[] = {&sp, (void *)&fl, (void *)&fc};
-            // (the LSD kernel for the failed lists; blocks of 256 threads take nmax <= 1024)
-            StageTimer tm2(c, ST_SORTFB);
-            HIPCHK(c, hipLaunchKernel(var->fn_list[c->atomic_rank ? 1 : 0], dim3(std::min(a.P, 2 * c->n_cu)), dim3(block), largs, lds, c->stream));
         } else if (use_bin) {
             HIPCHK(c, c->sortctl.reserve(sizeof(BinSortCtl) + (size_t)a.P * 4));
             HIPCHK(c, hipMemsetAsync(c->sortctl.p, 0, sizeof(BinSortCtl), c->stream));
@@ -822,21 +690,14 @@ int launch_sort_walk(vdet_ctx *c, const SortWalkArgs &a, int nmax, int64_t order
     wp.cap = a.cap;
     wp.status = &c->d_cnt->status;
     wp.mask_words = (int)(r16((size_t)4 * ((std::max(nmax, 1) + 31) / 32)) / 4);
-    wp.group_flags = (c->sym_built && !c->walk_careful) ? c->gflags.as<uint32_t>() : nullptr;   // frames whose graph is symmetric
-    wp.packed = (wp.group_flags && c->walk_packed && c->wmeta_built) ? c->walk_packed : 0;    // 1: eight, 2: sixteen candidates per pass
-    wp.wave_words = wp.mask_words + (wp.packed == 2 ? 8 * kPackRing2 : wp.packed ? 8 * kPackRing : 0);   // + the ring of alive candidates
+    wp.group_flags = c->sym_built ? c->gflags.as<uint32_t>() : nullptr;   // frames whose graph is symmetric
+    wp.packed = (wp.group_flags && c->wmeta_built) ? 1 : 0;               // regular frames: eight candidates per pass
+    wp.wave_words = wp.mask_words + (wp.packed ? 8 * kPackRing : 0);      // + the ring of alive candidates
     wp.wmeta = c->wmeta.as<WalkMeta>();
     wp.t32 = c->gt32;
-    if (c->lists_bucketed && !a.order_in && wp.packed == 1) {
-        wp.ent = c->ent.as<uint32_t>(); wp.nsb = c->nsb.as<int32_t>();
-        wp.bk_raw = c->bk_raw; wp.bk_floats = c->bk_floats;
-        wp.dbg = c->walk_dbg;
-    } else if (c->lists_bucketed && !a.order_in) {
-        return fail(c, VDET_EHIP, "internal: bucketed lists without the packed walk");
-    }
     // frames of at most 384 boxes: one LANE per list, the frames' rows in LDS (small_kernels.hpp); the lists of irregular frames
     // are left to the general walk (walk_rest_kernel: normally nothing)
-    const bool small_walk = c->small_lists && a.mode != 2 && nmax <= kSmallMax && wp.group_flags && !wp.ent && a.C > 0 && a.P % a.C == 0;
+    const bool small_walk = c->small_lists && a.mode != 2 && nmax <= kSmallMax && wp.group_flags && a.C > 0 && a.P % a.C == 0;
     if (small_walk) {
         const int G = a.P / a.C;
         const int nq = nmax <= 128 ? 1 : nmax <= 256 ? 2 : 3;
@@ -844,7 +705,9 @@ int launch_sort_walk(vdet_ctx *c, const SortWalkArgs &a, int nmax, int64_t order
         const size_t row_bytes = (size_t)nm * 4 * nq * 4;
         const int fpw = a.C > 32 ? 1 : (int)std::max<size_t>(1, std::min<size_t>((size_t)(64 / a.C), (size_t)(44 * 1024) / row_bytes));
         const size_t lds_bytes = (size_t)fpw * row_bytes;
-        const int vec4 = a.B % 4 == 0 ? 1 : 0;       // a list's candidates four per 8-byte load
+        // a list's candidates four per 8-byte load: rows of B % 4 == 0 entries from an 8-byte aligned base (the caller's lists of
+        // vdet_nms_volume_ordered may sit anywhere)
+        const int vec4 = (a.B % 4 == 0 && ((uintptr_t)wp.order & 7) == 0) ? 1 : 0;
         const int grid = (G + fpw - 1) / fpw;
         StageTimer tm(c, ST_WALK);
 #define VDET_SMALLW(NQ_, V_) hipLaunchKernelGGL((small_walk_kernel<NQ_, V_>), dim3(grid), dim3(64), lds_bytes, c->stream, wp, G, fpw, nm)
@@ -967,6 +830,71 @@ int group_by_frame(vdet_ctx *c, const float *frames, int64_t n, int64_t ld, std:
     return VDET_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The drop-in calls on <= kFusedMax rows: ONE launch (fused_kernels.hpp).  The rows are packed into host-mapped memory the
+// kernel reads directly and the kept list comes back the same way: a call is one launch and one host wait -- no staging
+// copies, no scratch shared with the volume entry points (the context's cache stays valid).
+// ---------------------------------------------------------------------------------------------
+constexpr size_t kFusedInBytes = (size_t)kFusedMax * 6 * 4 + (size_t)kFusedMax * 4 + (size_t)kFusedMaxTracks * 5 * 4;
+constexpr size_t kFusedOutBytes = (size_t)(2 + kFusedMax) * 4;
+
+int fused_call(vdet_ctx *c, const float *h_rows, int64_t n, int64_t ld, int ncols, double thresh, const int64_t *h_order,
+               const float *h_tracks, int64_t t, int64_t ldt, int64_t *h_keep, int64_t *n_keep)
+{
+    if (!c->fused_in) {
+        void *pi = nullptr, *po = nullptr;
+        if (hipHostMalloc(&pi, kFusedInBytes, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+            hipHostMalloc(&po, kFusedOutBytes, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+            if (pi) (void)hipHostFree(pi);
+            return fail(c, VDET_ENOMEM, "host-mapped staging memory for the single-launch calls");
+        }
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(fused_nms_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->max_lds));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(fused_nms_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->max_lds));
+        c->fused_in = pi; c->fused_out = po;
+    }
+    float *rows = static_cast<float *>(c->fused_in);
+    int32_t *rank = reinterpret_cast<int32_t *>(rows + (size_t)kFusedMax * 6);
+    float *trk = reinterpret_cast<float *>(rank + kFusedMax);
+    volatile int32_t *out = static_cast<volatile int32_t *>(c->fused_out);
+    if (ld == ncols) memcpy(rows, h_rows, (size_t)n * ncols * 4);
+    else for (int64_t i = 0; i < n; ++i) memcpy(rows + i * ncols, h_rows + i * ld, (size_t)ncols * 4);
+    if (h_order) {   // caller-supplied order: priority = position (earlier = higher)
+        for (int64_t i = 0; i < n; ++i) rank[i] = 0;
+        for (int64_t pos = 0; pos < n; ++pos) {
+            const int64_t i = h_order[pos];
+            if (i < 0 || i >= n || rank[i]) return fail(c, VDET_EINVAL, "order is not a permutation of 0..n-1");
+            rank[i] = (int32_t)(n - pos);
+        }
+    }
+    for (int64_t j = 0; j < t; ++j) memcpy(trk + j * 5, h_tracks + j * ldt, 20);
+    void *d_in = nullptr, *d_out = nullptr;
+    HIPCHK(c, hipHostGetDevicePointer(&d_in, c->fused_in, 0));
+    HIPCHK(c, hipHostGetDevicePointer(&d_out, c->fused_out, 0));
+    FusedParams fp{};
+    fp.rows = static_cast<const float *>(d_in);
+    fp.rank = h_order ? reinterpret_cast<const int32_t *>(fp.rows + (size_t)kFusedMax * 6) : nullptr;
+    fp.tracks = h_tracks ? reinterpret_cast<const float *>(reinterpret_cast<const int32_t *>(fp.rows + (size_t)kFusedMax * 6) + kFusedMax) : nullptr;
+    fp.n = (int)n; fp.ncols = ncols; fp.t = (int)t;
+    fp.t32 = thresh_to_f32(thresh);
+    fp.out = static_cast<int32_t *>(d_out);
+    int n2 = 64;
+    while (n2 < n) n2 <<= 1;
+    const size_t lds = fused_lds_bytes((int)n, n2);
+    {
+        StageTimer tm(c, ST_WALK);
+        if (n <= 128) hipLaunchKernelGGL(fused_nms_kernel<256>, dim3(1), dim3(256), lds, c->stream, fp);
+        else hipLaunchKernelGGL(fused_nms_kernel<1024>, dim3(1), dim3(1024), lds, c->stream, fp);
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, host_sync(c));
+    if (out[0] & kStDivZero) return fail(c, VDET_EDIVZERO, "float division (zero union)");
+    const int64_t nk = out[1];
+    if (nk < 0 || nk > n) return fail(c, VDET_EHIP, "internal: single-launch NMS returned %lld of %lld rows", (long long)nk, (long long)n);
+    for (int64_t k = 0; k < nk; ++k) h_keep[k] = out[2 + k];
+    *n_keep = nk;
+    return VDET_OK;
+}
+
 }  // namespace
 
 // =============================================================================================
@@ -1010,36 +938,11 @@ int vdet_create(vdet_ctx **out, int device)
     }
     c->stream = c->own_stream;
     (void)hipMemsetAsync(c->d_cnt, 0, sizeof(Counters), c->stream);
-    if (const char *e = getenv("VDET_NO_TRANSPOSE")) c->no_transpose = atoi(e) != 0;
     if (const char *e = getenv("VDET_NO_INDEX")) c->no_index = atoi(e) != 0;
     if (const char *e = getenv("VDET_NO_LAZY")) c->no_lazy = atoi(e) != 0;
-    if (const char *e = getenv("VDET_WALK_CAREFUL")) c->walk_careful = atoi(e) != 0;
-    if (const char *e = getenv("VDET_WALK_PACKED")) c->walk_packed = std::max(0, std::min(2, atoi(e)));
-    if (const char *e = getenv("VDET_LINK_MATERIALIZE")) c->link_materialize = atoi(e) != 0;
-    if (const char *e = getenv("VDET_SERIES_SERIAL")) c->series_serial = atoi(e) != 0;
-    if (const char *e = getenv("VDET_RESCORE_ADJ")) c->rescore_adj = atoi(e) != 0;
-    if (const char *e = getenv("VDET_LINK_MEMO")) c->link_memo = atoi(e) != 0;
+    if (const char *e = getenv("VDET_NO_FUSED")) c->no_fused = atoi(e) != 0;
     if (const char *e = getenv("VDET_BINSORT")) c->binsort = atoi(e) != 0;
-    if (const char *e = getenv("VDET_BUCKETS")) c->bucket_mode = atoi(e);
-    if (const char *e = getenv("VDET_LINK_FILL")) c->link_fill = atoi(e);
-    if (const char *e = getenv("VDET_LINK_COHERENT")) c->link_coherent = atoi(e) != 0;
-    if (const char *e = getenv("VDET_BATCH_CHAINS")) c->batch_chains = atoi(e) != 0;
-    if (const char *e = getenv("VDET_BUCKET_BLOCK")) c->bucket_block = atoi(e);
-    if (const char *e = getenv("VDET_BUCKET_HEAD")) c->bucket_head = std::max(0, std::min(atoi(e), 400));
-    if (const char *e = getenv("VDET_BK_DBG")) c->bk_dbg = atoi(e);
-    if (const char *e = getenv("VDET_WALK_DBG")) c->walk_dbg = atoi(e);
-    if (const char *e = getenv("VDET_TRACK_LOOP")) c->track_loop = atoi(e) != 0;
-    if (const char *e = getenv("VDET_LINK_WARM")) c->link_warm = atoi(e);
-    if (const char *e = getenv("VDET_LINK_MAXB")) c->link_maxb = atoi(e) == 16 ? 16 : 8;
-    if (const char *e = getenv("VDET_LINK_U16")) c->link_u16 = atoi(e) != 0;
-    if (const char *e = getenv("VDET_LINK_LPT")) c->link_lpt = atoi(e) != 0;
-    if (const char *e = getenv("VDET_GRAPH_PIPE")) c->graph_pipe = atoi(e) != 0;
-    if (const char *e = getenv("VDET_AUX_STREAM")) c->use_aux = atoi(e) != 0;
-    if (const char *e = getenv("VDET_LINK_FILL_LDS")) c->link_fill_lds = atoi(e) != 0;
     if (const char *e = getenv("VDET_SMALL_LISTS")) c->small_lists = atoi(e) != 0;
-    if (const char *e = getenv("VDET_WARM_THREADS")) { const int v = atoi(e); if (v == 64 || v == 128 || v == 256) c->warm_threads = v; }
-    if (const char *e = getenv("VDET_LINK_THREADS")) { const int v = atoi(e); if (v == 64 || v == 128 || v == 256) c->link_threads = v; }
-    if (const char *e = getenv("VDET_DEBUG_SYNC")) c->debug_sync = atoi(e) != 0;
     {   // probe: do returning LDS atomics resolve same-address lanes in ascending lane order?
         const int npat = 4096;
         std::vector<uint8_t> pats((size_t)npat * 64);
@@ -1110,15 +1013,13 @@ int vdet_destroy(vdet_ctx *c)
                       &c->rowz, &c->rowmeta, &c->groupz, &c->adj, &c->comp, &c->origidx, &c->out64,
                       &c->trk_frames, &c->trk_boxes, &c->b1, &c->b2, &c->iou_out, &c->order, &c->ncand, &c->keepidx,
                       &c->keepcnt, &c->gflags, &c->pairs, &c->tkeys, &c->tstate, &c->visited, &c->heads, &c->xkeys, &c->xord, &c->xncand, &c->linkmemo, &c->linkstats, &c->linkwarm, &c->linkorder, &c->linkchains, &c->linknodes, &c->tracknode, &c->rtodo,
-                      &c->xbox, &c->xbox16, &c->xord16, &c->xcum, &c->xinfo, &c->wmeta, &c->reachtab, &c->sortctl, &c->segtab, &c->vidtab, &c->ent, &c->nsb, &c->nover, &c->ordncand};
+                      &c->xbox, &c->xbox16, &c->xord16, &c->xcum, &c->xinfo, &c->wmeta, &c->reachtab, &c->sortctl, &c->segtab, &c->vidtab, &c->nover, &c->ordncand};
     for (DevBuf *b : bufs) b->release();
     for (DevBuf &b : c->tmp) b.release();
     for (auto &e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (c->d_cnt) (void)hipFree(c->d_cnt);
-    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
-    for (hipEvent_t e : c->ev_pipe) (void)hipEventDestroy(e);
-    if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
+    if (c->fused_in) (void)hipHostFree(c->fused_in);
+    if (c->fused_out) (void)hipHostFree(c->fused_out);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return VDET_OK;
@@ -1165,13 +1066,6 @@ int vdet_query(vdet_ctx *c, int what)
     if (what == 8) return (int)std::min<long long>(c->n_host_syncs, 0x7FFFFFFF);
     if (what == 9) {   // problems the last volume sort's counting kernel handed to the LSD kernel (-1: it did not run)
         if (!c->last_sort_binned || !c->sortctl.p) return -1;
-        BinSortCtl h{};
-        if (hipMemcpyAsync(&h, c->sortctl.p, sizeof h, hipMemcpyDeviceToHost, c->stream) != hipSuccess || host_sync(c) != hipSuccess) return VDET_EHIP;
-        return h.nfail;
-    }
-    if (what == 10) return c->last_sort_bucketed ? 1 : 0;   // the last volume sort cut its lists into buckets (bucket_kernels.hpp)
-    if (what == 11) {  // ... and handed this many lists to the LSD kernel (-1: it did not run)
-        if (!c->last_sort_bucketed || !c->sortctl.p) return -1;
         BinSortCtl h{};
         if (hipMemcpyAsync(&h, c->sortctl.p, sizeof h, hipMemcpyDeviceToHost, c->stream) != hipSuccess || host_sync(c) != hipSuccess) return VDET_EHIP;
         return h.nfail;
@@ -1267,6 +1161,8 @@ int vdet_nms_f32(vdet_ctx *c, const float *h_dets, int64_t n, int64_t ld, int nc
     if (n > 0x7FFFFFFF) return fail(c, VDET_EINVAL, "too many detections");
     HIPCHK(c, hipSetDevice(c->device));
     timing_reset(c);
+    if (n <= kFusedMax && !c->no_fused)      // the T-CNN call sizes: one launch (fused_kernels.hpp)
+        return fused_call(c, h_dets, n, ld, ncols, thresh, h_order, nullptr, 0, 0, h_keep, n_keep);
     const int o = ncols == 6 ? 1 : 0;
 
     NmsPlan pl;
@@ -1332,6 +1228,8 @@ int vdet_track_det_nms_f32(vdet_ctx *c, const float *h_tracks, int64_t t, int64_
     if (m > 0x7FFFFFFF || t > 0x7FFFFFFF) return fail(c, VDET_EINVAL, "too many rows");
     HIPCHK(c, hipSetDevice(c->device));
     timing_reset(c);
+    if (m <= kFusedMax && t <= kFusedMaxTracks && !c->no_fused)      // the T-CNN call sizes: one launch (fused_kernels.hpp)
+        return fused_call(c, h_dets, m, ldd, 6, thresh, nullptr, t > 0 ? h_tracks : nullptr, t, ldt, h_keep, n_keep);
     NmsPlan pl;
     std::vector<int64_t> perm;
     int rc = group_by_frame(c, h_dets, m, ldd, perm, pl.groups);
@@ -1494,15 +1392,11 @@ int vdet_det_nms_volume(vdet_ctx *c, const float *d_boxes, const float *d_scores
     HIPCHK(c, c->nover.reserve((size_t)(F * K) * 4));
     SortWalkArgs a{};
     a.sort_only = true;
-    a.no_buckets = true;             // the selection wants the k best in exact order
     a.mode = 0; a.P = (int)(F * K); a.B = (int)B; a.C = (int)K;
     a.scores = d_scores;
     a.use_thr = use_score_thresh ? 1 : 0; a.thr = score_thresh; a.topk = topk;
     a.nover_out = c->nover.as<int32_t>();
-    const bool saved = c->no_transpose;
-    c->no_transpose = false;
     const int rc = launch_sort_walk(c, a, (int)B, F * K * B);
-    c->no_transpose = saved;
     if (rc) return rc;
     DetNmsParams dp{};
     dp.boxes = reinterpret_cast<const float4 *>(d_boxes); dp.scores = d_scores;
@@ -1620,7 +1514,7 @@ int vdet_nms_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scor
     const bool same_geo = c->cache_enabled && c->graph_valid && c->prep.boxes == d_boxes && c->prep.F == F &&
                           c->prep.B == B && memcmp(&c->prep.t32, &t32, 4) == 0;
     const bool same_lists = same_geo && c->lists_valid && c->prep.scores == d_scores && c->prep.C == C &&
-                            c->prep.layout == VDET_LAYOUT_FBC && c->prep.use_thr == 0 && c->prep.topk == 0 && !c->no_transpose;
+                            c->prep.layout == VDET_LAYOUT_FBC && c->prep.use_thr == 0 && c->prep.topk == 0;
     int rc;
     if (!same_geo) {
         c->graph_valid = c->lists_valid = false;
@@ -1631,15 +1525,11 @@ int vdet_nms_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scor
     }
     if (!same_lists) {
         // descending lists per (frame, class): always through the transposed keys (pick needs them)
-        const bool saved = c->no_transpose;
-        c->no_transpose = false;
         SortWalkArgs a{};
         a.sort_only = true;
-        a.want_heads = true;
         a.mode = 0; a.P = (int)(F * C); a.B = (int)B; a.C = (int)C;
         a.scores = d_scores;
         rc = launch_sort_walk(c, a, (int)B, F * C * B);
-        c->no_transpose = saved;
         if (rc) return rc;
     }
     // regular-frame fast paths (lazy lists, x-window link): only when THIS graph build (or the cached
@@ -1650,93 +1540,58 @@ int vdet_nms_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scor
     const uint32_t *w_flags = regular_ok ? c->gflags.as<uint32_t>() : nullptr;
     FrameIndex w_ix{nullptr, nullptr, nullptr, nullptr};
     if (w_flags && c->index_valid && !c->no_index) w_ix = frame_index_of(c);
-    BucketLists bkl{nullptr, nullptr};     // how far the u16 rows of bucketed lists are materialised (track_kernels.hpp)
-    if (c->lists_bucketed) bkl = BucketLists{c->ent.as<uint32_t>(), c->nsb.as<int32_t>()};
     c->nodes_valid = false;
     HIPCHK(c, c->tracknode.reserve((size_t)std::max<int64_t>(C * max_tracks * F, 1) * 4));
     HIPCHK(c, hipMemsetAsync(c->tracknode.p, 0xFF, (size_t)std::max<int64_t>(C * max_tracks * F, 1) * 4, c->stream));
-    bool forked = false;
     int materialized = 0;            // warm chains per class whose tubelets are written out (0: none)
-    if (c->link_memo) {      // one memo per call: a link step depends on the video's boxes and link_thres only
-        HIPCHK(c, c->linkmemo.reserve((size_t)2 * F * B * 8));
-        HIPCHK(c, c->linkstats.reserve(16));
-        // warm the memo: the chains of every class's likely anchors, all at once (the chip is full instead of running
-        // 2 C latency-bound blocks per track); the tracking loop below then mostly walks known steps.  The warm-up only
-        // reads the sorted lists, so it runs on the context's second stream NEXT TO the NMS walk of the same video
-        // (per-stage timing keeps everything on one stream: HIP events on two streams would not add up)
-        const int wm_raw = c->link_warm < 0 ? std::min(max_tracks + (c->link_materialize ? 6 : 2), 24) : std::min(c->link_warm, 64);   // (measured: 12 / 16 of 10 tracks)
-        // + slots for the anchors of COHERENT videos (track_warm_anchors_body: filled only when a class's raw candidates repeat
-        // each other's objects across frames; empty -- and free -- otherwise).  Large frames only: small ones get the whole table
-        const bool coherent_slots = c->link_coherent && c->link_warm < 0 && wm_raw > 0 && F <= 512 && regular_ok &&
-                                    !(c->link_fill > 0 && B <= c->link_fill && w_ix.xbox != nullptr);
-        const int wm = coherent_slots ? std::min(wm_raw + max_tracks, 32) : wm_raw;
-        hipStream_t ws = c->stream;
-        if (c->use_aux && want_nms && !c->timing && wm > 0 && max_tracks > 0) {
-            if (!c->aux_stream) {
-                HIPCHK(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
-                HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-                HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
-            }
-            HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
-            HIPCHK(c, hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
-            ws = c->aux_stream;
-            forked = true;
-        }
-        HIPCHK(c, hipMemsetAsync(c->linkmemo.p, 0, (size_t)2 * F * B * 8, ws));
-        HIPCHK(c, hipMemsetAsync(c->linkstats.p, 0, 16, ws));
+    // one link memo per call: a link step depends on the video's boxes and link_thres only
+    HIPCHK(c, c->linkmemo.reserve((size_t)2 * F * B * 8));
+    HIPCHK(c, c->linkstats.reserve(16));
+    HIPCHK(c, hipMemsetAsync(c->linkmemo.p, 0, (size_t)2 * F * B * 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->linkstats.p, 0, 16, c->stream));
+    if (max_tracks > 0) {
         // small frames: the whole link table up front (every node's window scan, chip-filling) -- then no step of any chain
         // is ever scanned again, whatever the anchors turn out to be
-        const bool filled = c->link_fill > 0 && B <= c->link_fill && w_ix.xbox != nullptr && max_tracks > 0;
-        if (filled) {
-            StageTimer tm(c, ST_TLINK);
-            if (c->link_fill_lds && B <= 1024)
-                hipLaunchKernelGGL(link_fill_frame_kernel, dim3((unsigned)F, 2), dim3((unsigned)(64 * ((B + 63) / 64))), link_fill_lds_bytes((int)B), ws,
-                                   reinterpret_cast<const float4 *>(d_boxes), (int)F, (int)B, link_t32, w_flags, w_ix, link_thres,
-                                   c->linkmemo.as<unsigned long long>());
-            else
-            hipLaunchKernelGGL(link_fill_kernel, dim3((unsigned)((F * B * kFillLanes + 255) / 256), 2), dim3(256), 0, ws, reinterpret_cast<const float4 *>(d_boxes),
-                               (int)F, (int)B, link_t32, w_flags, w_ix, link_thres, c->linkmemo.as<unsigned long long>());
+        const bool filled = B <= kLinkFillMax && w_ix.xbox != nullptr;
+        // warm the memo otherwise: the chains of every class's likely anchors, all at once (the chip is full instead of
+        // running 2 C latency-bound blocks per track); the tracking loop below then mostly walks known steps.  + slots for
+        // the anchors of COHERENT videos (track_warm_anchors_body: filled only when a class's raw candidates repeat each
+        // other's objects across frames; empty -- and free -- otherwise)
+        const int wm_raw = std::min(max_tracks + 6, 24);       // (measured: 16 of 10 tracks)
+        const bool coherent_slots = F <= 512 && regular_ok && !filled;
+        const int wm = coherent_slots ? std::min(wm_raw + max_tracks, 32) : wm_raw;
+        StageTimer tm(c, ST_TLINK);
+        if (filled)
+            hipLaunchKernelGGL(link_fill_frame_kernel, dim3((unsigned)F, 2), dim3((unsigned)(64 * ((B + 63) / 64))), link_fill_lds_bytes((int)B), c->stream,
+                               reinterpret_cast<const float4 *>(d_boxes), (int)F, (int)B, link_t32, w_flags, w_ix, link_thres,
+                               c->linkmemo.as<unsigned long long>());
+        HIPCHK(c, c->linkwarm.reserve((size_t)C * wm * 4));
+        hipLaunchKernelGGL(track_warm_anchors_kernel, dim3((unsigned)C), dim3(256), 0, c->stream, c->tkeys.as<uint32_t>(),
+                           c->order.as<uint16_t>(), c->ncand.as<int32_t>(), (int)F, (int)B, (int)C, d_scores, thres, wm,
+                           c->linkwarm.as<int32_t>(),
+                           WarmExtra{coherent_slots ? reinterpret_cast<const float4 *>(d_boxes) : nullptr, t32, wm_raw, max_tracks});
+        if (!filled) {
+            // longest chains first, then every (chain, direction) as one block of the warm-up launch
+            HIPCHK(c, c->linkorder.reserve((size_t)C * wm * 2 * 4));
+            hipLaunchKernelGGL(warm_order_kernel, dim3(1), dim3(1024), 0, c->stream, c->linkwarm.as<int32_t>(), (int)(C * wm), (int)F, (int)B,
+                               reach, c->linkorder.as<int32_t>());
+            hipLaunchKernelGGL((track_link_memo_kernel<256, 1, 8>), dim3((unsigned)(C * wm), 2), dim3(256), 0, c->stream,
+                               reinterpret_cast<const float4 *>(d_boxes), (int)F, (int)B, max_tracks, link_t32, reach,
+                               (const TrackState *)nullptr, (float *)nullptr, w_flags, w_ix, link_thres,
+                               c->linkmemo.as<unsigned long long>(), c->linkstats.as<unsigned int>(), c->linkwarm.as<int32_t>(),
+                               (int32_t *)nullptr, (const int32_t *)c->linkorder.as<int32_t>());
         }
-        if (wm > 0 && max_tracks > 0) {
-            HIPCHK(c, c->linkwarm.reserve((size_t)C * wm * 4));
-            StageTimer tm(c, ST_TLINK);
-            hipLaunchKernelGGL(track_warm_anchors_kernel, dim3((unsigned)C), dim3(256), 0, ws, c->tkeys.as<uint32_t>(),
-                               c->order.as<uint16_t>(), c->ncand.as<int32_t>(), (int)F, (int)B, (int)C, d_scores, thres, wm,
-                               c->linkwarm.as<int32_t>(), bkl,
-                               WarmExtra{coherent_slots ? reinterpret_cast<const float4 *>(d_boxes) : nullptr, t32, wm_raw, max_tracks});
-            const int32_t *w_order = nullptr;
-            if (c->link_lpt && !filled) {       // longest chains first
-                HIPCHK(c, c->linkorder.reserve((size_t)C * wm * 2 * 4));
-                hipLaunchKernelGGL(warm_order_kernel, dim3(1), dim3(1024), 0, ws, c->linkwarm.as<int32_t>(), (int)(C * wm), (int)F, (int)B,
-                                   reach, c->linkorder.as<int32_t>());
-                w_order = c->linkorder.as<int32_t>();
-            }
-#define VDET_WARM_LT(LT, MB) hipLaunchKernelGGL((track_link_memo_kernel<LT, 1, MB>), dim3((unsigned)(C * wm), 2), dim3(LT), 0, ws, \
-                               reinterpret_cast<const float4 *>(d_boxes), (int)F, (int)B, max_tracks, link_t32, reach, \
-                               (const TrackState *)nullptr, (float *)nullptr, w_flags, w_ix, link_thres, \
-                               c->linkmemo.as<unsigned long long>(), c->linkstats.as<unsigned int>(), c->linkwarm.as<int32_t>(), \
-                               (int32_t *)nullptr, w_order)
-            if (filled) {}                   // (every step is known already)
-            else if (c->link_maxb == 16) VDET_WARM_LT(256, 16);
-            else if (c->warm_threads == 64) VDET_WARM_LT(64, 8);
-            else if (c->warm_threads == 128) VDET_WARM_LT(128, 8);
-            else VDET_WARM_LT(256, 8);
-#undef VDET_WARM_LT
-            if (c->link_materialize) {
-                // every step of the warm chains is known now: write each predicted anchor's tubelet ONCE (one wave walks
-                // a chain; all of them side by side), for the tracking loop to copy (the tail of track_pick_kernel)
-                HIPCHK(c, c->linkchains.reserve((size_t)C * wm * F * 5 * 4));
-                HIPCHK(c, c->linknodes.reserve((size_t)C * wm * F * 4));
-                HIPCHK(c, hipMemsetAsync(c->linknodes.p, 0xFF, (size_t)C * wm * F * 4, ws));
-                hipLaunchKernelGGL((track_link_memo_kernel<64, 2, 8>), dim3((unsigned)(C * wm), 2), dim3(64), 0, ws,
-                                   reinterpret_cast<const float4 *>(d_boxes), (int)F, (int)B, max_tracks, link_t32, reach,
-                                   (const TrackState *)nullptr, c->linkchains.as<float>(), w_flags, w_ix, link_thres,
-                                   c->linkmemo.as<unsigned long long>(), (unsigned int *)nullptr, c->linkwarm.as<int32_t>(),
-                                   c->linknodes.as<int32_t>());
-                materialized = wm;
-            }
-        }
-        if (forked) HIPCHK(c, hipEventRecord(c->ev_join, c->aux_stream));
+        // every step of the warm chains is known now: write each predicted anchor's tubelet ONCE (one wave walks a chain; all
+        // of them side by side), for the tracking loop to copy
+        HIPCHK(c, c->linkchains.reserve((size_t)C * wm * F * 5 * 4));
+        HIPCHK(c, c->linknodes.reserve((size_t)C * wm * F * 4));
+        HIPCHK(c, hipMemsetAsync(c->linknodes.p, 0xFF, (size_t)C * wm * F * 4, c->stream));
+        hipLaunchKernelGGL((track_link_memo_kernel<64, 2, 8>), dim3((unsigned)(C * wm), 2), dim3(64), 0, c->stream,
+                           reinterpret_cast<const float4 *>(d_boxes), (int)F, (int)B, max_tracks, link_t32, reach,
+                           (const TrackState *)nullptr, c->linkchains.as<float>(), w_flags, w_ix, link_thres,
+                           c->linkmemo.as<unsigned long long>(), (unsigned int *)nullptr, c->linkwarm.as<int32_t>(),
+                           c->linknodes.as<int32_t>(), (const int32_t *)nullptr);
+        materialized = wm;
     }
     if (want_nms) {                  // the NMS survivors: one walk over the lists, before they are consumed
         SortWalkArgs a{};
@@ -1753,6 +1608,7 @@ int vdet_nms_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scor
     const unsigned cg = (unsigned)((C + 63) / 64);
     hipLaunchKernelGGL(track_init_kernel, dim3(cg), dim3(64), 0, c->stream, st, (int)C);
     HIPCHK(c, hipMemsetAsync(d_ntracks, 0, (size_t)C * 4, c->stream));
+    if (max_tracks == 0) return VDET_OK;
     SuppressParams sp{};
     sp.boxes = reinterpret_cast<const float4 *>(d_boxes);
     sp.F = (int)F; sp.B = (int)B; sp.C = (int)C; sp.max_tracks = max_tracks;
@@ -1775,25 +1631,22 @@ int vdet_nms_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scor
     sp.status = &c->d_cnt->status;
     sp.mask_words = (int)((((size_t)4 * ((B + 31) / 32) + 15) & ~(size_t)15) / 4);
     sp.lazy = c->no_lazy ? 0 : 1;
-    // lazy-list state of track_pick_kernel: t1 | head | nkp | pos, [F*C] int32 each
+    // lazy-list state of the pick: t1 | head | nkp | pos, [F*C] int32 each
     HIPCHK(c, c->heads.reserve((size_t)(F * C) * 16));
     HIPCHK(c, hipMemsetAsync(c->heads.p, 0, (size_t)(F * C) * 16, c->stream));
     LazyLists lz{};
     lz.boxes = sp.boxes; lz.tracks = d_tracks; lz.t32 = t32;
     lz.t1 = c->heads.as<int32_t>(); lz.head = lz.t1 + F * C; lz.nkp = lz.head + F * C; lz.pos = lz.nkp + F * C;
     lz.group_flags = sp.lazy ? sp.group_flags : nullptr;
-    lz.bk = bkl;
-    // the eager track_det_nms kernel is only needed for the lists the pick does not maintain; when the
+    // the eager track_det_nms pass is only needed for the lists the pick does not maintain; when the
     // host does not know whether every frame is regular (asynchronous build) the kernel asks the device
     const bool need_suppress = !sp.lazy || !sp.group_flags || !c->all_regular;
     sp.n_irregular = &c->d_cnt->irregular;
-    if (forked) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));      // the memo is warm
-    ResolveArgs rv{nullptr, 0, nullptr, nullptr, nullptr, nullptr};
-    if (materialized)      // predicted anchors: their tubelets exist already, the pick kernel copies them
-        rv = ResolveArgs{c->linkwarm.as<int32_t>(), materialized, c->linkchains.as<float>(), c->linknodes.as<int32_t>(), d_tracks,
-                         c->tracknode.as<int32_t>()};
-    if (c->track_loop && c->link_memo && c->link_threads == 256 && !c->debug_sync && max_tracks > 0) {
-        // the whole loop in one launch: one persistent block per class (track_loop_kernel)
+    // predicted anchors: their tubelets exist already, the loop copies them
+    ResolveArgs rv{c->linkwarm.as<int32_t>(), materialized, c->linkchains.as<float>(), c->linknodes.as<int32_t>(), d_tracks,
+                   c->tracknode.as<int32_t>()};
+    {
+        // the whole tracking loop in one launch: one persistent block per class (track_loop_kernel)
         LoopArgs la{};
         la.keys = c->tkeys.as<uint32_t>(); la.lists = c->order.as<uint16_t>(); la.cnt = c->ncand.as<int32_t>();
         la.scores = d_scores; la.thres = thres; la.link_thres = link_thres; la.anchors = d_anchors;
@@ -1803,48 +1656,11 @@ int vdet_nms_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scor
         la.need_suppress = need_suppress ? 1 : 0;
         StageTimer tm(c, ST_TLOOP);
         hipLaunchKernelGGL(track_loop_kernel, dim3((unsigned)C), dim3(256), (size_t)sp.mask_words * 16, c->stream, la, lz, rv, sp);
-    } else
-    for (int t = 0; t < max_tracks; ++t) {
-        {
-            StageTimer tm(c, ST_TPICK);
-            hipLaunchKernelGGL(track_pick_kernel, dim3((unsigned)C), dim3(256), 0, c->stream, c->tkeys.as<uint32_t>(),
-                               c->order.as<uint16_t>(), c->ncand.as<int32_t>(), (int)F, (int)B, (int)C, d_scores, thres,
-                               max_tracks, st, d_anchors, lz, rv);
-        }
-        if (c->debug_sync) { fprintf(stderr, "[vdet] iter %d pick...\n", t); HIPCHK(c, host_sync(c)); fprintf(stderr, "[vdet] iter %d pick ok\n", t); }
-        {
-            StageTimer tm(c, ST_TLINK);
-#define VDET_LINK(LTV) hipLaunchKernelGGL(track_link_kernel<LTV>, dim3((unsigned)C, 2), dim3(LTV), 0, c->stream, \
-                               reinterpret_cast<const float4 *>(d_boxes), (int)F, (int)B, max_tracks, link_t32, reach, st, \
-                               d_tracks, sp.group_flags, sp.ix, link_thres)
-#define VDET_LINKM(LTV) hipLaunchKernelGGL((track_link_memo_kernel<LTV, 0, 8>), dim3((unsigned)C, 2), dim3(LTV), 0, c->stream, \
-                               reinterpret_cast<const float4 *>(d_boxes), (int)F, (int)B, max_tracks, link_t32, reach, st, \
-                               d_tracks, sp.group_flags, sp.ix, link_thres, c->linkmemo.as<unsigned long long>(), c->linkstats.as<unsigned int>(), \
-                               (const int32_t *)nullptr, c->tracknode.as<int32_t>())
-            if (c->link_memo) {
-                if (c->link_threads == 64) VDET_LINKM(64); else if (c->link_threads == 128) VDET_LINKM(128); else VDET_LINKM(256);
-            } else {
-                if (c->link_threads == 64) VDET_LINK(64); else if (c->link_threads == 128) VDET_LINK(128); else VDET_LINK(256);
-            }
-#undef VDET_LINK
-#undef VDET_LINKM
-        }
-        if (c->debug_sync) { fprintf(stderr, "[vdet] iter %d link...\n", t); HIPCHK(c, host_sync(c)); fprintf(stderr, "[vdet] iter %d link ok\n", t); }
-        if (need_suppress) {
-            StageTimer tm(c, ST_TSUPP);
-            const int64_t nblk = (F * C + 3) / 4;     // grid-stride: a video without irregular frames exits at once
-            hipLaunchKernelGGL(track_suppress_kernel, dim3((unsigned)std::min<int64_t>(nblk, 8 * c->n_cu)), dim3(256),
-                               (size_t)sp.mask_words * 16, c->stream, sp);
-        }
-        if (c->debug_sync) { fprintf(stderr, "[vdet] iter %d suppress...\n", t); HIPCHK(c, host_sync(c)); fprintf(stderr, "[vdet] iter %d suppress ok\n", t); }
-        hipLaunchKernelGGL(track_commit_kernel, dim3(cg), dim3(64), 0, c->stream, st, (int)C, d_ntracks);
     }
     HIPCHK(c, hipGetLastError());
-    if (c->link_memo) {
-        c->nodekey.tracks = d_tracks; c->nodekey.boxes = d_boxes; c->nodekey.F = F; c->nodekey.B = B; c->nodekey.C = C;
-        c->nodekey.T = max_tracks; c->nodekey.nms_thres = nms_thres;
-        c->nodes_valid = true;
-    }
+    c->nodekey.tracks = d_tracks; c->nodekey.boxes = d_boxes; c->nodekey.F = F; c->nodekey.B = B; c->nodekey.C = C;
+    c->nodekey.T = max_tracks; c->nodekey.nms_thres = nms_thres;
+    c->nodes_valid = true;
     return VDET_OK;
 }
 
@@ -1878,8 +1694,6 @@ int vdet_video_batch(vdet_ctx *c, const float *d_boxes, const float *d_scores, c
     }
     const int64_t F = h_frame_off[V];
     if (F * C > 0x7FFFFFF0ll || F * B > 0x7FFFFFF0ll || V * C > 0x7FFFFFF0ll) return fail(c, VDET_EINVAL, "volume too large");
-    if (want_rescore && max_tracks > 0 && Fmax > kSeriesWaveMaxF)      // (checked before anything is enqueued; only the re-scoring's series kernel has the limit)
-        return fail(c, VDET_EINVAL, "a video of %lld frames: the batched call re-scores at most %d per video", (long long)Fmax, kSeriesWaveMaxF);
     HIPCHK(c, hipSetDevice(c->device));
     timing_reset(c);
     const float t32 = thresh_to_f32(nms_thres);
@@ -1891,15 +1705,11 @@ int vdet_video_batch(vdet_ctx *c, const float *d_boxes, const float *d_scores, c
     c->prep.boxes = d_boxes; c->prep.F = F; c->prep.B = B; c->prep.t32 = t32;
     c->graph_valid = true;
     {
-        const bool saved = c->no_transpose;
-        c->no_transpose = false;
         SortWalkArgs a{};
         a.sort_only = true;
-        a.no_buckets = true;         // (the batch kernels read sorted rows; small frames are not worth cutting anyway)
         a.mode = 0; a.P = (int)(F * C); a.B = (int)B; a.C = (int)C;
         a.scores = d_scores;
         rc = launch_sort_walk(c, a, (int)B, F * C * B);
-        c->no_transpose = saved;
         if (rc) return rc;
     }
     if (want_nms) {
@@ -1948,10 +1758,13 @@ int vdet_video_batch(vdet_ctx *c, const float *d_boxes, const float *d_scores, c
             same_tab = c->h_vids[(size_t)v].f0 == (int32_t)h_frame_off[v] && c->h_vids[(size_t)v].F == (int32_t)(h_frame_off[v + 1] - h_frame_off[v]);
         if (!same_tab) {
             (void)host_sync(c);
-            c->h_vids.resize((size_t)V);
-            for (int64_t v = 0; v < V; ++v) c->h_vids[(size_t)v] = VidDesc{(int32_t)h_frame_off[v], (int32_t)(h_frame_off[v + 1] - h_frame_off[v])};
+            c->h_vids.clear();           // (committed below, once the copy is enqueued: a failure must not leave a "resident" table)
+            std::vector<VidDesc> tab((size_t)V);
+            for (int64_t v = 0; v < V; ++v) tab[(size_t)v] = VidDesc{(int32_t)h_frame_off[v], (int32_t)(h_frame_off[v + 1] - h_frame_off[v])};
             HIPCHK(c, c->vidtab.reserve((size_t)V * sizeof(VidDesc)));
-            HIPCHK(c, hipMemcpyAsync(c->vidtab.p, c->h_vids.data(), (size_t)V * sizeof(VidDesc), hipMemcpyHostToDevice, c->stream));
+            c->h_vids_stage.swap(tab);   // the copy's source must outlive it
+            HIPCHK(c, hipMemcpyAsync(c->vidtab.p, c->h_vids_stage.data(), (size_t)V * sizeof(VidDesc), hipMemcpyHostToDevice, c->stream));
+            c->h_vids = c->h_vids_stage;
         }
     }
     BatchTrack bt{};
@@ -1976,20 +1789,12 @@ int vdet_video_batch(vdet_ctx *c, const float *d_boxes, const float *d_scores, c
     bt.status = &c->d_cnt->status; bt.n_irregular = &c->d_cnt->irregular;
     {
         StageTimer tm(c, ST_TLINK);
-        if (c->link_fill > 0 && B <= c->link_fill && have_ix) {
+        if (B <= kLinkFillMax && have_ix) {
             // the whole link table of every video: no chain ever scans, whatever its anchor -- so nothing is predicted or
-            // materialised either (VDET_BATCH_CHAINS=1 keeps the predicted chains: measured below)
-            if (c->link_fill_lds && B <= 1024)
-                hipLaunchKernelGGL(batch_link_fill_frame_kernel, dim3((unsigned)Fmax, 2, (unsigned)V), dim3((unsigned)(64 * ((B + 63) / 64))),
-                                   link_fill_lds_bytes((int)B), c->stream, bt);
-            else
-            hipLaunchKernelGGL(batch_link_fill_kernel, dim3((unsigned)((Fmax * B * kFillLanes + 255) / 256), 2, (unsigned)V), dim3(256), 0, c->stream, bt);
-            if (c->batch_chains) {
-                hipLaunchKernelGGL(batch_warm_anchors_kernel, dim3((unsigned)C, (unsigned)V), dim3(256), 0, c->stream, bt);
-                hipLaunchKernelGGL((batch_link_kernel<64, 2>), dim3((unsigned)(C * wm), 2, (unsigned)V), dim3(64), 0, c->stream, bt);
-            } else {
-                bt.wm = 0;
-            }
+            // materialised either
+            hipLaunchKernelGGL(batch_link_fill_frame_kernel, dim3((unsigned)Fmax, 2, (unsigned)V), dim3((unsigned)(64 * ((B + 63) / 64))),
+                               link_fill_lds_bytes((int)B), c->stream, bt);
+            bt.wm = 0;
         } else {
             hipLaunchKernelGGL(batch_warm_anchors_kernel, dim3((unsigned)C, (unsigned)V), dim3(256), 0, c->stream, bt);
             hipLaunchKernelGGL((batch_link_kernel<256, 1>), dim3((unsigned)(C * wm), 2, (unsigned)V), dim3(256), 0, c->stream, bt);
@@ -2005,7 +1810,7 @@ int vdet_video_batch(vdet_ctx *c, const float *d_boxes, const float *d_scores, c
             StageTimer tm(c, ST_RSPATIAL);
             // candidates from the suppression graph wherever the tracking loop recorded the proposal a tubelet box came from (as
             // vdet_rescore_tracks does; needs overlap_thres well above the graph's threshold), the window scan for the rest
-            const bool use_adj = c->rescore_adj && g_flags && overlap_thres - nms_thres > 0.05 && nms_thres > 0.0 && overlap_thres < 1.0;
+            const bool use_adj = g_flags && overlap_thres - nms_thres > 0.05 && nms_thres > 0.0 && overlap_thres < 1.0;
             if (use_adj) {
                 const int64_t nb = F * C * T;
                 HIPCHK(c, c->rtodo.reserve((size_t)nb * 8 + 16));
@@ -2020,9 +1825,13 @@ int vdet_video_batch(vdet_ctx *c, const float *d_boxes, const float *d_scores, c
                                overlap_thres, d_det_score, d_boxes_out);
         }
         StageTimer tm(c, ST_RSERIES);
-        const int stride = (int)(((size_t)Fmax * 9 + 15) & ~(size_t)15);
+        // one wave per series with the series in LDS; videos too long for that stage take the one-thread-per-series kernel
+        const int stride = (int)(((size_t)std::min<int64_t>(Fmax, kSeriesWaveMaxF) * 9 + 15) & ~(size_t)15);
         hipLaunchKernelGGL(batch_rescore_series_kernel, dim3((unsigned)((C * T + 3) / 4), (unsigned)V), dim3(256), (size_t)stride * 4, c->stream, bt,
                            d_det_score, d_pooled, window, &c->d_cnt->eindex, stride);
+        if (Fmax > kSeriesWaveMaxF)
+            hipLaunchKernelGGL(batch_rescore_series_long_kernel, dim3((unsigned)((C * T + 63) / 64), (unsigned)V), dim3(64), 0, c->stream, bt,
+                               d_det_score, d_pooled, window, &c->d_cnt->eindex);
     }
     HIPCHK(c, hipGetLastError());
     return VDET_OK;
@@ -2073,7 +1882,7 @@ int vdet_rescore_tracks(vdet_ctx *c, const float *d_tracks, const int32_t *d_ntr
         StageTimer tm(c, ST_RSPATIAL);
         // the tracks of the last tracking call on this context, same boxes, graph still in place (cache contract):
         // candidates from the suppression graph (see the kernel); needs overlap_thres well above the graph's threshold
-        const bool use_adj = c->rescore_adj && flags && c->cache_enabled && c->nodes_valid && c->graph_valid &&
+        const bool use_adj = flags && c->cache_enabled && c->nodes_valid && c->graph_valid &&
                              c->nodekey.tracks == d_tracks && c->nodekey.boxes == d_boxes && c->prep.boxes == d_boxes &&
                              c->nodekey.F == F && c->nodekey.B == B && c->nodekey.C == C && c->nodekey.T == max_tracks &&
                              c->prep.F == F && c->prep.B == B && overlap_thres - c->nodekey.nms_thres > 0.05 &&
@@ -2108,7 +1917,7 @@ int vdet_rescore_tracks(vdet_ctx *c, const float *d_tracks, const int32_t *d_ntr
     {
         StageTimer tm(c, ST_RSERIES);
         const int n = (int)(C * max_tracks);
-        if (F <= kSeriesWaveMaxF && !c->series_serial) {      // one wave per series
+        if (F <= kSeriesWaveMaxF) {      // one wave per series, the series in LDS
             const int stride = (int)(((size_t)F * 9 + 15) & ~(size_t)15);
             hipLaunchKernelGGL(rescore_series_wave_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), (size_t)stride * 4, c->stream,
                                d_det_score, d_pooled, d_ntracks, (int)F, (int)C, max_tracks, window, &c->d_cnt->eindex, stride);
@@ -2459,12 +2268,13 @@ static int upload_segments(vdet_ctx *c, const int64_t *h_frame_off, int64_t V, i
     // the per-frame {first, one past last} table: rebuilt and uploaded only when the offsets differ from the resident ones
     if (c->segtab.p && c->h_seg_off.size() == (size_t)V + 1 && std::equal(c->h_seg_off.begin(), c->h_seg_off.end(), h_frame_off)) return VDET_OK;
     (void)host_sync(c);      // (an earlier copy from the host table may be in flight)
-    c->h_seg_off.assign(h_frame_off, h_frame_off + V + 1);
+    c->h_seg_off.clear();    // (committed below, once the copy is enqueued: a failure must not leave a "resident" table)
     c->h_seg.resize((size_t)std::max<int64_t>(F, 1));
     for (int64_t v = 0; v < V; ++v)
         for (int64_t f = h_frame_off[v]; f < h_frame_off[v + 1]; ++f) c->h_seg[(size_t)f] = make_int2((int)h_frame_off[v], (int)h_frame_off[v + 1]);
     HIPCHK(c, c->segtab.reserve(c->h_seg.size() * sizeof(int2)));
     if (F) HIPCHK(c, hipMemcpyAsync(c->segtab.p, c->h_seg.data(), (size_t)F * sizeof(int2), hipMemcpyHostToDevice, c->stream));
+    c->h_seg_off.assign(h_frame_off, h_frame_off + V + 1);
     return VDET_OK;
 }
 
@@ -2499,7 +2309,7 @@ static int volume_pass_impl(vdet_ctx *c, const float *d_scores, int64_t F, int64
     // 4 items per thread (the window of every item lives in registers: more would cost occupancy), 256 or 512 threads
     const int64_t C4 = C / 4;
     int items = 0, TB = 0, NT = 0;
-    if (C % 4 == 0 && (window == 3 || window == 5) && !c->no_transpose &&
+    if (C % 4 == 0 && (window == 3 || window == 5) &&
         (((uintptr_t)d_scores | (uintptr_t)d_out_max | (uintptr_t)(conv ? d_out_conv : d_out_max)) & 15) == 0) {
         for (int nt : {256, 512}) {
             int tb = 64;
@@ -2507,11 +2317,6 @@ static int volume_pass_impl(vdet_ctx *c, const float *d_scores, int64_t F, int64
             if (tb >= 16 && (nt == 512 || tb >= 32)) { items = 4; TB = tb; NT = nt; break; }
         }
         if (items && (size_t)2 * C4 * TB * 16 > c->max_lds / 2) items = 0;
-        if (const char *e = getenv("VDET_VPASS")) {   // A-B knob: "NT,TB" (e.g. 256,16)
-            int nt = 0, tb = 0;
-            if (sscanf(e, "%d,%d", &nt, &tb) == 2 && (nt == 256 || nt == 512) && (tb == 16 || tb == 32 || tb == 64) &&
-                (int64_t)tb * C4 <= (int64_t)nt * 4 && items) { NT = nt; TB = tb; }
-        }
     }
     if (!items) {
         // shapes the fused kernel does not cover: the temporal pass(es) now, the key transpose with the sort
@@ -2531,7 +2336,6 @@ static int volume_pass_impl(vdet_ctx *c, const float *d_scores, int64_t F, int64
     if (conv) for (int k = 0; k < window; ++k) taps.w[k] = h_taps[k];
     const int ntiles = (int)((B + TB - 1) / TB);
     int64_t chunks = std::min<int64_t>(std::max<int64_t>(F / 8, 1), (8 * c->n_cu + ntiles - 1) / ntiles);
-    if (const char *e = getenv("VDET_VPASS_CHUNKS")) { const int v = atoi(e); if (v > 0) chunks = std::min<int64_t>(v, F); }   // A-B knob
     chunks = std::max<int64_t>(1, std::min<int64_t>(chunks, 65535));
     const int fchunk = (int)((F + chunks - 1) / chunks);
     const dim3 grid((unsigned)ntiles, (unsigned)((F + fchunk - 1) / fchunk));
@@ -2552,8 +2356,6 @@ static int volume_pass_impl(vdet_ctx *c, const float *d_scores, int64_t F, int64
     const float4 *in4 = reinterpret_cast<const float4 *>(d_scores);
     float4 *om = reinterpret_cast<float4 *>(d_out_max), *oc = reinterpret_cast<float4 *>(d_out_conv);
     uint32_t *keys = c->tkeys.as<uint32_t>();
-    const bool nokeys = getenv("VDET_VPASS_NOKEYS") != nullptr;      // timing experiments only: results are NOT valid
-    if (nokeys) keys = nullptr;
     int Fi = (int)F, Bi = (int)B, C4i = (int)C4;
     void *args[] = {&in4, &om, &oc, &keys, &Fi, &Bi, &C4i, &TB, &tb_shift, (void *)&fchunk, &pad_max, &pad_conv, &bias, &taps,
                     &use_score_thresh, &score_thresh, (void *)&d_seg};
@@ -2564,7 +2366,7 @@ static int volume_pass_impl(vdet_ctx *c, const float *d_scores, int64_t F, int64
     HIPCHK(c, hipGetLastError());
     c->keysrc.scores = d_scores; c->keysrc.F = F; c->keysrc.B = B; c->keysrc.C = C;
     c->keysrc.use_thr = use_score_thresh ? 1 : 0; c->keysrc.thr = score_thresh;
-    c->keys_valid = !nokeys;
+    c->keys_valid = true;
     return VDET_OK;
 }
 
