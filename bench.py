@@ -110,24 +110,15 @@ def kept_dets_to_det_proto(video_name, kept_idx, kept_cnt, boxes, scores, class_
     return {"video": video_name, "detections": [dets[k] for k in sorted(dets)]}
 
 
-def run_sharded(args):
-    """BASELINE configs[3]: `--videos` videos sharded over the ranks (LPT by frames x boxes), `--streams` of them in flight
-    per rank, and ONE exchange step per pass: ragged RCCL all-gathers of every video's results (tubelets with their
-    re-scored boxes and pooled scores, the top-k kept detections per (frame, class) + counts).  A "step" = one pass over
-    all the videos.  Rank 0 turns one gathered video into det_proto / track_proto dicts."""
+def sharded_core(args, torch, dist, vdist, dev, local, world, rank, V, steps, warmup, force_x, one_gpu, check_oracle=False):
+    """BASELINE configs[3]: V videos sharded over the ranks (LPT by frames x boxes), `--streams` of them in flight per rank,
+    and ONE exchange step per pass: ragged RCCL all-gathers of every video's results (tubelets with their re-scored boxes and
+    pooled scores, the top-k kept detections per (frame, class) + counts).  A "step" = one pass over all the videos.  Rank 0
+    turns one gathered video into det_proto / track_proto dicts and (check_oracle) checks it against the CPU oracle.
+    Returns the result dict on rank 0 (None elsewhere)."""
     import numpy as np
-    import torch
-    import torch.distributed as dist
-    from vdetlib_amd import ops, _lib, dist as vdist
-    world, rank, local = vdist.env_world()
-    one_gpu = os.environ.get("VDET_BENCH_ONE_GPU") == "1"
-    if one_gpu:
-        local = 0
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    force_x = args.force_exchange
-    vdist.init(backend=("gloo" if one_gpu else "nccl") if (world > 1 or force_x) else None, device=dev, force=force_x)
-    V, B, C, T, TOPK = args.videos, args.boxes, args.classes, args.max_tracks, min(100, args.cap)
+    from vdetlib_amd import ops, _lib
+    B, C, T, TOPK = args.boxes, args.classes, args.max_tracks, min(100, args.cap)
     TAPS = [0.25, 0.5, 0.25]
     rs = np.random.RandomState(3000)
     frames = [max(3, int(round(args.frames * (0.75 + 0.5 * u)))) for u in rs.rand(V)]      # videos differ in length
@@ -183,7 +174,7 @@ def run_sharded(args):
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(max(args.warmup, 2)):
+    for _ in range(max(warmup, 2)):
         one_pass()
         for cx in ctxs:
             try:
@@ -193,7 +184,7 @@ def run_sharded(args):
     fence()
     del exch_ms[:]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         res, gathered = one_pass()
     fence()
     dt = time.perf_counter() - t0
@@ -210,7 +201,7 @@ def run_sharded(args):
     total_boxes = sum(frames) * B
     result = None
     if rank == 0:
-        xinfo, protos = None, None
+        xinfo, protos, oracle_check = None, None, None
         if gathered is not None:
             xms = [a.elapsed_time(b) for a, b in exch_ms]
             got = sorted(int(m[0]) for part in gathered["meta"] for m in part.tolist())
@@ -218,45 +209,164 @@ def run_sharded(args):
                      "backend": dist.get_backend(), "world": dist.get_world_size(), "videos_gathered": len(got),
                      "all_videos_present": got == list(range(V))}
             # one video of the LAST rank's shard -> protocol dicts on rank 0 (boxes / scores of a remote video: regenerated
-            # from its seed here; a deployment has the box protos on the host)
+            # from its seed here; a deployment has the box protos on the host).  The shortest one: the oracle check below is
+            # single-threaded python + C
             r_ = len(gathered["meta"]) - 1
             while r_ > 0 and gathered["meta"][r_].shape[0] == 0:
                 r_ -= 1
             metas = gathered["meta"][r_].tolist()
-            v, Fv = int(metas[0][0]), int(metas[0][1])
-            tub = gathered["tub"][r_][:C * T * Fv].reshape(C, T, Fv, 10)
-            anc = gathered["anchors"][r_][:C * T].reshape(C, T, 3)
-            ntr = gathered["ntracks"][r_][:C]
-            kept = gathered["kept"][r_][:Fv * C].reshape(Fv, C, TOPK).cpu().numpy()
-            kcnt = gathered["kcnt"][r_][:Fv * C].reshape(Fv, C).cpu().numpy()
+            slot = min(range(len(metas)), key=lambda q: (metas[q][1], q))
+            v, Fv = int(metas[slot][0]), int(metas[slot][1])
+            f_before = sum(int(m[1]) for m in metas[:slot])
+            tub = gathered["tub"][r_][C * T * f_before:C * T * (f_before + Fv)].reshape(C, T, Fv, 10)
+            anc = gathered["anchors"][r_][C * T * slot:C * T * (slot + 1)].reshape(C, T, 3)
+            ntr = gathered["ntracks"][r_][C * slot:C * (slot + 1)]
+            kept = gathered["kept"][r_][f_before * C:(f_before + Fv) * C].reshape(Fv, C, TOPK).cpu().numpy()
+            kcnt = gathered["kcnt"][r_][f_before * C:(f_before + Fv) * C].reshape(Fv, C).cpu().numpy()
             c_best = int(torch.argmax(ntr).item())
             tp = ops.tracks_to_proto("synth_%d" % v, tub[c_best, :, :, :5].contiguous(), anc[c_best], int(ntr[c_best]))
             hb, hs = [t.cpu().numpy() for t in (vids[v] if v in vids else synth_video_cuda(torch, 3000 + v, Fv, B, C, dev, args.scores))]
             dp = kept_dets_to_det_proto("synth_%d" % v, kept[:min(Fv, 3)], kcnt[:min(Fv, 3)], hb, hs, ["c%d" % (c + 1) for c in range(C)], TOPK)
             protos = {"video": v, "from_rank": r_, "track_proto_class": c_best + 1, "tracks": len(tp["tracks"]),
                       "track_boxes": sum(len(t) for t in tp["tracks"]), "det_proto_frames": min(Fv, 3), "detections": len(dp["detections"])}
+            if check_oracle:
+                # the GATHERED records of that video against the CPU oracle: the kept lists of 4 frames x all classes
+                # (utils/nms.pyx:17-68 per (frame, class)) and every tubelet of one class with its re-scoring
+                # (vdet/track.py:189-252, vdet/tubelet_cls.py:493-535, :284-303, :386-414)
+                from oracle import oracle
+                oracle.build()
+                fr = sorted(set([0, Fv // 3, (2 * Fv) // 3, Fv - 1]))
+                nthr = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+                widx, wcnt = oracle.nms_volume(hb[fr], np.ascontiguousarray(hs[fr]), args.thresh, cap=args.cap, threads=nthr)
+                ok_nms = bool(np.array_equal(kcnt[fr], wcnt))
+                for a, f in enumerate(fr):
+                    for c in range(C):
+                        n = min(int(wcnt[a, c]), TOPK)
+                        ok_nms = ok_nms and bool(np.array_equal(kept[f, c, :n], widx[a, c, :n]))
+                wt, wn, wpool, wbx = oracle.rescored_tubelets(hb, np.ascontiguousarray(hs[:, :, c_best:c_best + 1]), args.thresh, args.track_thres, T,
+                                                              args.link_thres, args.pool_thres, args.window)
+                n = int(wn[0])
+                gt = tub[c_best].cpu().numpy()
+                ok_tub = int(ntr[c_best]) == n and bool(np.array_equal(gt[:n, :, :5], wt[0, :n], equal_nan=True))
+                has = ~np.isnan(wt[0, :n, :, 0])
+                ok_tub = ok_tub and bool(np.array_equal(gt[:n, :, 5:9][has], wbx[0, :n][has]))
+                ok_tub = ok_tub and bool(np.allclose(gt[:n, :, 9][has], wpool[0, :n][has].astype(np.float32), rtol=0, atol=1e-5))
+                oracle_check = {"video": v, "frames": Fv, "nms_frames": fr, "nms_lists": len(fr) * C, "nms_ok": ok_nms,
+                                "tubelet_class": c_best + 1, "tubelets": n, "tubelets_ok": bool(ok_tub)}
         bpb = 16 * C + 16
+        loads8 = [sum(frames[v] for v in o) * B for o in vdist.shard_lpt([f * B for f in frames], 8)]
         result = {
-            "metric": METRIC, "value": total_boxes * args.steps / dt, "unit": "boxes/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "metric": METRIC, "value": total_boxes * steps / dt, "unit": "boxes/s", "n_gpus": world, "steps": steps,
+            "warmup": warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[3]: %d videos (%d..%d frames x %d boxes x %d classes) sharded over %d rank(s) by LPT, %d in flight per "
                                    "rank; per video NMS + temporal pass + %d tubelets/class + re-scoring; one ragged all-gather of all results "
                                    "per pass (a step = one pass over all videos)" % (V, min(frames), max(frames), B, C, world, nstreams, T),
                        "videos": V, "frames": frames, "boxes": B, "classes": C, "shards": owned, "parallelism": "video-sharded x%d" % world},
-            "exchange": xinfo, "protocol_dicts": protos,
+            "exchange": xinfo, "protocol_dicts": protos, "oracle_check": oracle_check,
+            "ms_per_video": dt / steps / V * 1e3,
+            "lpt_loads_world8_boxes": loads8,
+            "lpt_imbalance_world8": max(loads8) / (sum(loads8) / 8.0),
             "per_rank": {"seconds": by_rank, "boxes": [sum(frames[v] for v in o) * B for o in owned],
-                         "hbm_frac_algorithmic": [sum(frames[v] for v in o) * B * args.steps / max(t, 1e-9) * bpb / HBM_PEAK for o, t in zip(owned, by_rank)]},
-            "roofline": {"bound": "hbm", "kernel": "whole path", "achieved": total_boxes * args.steps / dt * bpb / 1e9, "peak": world * HBM_PEAK / 1e9,
-                         "unit": "GB/s", "frac": total_boxes * args.steps / dt * bpb / (world * HBM_PEAK), "traffic": None,
+                         "hbm_frac_algorithmic": [sum(frames[v] for v in o) * B * steps / max(t, 1e-9) * bpb / HBM_PEAK for o, t in zip(owned, by_rank)]},
+            "roofline": {"bound": "hbm", "kernel": "whole path", "achieved": total_boxes * steps / dt * bpb / 1e9, "peak": world * HBM_PEAK / 1e9,
+                         "unit": "GB/s", "frac": total_boxes * steps / dt * bpb / (world * HBM_PEAK), "traffic": None,
                          "algorithmic_bytes_per_box": bpb},
             "cpu_baseline": None,
         }
+    for cx in ctxs:
+        cx.close()
+    del vids, ctxs, res, gathered
+    torch.cuda.empty_cache()
+    return result
+
+
+def run_sharded(args):
+    """`python bench.py --videos N` (and `torchrun --nproc-per-node 8 bench.py --gpus 8 --videos 64`): BASELINE configs[3]"""
+    import torch
+    import torch.distributed as dist
+    from vdetlib_amd import dist as vdist
+    world, rank, local = vdist.env_world()
+    one_gpu = os.environ.get("VDET_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local = 0
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    force_x = args.force_exchange
+    vdist.init(backend=("gloo" if one_gpu else "nccl") if (world > 1 or force_x) else None, device=dev, force=force_x)
+    result = sharded_core(args, torch, dist, vdist, dev, local, world, rank, args.videos, args.steps, args.warmup, force_x, one_gpu,
+                          check_oracle=args.check_oracle)
     if world > 1 or force_x:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result))
+
+
+def dropin_latency_leg(reps_small=200):
+    """The boundary T-CNN actually calls: seconds per CALL of the three `utils.cython_nms` entry points through the python
+    drop-in module (numpy in, python list out), beside the reference's own Cython module on one core of the build container
+    (oracle/reference_ratio.json).  Calls of <= 1 024 rows are ONE launch (csrc/fused_kernels.hpp)."""
+    import numpy as np
+    import synth
+    from vdetlib.utils import cython_nms
+
+    def per_call(fn, reps):
+        for _ in range(3):
+            fn()
+        t = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        return (time.perf_counter() - t) / reps * 1e3
+
+    out = {"unit": "ms per call (python drop-in module, host numpy in -> python list out)",
+           "reference_ms": {"nms_300": 1.0, "nms_1000": 4.8, "nms_2000": "13-15", "nms_10000": "107-162", "vid_nms_9000x30f": "~117 (3.5 s / 30 classes)",
+                            "where": "BASELINE.md section 2: the reference's Cython module, one core of the build container"}}
+    for n in (100, 300, 1000, 2000, 10000):
+        d = synth.dets5(n, n)
+        out["nms_%d" % n] = per_call(lambda: cython_nms.nms(d, 0.3), reps_small if n <= 1000 else 20)
+    d6 = synth.dets6(77, 9000, 30)
+    out["vid_nms_9000x30f"] = per_call(lambda: cython_nms.vid_nms(d6, 0.3), 20)
+    for m in (300, 10000):
+        dd = synth.dets6(78 + m, m, 1)
+        tr = np.hstack([[1.0], dd[m // 2, 1:5] + 2.0]).astype(np.float32).reshape(1, 5)
+        out["track_det_nms_%d" % m] = per_call(lambda: cython_nms.track_det_nms(tr, dd, 0.3), reps_small if m <= 1000 else 20)
+    return out
+
+
+def c1_dict_api_leg():
+    """BASELINE configs[0] end to end through the reference's IMPORT NAMES (`vdetlib.*`, served by the build): the driver of
+    tests/c1_flow.py -- the one the reference itself was run with (tests/golden/make_golden.py --c1-only) -- seconds per
+    function beside the reference's on the same inputs, outputs compared with what the reference returned."""
+    import gzip
+    import c1_flow
+    from vdetlib.vdet import video_det as V, image_det as I, track as K, tubelet_cls as T
+    from vdetlib.utils import protocol as P, common as Cm
+    mods = dict(V=V, I=I, K=K, T=T, P=P, Cm=Cm)
+    inp = c1_flow.inputs()
+    c1_flow.run(mods, inp, classes=[1, 2])           # warm-up (contexts, scratch)
+    best, got = None, None
+    for _ in range(2):
+        sec, got = c1_flow.run(mods, inp)
+        best = sec if best is None else {k: min(best[k], sec[k]) for k in sec}
+    res = {"seconds": best, "shape": "%d frames x %d proposals x %d classes, %d tracks/class" % (c1_flow.F, c1_flow.B, c1_flow.C, c1_flow.MAX_TRACKS)}
+    gp = os.path.join(ROOT, "tests", "golden", "c1_flow_golden.json.gz")
+    if os.path.isfile(gp):
+        with gzip.open(gp, "rt") as f:
+            want = json.load(f)
+        bad = c1_flow.compare(got, want, tol=1e-5)
+        res["matches_reference_outputs"] = bad == []
+        if bad:
+            res["mismatching"] = bad
+    rp = os.path.join(ROOT, "oracle", "reference_c1.json")
+    if os.path.isfile(rp):
+        ref = json.load(open(rp))
+        res["reference_seconds"] = ref.get("seconds")
+        res["reference_host"] = ref.get("host")
+        if ref.get("seconds"):
+            res["speedup_vs_reference"] = {k: ref["seconds"][k] / max(best.get(k, 0.0), 1e-9) for k in ref["seconds"] if k in best}
+    return res
+
 
 def vid_shape_leg(torch, ops, _lib, dev, taps, V=64, B=300, C=30, T=4):
     """64 VID-shaped synthetic videos (400-600 frames, 200-300 proposals per frame padded to 300 with far-away boxes and
@@ -361,8 +471,10 @@ def main():
     ap.add_argument("--no-rescore", action="store_true", help="(ablation) tubelets without the spatial / temporal re-scoring")
     ap.add_argument("--videos", type=int, default=0, help="configs[3]: this many videos sharded over the ranks (LPT), one ragged exchange per pass; "
                     "0 (default): the headline step, one video per rank and step")
-    ap.add_argument("--no-latency-leg", action="store_true", help="skip the single-video run with the library's latency options (profiling: that leg "
-                    "overlaps kernels of two streams, which inflates their traced durations)")
+    ap.add_argument("--check-oracle", action="store_true", help="--videos: check one gathered video against the CPU oracle on rank 0")
+    ap.add_argument("--no-sharded-leg", action="store_true", help="skip the default line's configs[3] leg (64 videos sharded, one exchange)")
+    ap.add_argument("--sharded-videos", type=int, default=64, help="videos of the default line's configs[3] leg")
+    ap.add_argument("--profile", action="store_true", help="headline step + per-kernel timing only (rocprofv3 runs): no caveat legs")
     ap.add_argument("--no-coherent", action="store_true", help="skip the coherent-video leg (reported next to value, never part of it)")
     ap.add_argument("--no-upload", action="store_true", help="skip the PCIe-fed pipeline leg (reported next to value, never part of it)")
     ap.add_argument("--force-exchange", action="store_true",
@@ -371,6 +483,8 @@ def main():
     args = ap.parse_args()
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
         args.no_cpu = True       # the CPU baseline / mAP-parity / PCIe legs are reported at N = 1 only
+    if args.profile:
+        args.no_cpu = args.no_coherent = args.no_upload = True
     if args.videos > 0:          # BASELINE configs[3]: many videos sharded over the ranks
         return run_sharded(args)
 
@@ -827,43 +941,8 @@ def main():
         torch.cuda.synchronize()
         single_video_ms = (time.perf_counter() - t6) / n1 * 1e3
         ctx.sync()
-        # how the per-(frame, class) lists of that last step were built (csrc/bucket_kernels.hpp: cut into score-ordered
-        # buckets; lists the bucket kernel handed to the LSD sort: crowded buckets / irregular frames)
-        lists = {"bucketed": ctx.query(10) == 1, "lsd_fallback_lists": ctx.query(11), "lists": F * C}
-        # the same, on a context created with the library's latency options (graph batches pipelined over two streams, memo
-        # warm-up next to the NMS walk): slower with several videos in flight, faster alone -- not the default
-        single_video_latency_ms = None
-        try:
-            if args.no_latency_leg:
-                raise RuntimeError("skipped (--no-latency-leg)")
-            saved = {k: os.environ.get(k) for k in ("VDET_GRAPH_PIPE", "VDET_AUX_STREAM")}
-            os.environ["VDET_GRAPH_PIPE"] = "1"; os.environ["VDET_AUX_STREAM"] = "1"
-            try:
-                lat_ctx = _lib.Context(local)
-            finally:
-                for k, v in saved.items():
-                    if v is None:
-                        os.environ.pop(k, None)
-                    else:
-                        os.environ[k] = v
-            lat_ctx.set_cache(True); lat_ctx.set_async(not args.sync_build)
-            keep0 = ctxs[0]
-            ctxs[0] = lat_ctx
-            for _ in range(3):
-                step_no[0] = 0
-                step(exchange=False)
-            torch.cuda.synchronize()
-            t7 = time.perf_counter()
-            for _ in range(n1):
-                step_no[0] = 0
-                step(exchange=False)
-            torch.cuda.synchronize()
-            single_video_latency_ms = (time.perf_counter() - t7) / n1 * 1e3
-            lat_ctx.sync()
-            ctxs[0] = keep0
-            lat_ctx.close()
-        except Exception as e:      # (never fails the line: a caveat field)
-            single_video_latency_ms = {"error": str(e)[:200]}
+        # how many of that last step's (frame, class) columns the equalised counting sort handed to the LSD kernel
+        lists = {"lsd_fallback_lists": ctx.query(9), "lists": F * C}
         value_other = None
         if not args.no_cpu:
             # the other synthetic score distribution (another radix-digit / sub-bin pattern for the sort): same step
@@ -987,6 +1066,78 @@ def main():
                 hbm_total = json.load(open(pj)).get("_per_video", None)
             except Exception:
                 hbm_total = None
+        # ---- the boundary T-CNN calls: per-call latency of the drop-in module, and BASELINE configs[0] end to end through the
+        # reference's import names, beside the reference's own seconds on the same inputs.  Never part of `value`.
+        dropin, c1_dict = None, None
+        if not args.no_cpu and world == 1:
+            try:
+                dropin = dropin_latency_leg()
+            except Exception as e:
+                dropin = {"error": repr(e)[:300]}
+            try:
+                c1_dict = c1_dict_api_leg()
+            except Exception as e:
+                c1_dict = {"error": repr(e)[:300]}
+        # ---- one full-size video from BASELINE.md section 3's HOST generator (RandomState(1000 * 2 + 0), tie-free scores per
+        # (frame, class): the reference's own visiting order): the same step, timed one video at a time, its NMS lists of two
+        # frames against the oracle.  Never part of `value`.
+        ref_inputs = None
+        if not args.no_cpu and world == 1:
+            try:
+                rb, rsc = synth_video_reference_stream(torch, 2000, F, B, C, dev)
+                keep_v = vids[0]
+                vids[0] = (rb, rsc)
+                for _ in range(2):
+                    step_no[0] = 0
+                    o_ = step(exchange=False)
+                torch.cuda.synchronize()
+                tr0 = time.perf_counter()
+                for _ in range(4):
+                    step_no[0] = 0
+                    o_ = step(exchange=False)
+                torch.cuda.synchronize()
+                rms = (time.perf_counter() - tr0) / 4 * 1e3
+                ctx.sync()
+                from oracle import oracle
+                fr = [0, F - 1]
+                widx, wcnt = oracle.nms_volume(rb[fr].cpu().numpy(), rsc[fr].contiguous().cpu().numpy(), args.thresh, cap=args.cap,
+                                               threads=len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 1)
+                gi, gc = o_[0][fr].cpu().numpy(), o_[1][fr].cpu().numpy()
+                live = np.arange(gi.shape[2])[None, None, :] < gc[:, :, None]
+                ref_inputs = {"single_video_ms": rms, "generator": "tests/synth.video(2000, %d, %d, %d) == np.random.RandomState(1000 * 2 + 0): integer "
+                                                                   "boxes, scores (rank + 0.5) / B tie-free per (frame, class)" % (F, B, C),
+                              "oracle_nms_lists": len(fr) * C, "oracle_nms_ok": bool(np.array_equal(gc, wcnt) and np.array_equal(np.where(live, gi, -1), widx))}
+                vids[0] = keep_v
+                del rb, rsc, o_
+            except Exception as e:
+                ref_inputs = {"error": repr(e)[:300]}
+        # ---- BASELINE configs[3] at its written size on the GPU(s) at hand: 64 videos of c2 shape (0.75-1.25 x 300 frames) sharded by
+        # LPT, `--streams` in flight, ONE ragged exchange per pass over RCCL (a world of one here; 8 ranks: the same code under
+        # torchrun), a gathered video turned into protocol dicts and checked against the oracle.  Never part of `value`.
+        sharded = None
+        if not args.no_cpu and not args.no_sharded_leg and world == 1 and args.sharded_videos > 0:
+            try:
+                for cx in ctxs[1:]:
+                    cx.close()
+                vids[:] = []
+                last_out[:] = [None] * nstreams
+                del boxes, scores, out
+                torch.cuda.empty_cache()
+                made_pg = False
+                if not dist.is_initialized():
+                    vdist.init(backend="nccl", device=dev, force=True)
+                    made_pg = True
+                sharded = sharded_core(args, torch, dist, vdist, dev, local, 1, 0, args.sharded_videos, 2, 2, True, False, check_oracle=True)
+                if sharded is not None:
+                    sharded = {k: sharded[k] for k in ("value", "ms_per_step", "ms_per_video", "steps", "config", "exchange", "protocol_dicts",
+                                                       "oracle_check", "lpt_loads_world8_boxes", "lpt_imbalance_world8", "roofline")}
+                    sharded["config"] = {k: v for k, v in sharded["config"].items() if k not in ("frames", "shards")}
+                    sharded["how_to_run_on_8_gpus"] = "torchrun --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 bench.py --gpus 8 --videos 64"
+                if made_pg:
+                    dist.barrier()
+                    dist.destroy_process_group()
+            except Exception as e:
+                sharded = {"error": repr(e)[:300]}
 
         result = {
             "metric": METRIC,
@@ -1014,13 +1165,16 @@ def main():
                 "hbm_frac_algorithmic": [F * B * args.steps / t * (16 * C + 16) / HBM_PEAK for t in by_rank],
                 "note": "each rank's own wall time for the K timed steps (its video per step + the exchange); value uses the MAX"},
             "single_video_ms": single_video_ms,          # one video at a time (no videos in flight): the latency of one step
-            "single_video_latency_mode_ms": single_video_latency_ms,   # ... with VDET_GRAPH_PIPE=1 VDET_AUX_STREAM=1 (not the default)
             "value_other_scores": value_other,           # the same step on the other synthetic score distribution
             "value_coherent": value_coherent,            # ... on a coherent video (proposals persist from frame to frame)
             "hbm_traffic_per_video": hbm_total,          # sum of the PMC table (profiles/pmc_traffic.json), all kernels of one step
             "vid_shape": vid_shape,
             "lists": lists,
             "c1_reference_flow": c1_flow,
+            "dropin_latency": dropin,                    # per-call latency of utils.cython_nms (the boundary T-CNN calls)
+            "c1_dict_api": c1_dict,                      # configs[0] end to end through `vdetlib.*` beside the reference's seconds
+            "value_reference_inputs": ref_inputs,        # the step on BASELINE.md section 3's host-generated, tie-free video
+            "sharded64": sharded,                        # configs[3] at its written size (one exchange per pass, oracle-checked)
             "timed_check": timed_check,
             "inputs": "HBM-resident (the PCIe-fed rate is upload_pipeline.boxes_per_s, never `value`)",
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_allcores": cpu_all, "map_parity": map_par, "pcie": pcie,

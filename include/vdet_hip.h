@@ -25,6 +25,26 @@
  *     default UNSTABLE sort): descending score, ties by DESCENDING original index
  *     (= argsort(kind='stable')[::-1]); -0.0 == +0.0; NaN scores sort first.  A caller-supplied
  *     `order` reproduces any other tie order exactly.
+ *
+ * Limits (the reference has none of them: its lists and loops are python objects; every limit is an error code, never a
+ * crash, and nothing is written out of bounds):
+ *   what                                   limit                      beyond it
+ *   boxes per frame, every entry point     B <= 32767                 VDET_EINVAL (u16 box indices, bit 15 = zero-union tag)
+ *   boxes per frame, d_* volume calls      B <= ~18000                VDET_EINVAL (a (frame, class) argsort lives in the CU's
+ *                                                                     160 KiB LDS: 6 B / box + tables); the h_* calls fall
+ *                                                                     back to a global bitonic sort up to 32767
+ *   regular-frame fast kernels             B <= 17408                 same results through the general kernels (slower)
+ *   rows of a volume                       F*C, F*B < 2^31 - 16       VDET_EINVAL
+ *   rows of an h_* call                    n < 2^31, <= 32767 / frame VDET_EINVAL
+ *   edges of one suppression graph         < 2^32                     VDET_ENOMEM
+ *   survivors per (frame, class)           cap (caller's choice)      VDET_ECAP latched, count still written
+ *   vdet_det_nms_volume top-k              1 <= topk <= 128           VDET_EINVAL
+ *   temporal window / taps                 odd, <= 31                 VDET_EINVAL (the one-pass volume kernel: 3 or 5, other
+ *                                                                     windows run the separate kernels)
+ *   frames per video, vdet_video_batch     none                       videos of more than 1536 frames re-score their tubelet
+ *                                                                     series one thread per series (slower, same results)
+ *   single-launch h_* calls                n <= 1024 rows, t <= 256   larger inputs take the general kernel chain (same results)
+ *   link table up front                    B <= 1024                  larger frames scan link steps on demand (same results)
  */
 #ifndef VDET_HIP_H
 #define VDET_HIP_H
@@ -100,7 +120,18 @@ int vdet_set_async(vdet_ctx *ctx, int enable);
  * what = 8 -> number of host waits (hipStreamSynchronize) this context has made so far: the asynchronous video
  * step (vdet_set_async) adds none between the entry and the return of the volume entry points;
  * what = 9 -> (frame, class) columns of the last volume sort that the equalised counting sort handed to the LSD
- * radix kernel (tied / quantised / thresholded columns; synchronises the stream), -1 if that sort did not use it. */
+ * radix kernel (tied / quantised / thresholded columns; synchronises the stream), -1 if that sort did not use it.
+ *
+ * Environment switches, read once by vdet_create (diagnostics: each FORCES a fallback path the library takes anyway on some
+ * inputs or devices, with identical results; none selects a tuning variant):
+ *   VDET_FORCE_GENERAL=1  the all-pairs predicate kernel + one-survivor walk on every frame (what irregular frames take)
+ *   VDET_NO_INDEX=1       no x-sorted proposal index (what frames too large for it take)
+ *   VDET_NO_LAZY=1        eager track_det_nms of every crossed list (what irregular frames take)
+ *   VDET_NO_FUSED=1       h_* calls of <= 1024 rows through the general kernel chain (what larger inputs take)
+ *   VDET_BINSORT=0        the LSD radix sort for every column (what tied / thresholded columns take)
+ *   VDET_SMALL_LISTS=0    frames of <= 384 boxes through the large-list sort and walk
+ *   VDET_ATOMIC_RANK=0 / VDET_WAVE_TRANSPOSE=0   the variants selected when the start-up hardware probes fail
+ *   VDET_BITS_BUDGET_MB=n bytes of bit-matrix scratch per graph-build batch (default 1024) */
 int vdet_query(vdet_ctx *ctx, int what);
 /* Per-stage HIP-event timing: 0 off (default), 1 on (events of the most recent call), 2 on and
  * accumulating over calls until vdet_last_timing_ms reads them. */
@@ -216,7 +247,7 @@ int vdet_conv1d_f32(vdet_ctx *ctx, const float *h_in, int Cin, int L, const floa
  *   d_keep_idx [F,C,cap] int32: kept box indices (0..B-1), descending score; entries >= count
  *                               are left untouched.   d_keep_cnt [F,C] int32.
  *   A (frame,class) with more than cap survivors latches VDET_ECAP (its count is still written).
- * Limits: B <= ~18000 (the per-problem argsort lives in the CU's 160 KiB LDS).
+ * Limits: see the table at the top of this file (B <= ~18000).
  */
 int vdet_nms_volume(vdet_ctx *ctx, const float *d_boxes, const float *d_scores, int layout,
                     int64_t F, int64_t B, int64_t C, double thresh, int use_score_thresh,

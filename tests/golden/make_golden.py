@@ -460,8 +460,30 @@ def g16_mat(R):
     print('  mat: frames %s, det_info %s %s' % (sorted(ftd), info.shape, info.dtype))
 
 
+def g17_c1_flow(R):
+    """G17 (round 5): BASELINE configs[0] end to end through the reference's dict API (tests/c1_flow.py: the same driver
+    bench.py / tests/test_c1_flow_gpu.py run on the build's `vdetlib.*` modules).  Outputs -> tests/golden/c1_flow_golden.json.gz,
+    the reference's seconds per function on one core of THIS container -> oracle/reference_c1.json."""
+    import c1_flow
+    inp = c1_flow.inputs()
+    best = None
+    for _ in range(2):                               # best of two passes (shared vCPUs)
+        sec, out = c1_flow.run(R, inp)
+        best = sec if best is None else {k: min(best[k], sec[k]) for k in sec}
+    with gzip.open(os.path.join(HERE, 'c1_flow_golden.json.gz'), 'wt') as f:
+        json.dump(to_py(out), f, separators=(',', ':'), sort_keys=True)
+    host = "build container: %d vCPU, %s" % (os.cpu_count(), open('/proc/cpuinfo').read().split('model name')[1].split('\n')[0].strip(': \t'))
+    with open(os.path.join(os.path.dirname(os.path.dirname(HERE)), 'oracle', 'reference_c1.json'), 'w') as f:
+        json.dump(dict(what="the reference's own modules (py3 copy, Cython nms) on tests/c1_flow.py: %d frames x %d proposals x %d classes, "
+                            "seconds per function, best of 2, one core" % (c1_flow.F, c1_flow.B, c1_flow.C), host=host, seconds=best), f, indent=1)
+    print('  c1 flow:', {k: round(v, 3) for k, v in best.items()})
+
+
 def main():
     R = load_reference()
+    if '--c1-only' in sys.argv:
+        g17_c1_flow(R)
+        return
     if '--mat-only' in sys.argv:
         g16_mat(R)
         return
@@ -486,6 +508,7 @@ def main():
     g14_link(R)
     g15_exotic(R)
     g16_mat(R)
+    g17_c1_flow(R)
     for fn in sorted(os.listdir(HERE)):
         print('%8d  %s' % (os.path.getsize(os.path.join(HERE, fn)), fn))
 

@@ -94,8 +94,7 @@ def test_volume_pass_stops_at_video_borders(C, window):
 
 
 def test_batch_options_and_limits():
-    """no tracks / no NMS output / no re-scoring; one video == the single-video call; a video too long for the batched
-    re-scoring (> 1 536 frames) is refused, offsets are validated"""
+    """no tracks / no NMS output / no re-scoring; one video == the single-video call; offsets are validated"""
     frames = [4, 6]
     vids, off, boxes, scores = _videos(frames, 90, 3, seed=40)
     out = ops.video_batch(boxes, scores, off, max_tracks=0, nms=True, rescore=False, nms_thres=0.3)
@@ -113,7 +112,37 @@ def test_batch_options_and_limits():
         ops.video_batch(boxes, scores, [0, 4, 9], **KW)
     with pytest.raises(ValueError):
         ops.video_batch(boxes, scores, [0, 4, 4, 10], **KW)
-    long_b = torch.zeros((1600, 8, 4), device="cuda") + torch.tensor([0.0, 0.0, 9.0, 9.0], device="cuda")
-    long_s = torch.rand((1600, 8, 2), device="cuda")
-    with pytest.raises(ValueError):
-        ops.video_batch(long_b, long_s, [0, 1600], **KW)
+
+
+def test_batch_with_a_video_longer_than_the_wave_series_stage():
+    """a 2 500-frame video (VID videos run past 2 000 frames; the reference has no length limit, vdet/tubelet_cls.py:284-303,
+    :386-414) between two short ones: its tubelet series do not fit the LDS stage of the one-wave-per-series kernel and
+    take the one-thread-per-series kernel -- same results as the single-video entry points (whose own long-video path is
+    the same serial kernel) and, for the short videos, as ever"""
+    frames = [9, 2500, 14]
+    B, C = 40, 3
+    vids, off, boxes, scores = _videos(frames, B, C, seed=7100)
+    # gaps in the long video's tubelet scores: a stretch of frames whose proposals do not overlap the tracked boxes enough
+    out = ops.video_batch(boxes, scores, off, overlap_thres=0.6, window=3, **KW)
+    one = _lib.Context(torch.cuda.current_device())
+    one.set_cache(True)
+    for v, (b, s) in enumerate(vids):
+        tb, ts = torch.from_numpy(b).cuda(), torch.from_numpy(s).cuda()
+        ki, kc, tr, an, nt = ops.nms_track_volume(tb, ts, ctx=one, **KW)
+        det, pool, bx = ops.rescore_tracks(tr, nt, tb, ts, overlap_thres=0.6, window=3, ctx=one)
+        assert torch.equal(out["ntracks"][v], nt), v
+        for c in range(C):
+            n = int(nt[c])
+            assert _eq(out["tracks"][v][c, :n], tr[c, :n]), (v, c)
+            assert _eq(out["det"][v][c, :n], det[c, :n]) and _eq(out["pooled"][v][c, :n], pool[c, :n]), (v, c)
+            assert _eq(out["tboxes"][v][c, :n], bx[c, :n]), (v, c)
+    # the long video's first class against the reference's own series functions restated by the oracle (score completion +
+    # temporal max-pool of every tubelet): do_score_completion / score_proto_temporal_maxpool
+    v = 1
+    det1 = out["det"][v][0].cpu().numpy()
+    pool1 = out["pooled"][v][0].cpu().numpy()
+    for t in range(int(out["ntracks"][v, 0])):
+        has = ~np.isnan(det1[t])
+        x = np.concatenate([[-1e5], det1[t][has], [-1e5]])                   # vdet/tubelet_cls.py:399-412, window 3
+        assert has.sum() > 0 and np.array_equal(pool1[t][has], np.maximum(np.maximum(x[:-2], x[1:-1]), x[2:])), t
+    one.close()

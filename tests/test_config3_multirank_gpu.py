@@ -197,3 +197,27 @@ def test_sharded_videos_two_ranks_dry_run():
     assert r["exchange"]["world"] == 2 and r["exchange"]["all_videos_present"] is True
     assert r["protocol_dicts"]["from_rank"] == 1 and r["protocol_dicts"]["tracks"] > 0
     assert len(r["per_rank"]["seconds"]) == 2 and r["scaling"] == "strong"
+
+
+def test_sharded_16_videos_c2_quarter_oracle_checked():
+    """configs[3] beyond the miniature: 16 videos of c2/4 size (56..94 frames x 10 000 boxes x 200 classes, 0.6 GB of scores each)
+    through `bench.py --videos 16` in a world of one over RCCL -- LPT shard, 4 videos in flight, ONE ragged exchange per pass,
+    one gathered video turned into protocol dicts and checked against the CPU oracle (kept lists of 4 frames x 200 classes,
+    all tubelets of one class incl. re-scored boxes and pooled scores).  The default bench line runs the same at 64 videos of
+    full c2 size (`sharded64`)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29557", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "2",
+           "--videos", "16", "--frames", "75", "--no-cpu", "--force-exchange", "--check-oracle"]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["config"]["videos"] == 16 and r["config"]["boxes"] == 10000 and r["config"]["classes"] == 200
+    x = r["exchange"]
+    assert x["backend"] == "nccl" and x["all_videos_present"] is True and x["videos_gathered"] == 16
+    oc = r["oracle_check"]
+    assert oc["nms_ok"] is True and oc["tubelets_ok"] is True and oc["nms_lists"] == len(oc["nms_frames"]) * 200 and oc["tubelets"] > 0
+    assert len(r["lpt_loads_world8_boxes"]) == 8 and 1.0 <= r["lpt_imbalance_world8"] < 1.2
+    assert r["protocol_dicts"]["tracks"] > 0 and r["protocol_dicts"]["detections"] > 0
