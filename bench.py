@@ -130,20 +130,27 @@ def sharded_core(args, torch, dist, vdist, dev, local, world, rank, V, steps, wa
     streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
     for cx in ctxs:
         cx.set_cache(True); cx.set_async(True)
+    # the large per-video outputs (both temporal volumes, the kept lists) live in ONE set of buffers per stream, sized for the
+    # rank's longest video: videos of different lengths would otherwise churn the caching allocator with multi-GB blocks of
+    # ever new sizes next to 157 GB of resident inputs
+    fmax = max([frames[v] for v in mine] or [1])
+    arena = [(torch.empty(fmax * B * C, dtype=torch.float32, device=dev), torch.empty(fmax * B * C, dtype=torch.float32, device=dev),
+              torch.empty(fmax * C * args.cap, dtype=torch.int32, device=dev)) for _ in range(nstreams)]
 
     def process(v, k):
         vb, vs = vids[v]
         cx = ctxs[k]
         with torch.cuda.stream(streams[k]):
             cx.invalidate()
-            pooled, conv = ops.volume_pass(vs, args.window, TAPS, ctx=cx)
+            pooled, conv = ops.volume_pass(vs, args.window, TAPS, ctx=cx, out=arena[k][:2])
             ki, kc, tr, an, nt = ops.nms_track_volume(vb, vs, nms_thres=args.thresh, thres=args.track_thres, max_tracks=T,
-                                                      link_thres=args.link_thres, cap=args.cap, sync=False, ctx=cx, pad=False)
+                                                      link_thres=args.link_thres, cap=args.cap, sync=False, ctx=cx, pad=False,
+                                                      keep_out=arena[k][2])
             det, tp, tb = ops.rescore_tracks(tr, nt, vb, vs, overlap_thres=args.pool_thres, window=args.window, sync=False, ctx=cx)
             Fv = frames[v]
             # the video's result records: tubelet rows (x1 y1 x2 y2 link-score | re-scored box | pooled score) and the top-k kept
             tub = torch.cat([tr.reshape(C * T * Fv, 5), tb.reshape(C * T * Fv, 4), tp.to(torch.float32).reshape(C * T * Fv, 1)], 1)
-            kept = ki[:, :, :TOPK].reshape(Fv * C, TOPK)
+            kept = ki[:, :, :TOPK].reshape(Fv * C, TOPK).clone()      # (a COPY: the slice of the stream's reused buffer would be a view)
             return {"v": v, "tub": tub, "anchors": an.reshape(C * T, 3), "ntracks": nt, "kept": kept, "kcnt": kc.reshape(Fv * C)}
 
     exch_ms = []
@@ -276,7 +283,7 @@ def sharded_core(args, torch, dist, vdist, dev, local, world, rank, V, steps, wa
         }
     for cx in ctxs:
         cx.close()
-    del vids, ctxs, res, gathered
+    del vids, ctxs, res, gathered, arena
     torch.cuda.empty_cache()
     return result
 
@@ -306,7 +313,7 @@ def run_sharded(args):
 def dropin_latency_leg(reps_small=200):
     """The boundary T-CNN actually calls: seconds per CALL of the three `utils.cython_nms` entry points through the python
     drop-in module (numpy in, python list out), beside the reference's own Cython module on one core of the build container
-    (oracle/reference_ratio.json).  Calls of <= 1 024 rows are ONE launch (csrc/fused_kernels.hpp)."""
+    (oracle/reference_ratio.json).  Calls of <= 640 rows are ONE launch (csrc/fused_kernels.hpp)."""
     import numpy as np
     import synth
     from vdetlib.utils import cython_nms
@@ -1108,7 +1115,7 @@ def main():
                                                                    "boxes, scores (rank + 0.5) / B tie-free per (frame, class)" % (F, B, C),
                               "oracle_nms_lists": len(fr) * C, "oracle_nms_ok": bool(np.array_equal(gc, wcnt) and np.array_equal(np.where(live, gi, -1), widx))}
                 vids[0] = keep_v
-                del rb, rsc, o_
+                del rb, rsc, o_, keep_v
             except Exception as e:
                 ref_inputs = {"error": repr(e)[:300]}
         # ---- BASELINE configs[3] at its written size on the GPU(s) at hand: 64 videos of c2 shape (0.75-1.25 x 300 frames) sharded by

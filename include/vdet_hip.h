@@ -43,7 +43,7 @@
  *                                                                     windows run the separate kernels)
  *   frames per video, vdet_video_batch     none                       videos of more than 1536 frames re-score their tubelet
  *                                                                     series one thread per series (slower, same results)
- *   single-launch h_* calls                n <= 1024 rows, t <= 256   larger inputs take the general kernel chain (same results)
+ *   single-launch h_* calls                n <= 640 rows, t <= 256    larger inputs take the general kernel chain (same results)
  *   link table up front                    B <= 1024                  larger frames scan link steps on demand (same results)
  */
 #ifndef VDET_HIP_H
@@ -127,7 +127,7 @@ int vdet_set_async(vdet_ctx *ctx, int enable);
  *   VDET_FORCE_GENERAL=1  the all-pairs predicate kernel + one-survivor walk on every frame (what irregular frames take)
  *   VDET_NO_INDEX=1       no x-sorted proposal index (what frames too large for it take)
  *   VDET_NO_LAZY=1        eager track_det_nms of every crossed list (what irregular frames take)
- *   VDET_NO_FUSED=1       h_* calls of <= 1024 rows through the general kernel chain (what larger inputs take)
+ *   VDET_NO_FUSED=1       h_* calls of <= 640 rows through the general kernel chain (what larger inputs take)
  *   VDET_BINSORT=0        the LSD radix sort for every column (what tied / thresholded columns take)
  *   VDET_SMALL_LISTS=0    frames of <= 384 boxes through the large-list sort and walk
  *   VDET_ATOMIC_RANK=0 / VDET_WAVE_TRANSPOSE=0   the variants selected when the start-up hardware probes fail

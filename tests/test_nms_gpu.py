@@ -17,7 +17,7 @@ def cnms1():
 
 @pytest.fixture(scope="module", params=["single_launch", "general"])
 def cnms(request):
-    """the drop-in module twice: calls of <= 1 024 rows as ONE launch (csrc/fused_kernels.hpp, the default) and -- on a
+    """the drop-in module twice: calls of <= 640 rows as ONE launch (csrc/fused_kernels.hpp, the default) and -- on a
     context created under VDET_NO_FUSED=1 -- through the general kernel chain that larger inputs take"""
     import os
     from vdetlib_amd.utils import cython_nms

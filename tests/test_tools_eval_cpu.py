@@ -176,3 +176,22 @@ def test_bench_reference_stream_generator_is_synth_video():
     b, s = bench.synth_video_reference_stream(torch, 2000, 3, 57, 5, torch.device("cpu"))
     wb, ws = synth.video(2000, 3, 57, 5)
     assert np.array_equal(b.numpy(), wb) and np.array_equal(s.numpy(), ws)
+
+
+def test_annotation_processor_on_committed_vid_xml(tmp_path):
+    """Four ILSVRC2015-VID style XML files (tests/golden/vid_xml: the dataset's own layout -- folder / filename / source /
+    size / object{trackid, name, bndbox{xmax, xmin, ymax, ymin}, occluded, generated}, one file without objects, tracks
+    that start late and interleave) against ILSVRC2015_val_00007000.expected.annot.
+    PINNING STATUS: the expectation was written by hand from the reference's rules
+    (tools/imagenet_annotation_processor.py:53-118: frame = int(filename) + 1, tracks in order of first appearance, bbox
+    [xmin, ymin, xmax, ymax] as ints, frame_size [height, width], json indent=2), NOT produced by running the reference: its
+    module imports `xmltodict` at the top (:6), which this image does not have, and the rules forbid a stand-in.  The build
+    reads the files in sorted name order (the reference takes glob's order, which is the filesystem's)."""
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'vid_xml')
+    d = os.path.join(src, 'ILSVRC2015_val_00007000')
+    want = json.load(open(os.path.join(src, 'ILSVRC2015_val_00007000.expected.annot')))
+    assert iap.annot_proto_from_dir(d) == want
+    out = tmp_path / 'a' / 'v.annot'
+    assert iap.main([d, str(out)]) == 0
+    assert open(out).read() == open(os.path.join(src, 'ILSVRC2015_val_00007000.expected.annot')).read()      # byte for byte (indent=2)
+    assert [t['id'] for t in want['annotations']] == ['0', '1', '2'] and want['annotations'][1]['track'][0]['frame'] == 2

@@ -429,17 +429,17 @@ def test_link_memo_shares_steps_across_chains(oracle):
     (vdet_query 4 / 5; 6 / 7 for the warm-up) -- with tubelets identical to the oracle's."""
     import torch
     from vdetlib_amd import ops, _lib
-    boxes, scores = synth.coherent_video(77, 30, 1100, 6)
+    boxes, scores = synth.coherent_video(77, 30, 1100, 16)         # 16 classes x 12 tracks = 192 chains over 1 100 persistent proposals
     tb, ts = torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda()
     cx = _lib.Context(torch.cuda.current_device())
-    tr, an, nt = ops.track_volume(tb, ts, thres=0.0, max_tracks=8, ctx=cx)
+    tr, an, nt = ops.track_volume(tb, ts, thres=0.0, max_tracks=12, ctx=cx)
     # steps found in the memo / scanned, by the tracking loop (4, 5) and by the warm-up of the predicted anchors (6, 7);
     # tubelets of predicted anchors are copied from the materialised warm chains, so the loop may have nothing left to do
     hits, misses = cx.query(4) + cx.query(6), cx.query(5) + cx.query(7)
     assert misses > 0
-    assert hits > 0          # 48 chains on coherent proposals do meet
+    assert hits > 0          # 192 chains on 1 100 proposal tracks do meet
     for c in (0, 5):
-        wt, wa, wn = oracle.greedy_track_volume(boxes, scores[:, :, c], 0.3, 0.0, 8, 0.5, 0)
+        wt, wa, wn = oracle.greedy_track_volume(boxes, scores[:, :, c], 0.3, 0.0, 12, 0.5, 0)
         assert int(nt[c]) == wn and np.array_equal(tr[c, :wn].cpu().numpy(), wt[:wn], equal_nan=True)
     cx.close()
 

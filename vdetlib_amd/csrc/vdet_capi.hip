@@ -130,7 +130,7 @@ struct vdet_ctx {
     bool force_general = false;   // VDET_FORCE_GENERAL=1: the general predicate kernel K1 on every frame (the irregular-frame path)
     bool atomic_rank = false;     // LDS returning atomics serve same-address lanes in lane order (probed; VDET_ATOMIC_RANK=0: ballot match)
     bool small_lists = true;      // VDET_SMALL_LISTS=0: frames of <= 384 boxes through the large-list sort and walk too (small_kernels.hpp)
-    bool no_fused = false;        // VDET_NO_FUSED=1: the host-buffer calls of <= 1 024 rows through the general kernel chain too (the path of larger inputs)
+    bool no_fused = false;        // VDET_NO_FUSED=1: the host-buffer calls of <= 640 rows through the general kernel chain too (the path of larger inputs)
     bool binsort = true;          // VDET_BINSORT=0: the LSD radix kernel (the fallback of tied / thresholded columns) for every column
     const std::vector<GroupDesc> *host_groups = nullptr;   // group table of the call in flight (mode 2)
     bool sym_built = false;       // the last graph build ran K0 + frame index + K1s (regular-frame fast path)
@@ -848,8 +848,16 @@ int fused_call(vdet_ctx *c, const float *h_rows, int64_t n, int64_t ld, int ncol
             if (pi) (void)hipHostFree(pi);
             return fail(c, VDET_ENOMEM, "host-mapped staging memory for the single-launch calls");
         }
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(fused_nms_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->max_lds));
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(fused_nms_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->max_lds));
+        for (const void *fn : {reinterpret_cast<const void *>(fused_nms_kernel<256>), reinterpret_cast<const void *>(fused_nms_kernel<1024>)}) {
+            hipFuncAttributes fa;       // (the dynamic limit is what the kernel's static LDS leaves of the CU's 160 KiB)
+            hipError_t e = hipFuncGetAttributes(&fa, fn);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(c->max_lds - (((size_t)fa.sharedSizeBytes + 15) & ~(size_t)15)));
+            if (e != hipSuccess) {
+                (void)hipHostFree(pi); (void)hipHostFree(po);
+                return fail(c, VDET_EHIP, "hipFuncSetAttribute(fused_nms_kernel) failed: %s", hipGetErrorString(e));
+            }
+        }
         c->fused_in = pi; c->fused_out = po;
     }
     float *rows = static_cast<float *>(c->fused_in);

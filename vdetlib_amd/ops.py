@@ -233,13 +233,16 @@ def temporal_maxpool_conv(vol, window, taps, pad_max=-1e5, bias=0.0, pad_conv=0.
     return out_m, out_c
 
 
-def volume_pass(scores, window=3, taps=None, pad_max=-1e5, bias=0.0, pad_conv=0.0, score_thresh=None, ctx=None, frame_off=None):
+def volume_pass(scores, window=3, taps=None, pad_max=-1e5, bias=0.0, pad_conv=0.0, score_thresh=None, ctx=None, frame_off=None,
+                out=None):
     """(``frame_off`` [V+1]: the volume is V videos concatenated along F -- a temporal window stops at its video's ends.)
     ONE read of a score volume [F,B,C]: ``temporal_maxpool(scores, window, pad_max)``, optionally
     ``temporal_conv(scores, taps, bias, pad_conv)`` (len(taps) == window), and -- left inside the context for
     the next ``nms_volume`` / ``track_volume`` / ``nms_track_volume`` call on the SAME scores tensor (cache
     enabled) -- the class-major sort keys of every (frame, class) problem (include/vdet_hip.h: vdet_volume_pass).
-    Returns (pooled, conv or None)."""
+    Returns (pooled, conv or None).  ``out`` = (pooled buffer, conv buffer or None): caller-owned float32 tensors of at
+    least ``scores.numel()`` elements to write into instead of fresh ones (a server keeps one pair per stream; the C-ABI
+    takes caller buffers anyway); the returned tensors are views of them shaped like ``scores``."""
     if window % 2 != 1:
         raise ValueError('Window size must be odd!')
     if scores.dtype != torch.float32:
@@ -254,8 +257,16 @@ def volume_pass(scores, window=3, taps=None, pad_max=-1e5, bias=0.0, pad_conv=0.
     scores = scores.contiguous()
     F, B, C = scores.shape
     ctx = _ctx_for(scores, ctx)
-    out_m = torch.empty_like(scores)
-    out_c = torch.empty_like(scores) if t is not None else None
+    if out is None:
+        out_m = torch.empty_like(scores)
+        out_c = torch.empty_like(scores) if t is not None else None
+    else:
+        def view(buf):
+            if buf.dtype != torch.float32 or not buf.is_contiguous() or buf.numel() < scores.numel() or buf.device != scores.device:
+                raise ValueError("out buffers must be contiguous float32 tensors of >= scores.numel() elements on the scores' device")
+            return buf.view(-1)[:scores.numel()].view(scores.shape)
+        out_m = view(out[0])
+        out_c = view(out[1]) if t is not None else None
     tail = (int(window), float(pad_max), t.ctypes.data if t is not None else None, float(bias), float(pad_conv),
             out_m.data_ptr(), out_c.data_ptr() if out_c is not None else None, 0 if score_thresh is None else 1,
             0.0 if score_thresh is None else float(score_thresh))
@@ -372,11 +383,12 @@ def track_volume(boxes, scores, nms_thres=0.3, thres=0.0, max_tracks=10, link_th
 
 
 def nms_track_volume(boxes, scores, nms_thres=0.3, thres=0.0, max_tracks=10, link_thres=0.5, max_frames=0, cap=None,
-                     sync=True, ctx=None, pad=True):
+                     sync=True, ctx=None, pad=True, keep_out=None):
     """``nms_volume`` (layout 'FBC', no score threshold) and ``track_volume`` of the same video in one
     call: both are greedy walks over the same sorted lists and suppression graph, and on regular
     videos one fused walk serves both (include/vdet_hip.h: vdet_nms_track_volume).  Results are
-    bit-identical to the two separate calls.
+    bit-identical to the two separate calls.  ``keep_out``: a caller-owned contiguous int32 tensor of >= F*C*cap elements
+    to hold keep_idx (the returned keep_idx is a view of it).
     Returns (keep_idx, keep_cnt, tracks, anchors, ntracks)."""
     if boxes.dtype != torch.float32 or scores.dtype != torch.float32:
         raise ValueError("Buffer dtype mismatch, expected 'float32_t'")
@@ -387,7 +399,14 @@ def nms_track_volume(boxes, scores, nms_thres=0.3, thres=0.0, max_tracks=10, lin
         raise ValueError("boxes must be [F,B,4]")
     cap = B if cap is None else int(cap)
     ctx = _ctx_for(boxes, ctx)
-    keep_idx = _keep_buffer((F, C, cap), boxes.device, pad)
+    if keep_out is None:
+        keep_idx = _keep_buffer((F, C, cap), boxes.device, pad)
+    else:
+        if keep_out.dtype != torch.int32 or not keep_out.is_contiguous() or keep_out.numel() < F * C * cap or keep_out.device != boxes.device:
+            raise ValueError("keep_out must be a contiguous int32 tensor of >= F*C*cap elements on the boxes' device")
+        keep_idx = keep_out.view(-1)[:F * C * cap].view(F, C, cap)
+        if pad:
+            keep_idx.fill_(-1)
     keep_cnt = torch.zeros((F, C), dtype=torch.int32, device=boxes.device)
     tracks = torch.full((C, max_tracks, F, 5), float('nan'), dtype=torch.float32, device=boxes.device)
     anchors = torch.zeros((C, max_tracks, 3), dtype=torch.float32, device=boxes.device)
