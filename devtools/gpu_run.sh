@@ -22,7 +22,7 @@ STEP="python $R/bench.py --profile --no-sharded-leg --streams 1"
 n=0
 for what in "$@"; do
   case "$what" in
-    tests)   timeout 2400 python -m pytest tests -m gpu -q -x 2>&1 | tail -40 > $O/${P}_tests.log; tail -5 $O/${P}_tests.log ;;
+    tests)   timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -60 > $O/${P}_tests.log; tail -5 $O/${P}_tests.log ;;
     tests:*) timeout 2400 python -m pytest tests -m gpu -q -k "${what#tests:}" 2>&1 | tail -60 > $O/${P}_tests.log; tail -8 $O/${P}_tests.log ;;
     smoke)   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/${P}_smoke.log 2>&1; tail -2 $O/${P}_smoke.log ;;
     bench)   timeout 1200 python bench.py > $O/${P}_bench.json 2> $O/${P}_bench.err; tail -c 600 $O/${P}_bench.err; head -c 400 $O/${P}_bench.json ;;
