@@ -478,6 +478,9 @@ def main():
     ap.add_argument("--no-rescore", action="store_true", help="(ablation) tubelets without the spatial / temporal re-scoring")
     ap.add_argument("--videos", type=int, default=0, help="configs[3]: this many videos sharded over the ranks (LPT), one ragged exchange per pass; "
                     "0 (default): the headline step, one video per rank and step")
+    ap.add_argument("--inputs", choices=["reference", "device"], default="reference",
+                    help="reference: BASELINE.md section 3's host RandomState(1000 * config + video) stream, tie-free scores (default); "
+                         "device: torch's device generator (rounds 1-4)")
     ap.add_argument("--check-oracle", action="store_true", help="--videos: check one gathered video against the CPU oracle on rank 0")
     ap.add_argument("--no-sharded-leg", action="store_true", help="skip the default line's configs[3] leg (64 videos sharded, one exchange)")
     ap.add_argument("--sharded-videos", type=int, default=64, help="videos of the default line's configs[3] leg")
@@ -522,7 +525,13 @@ def main():
     # (different boxes and scores).  All results of all K steps are complete before the timed region ends
     # (fence() synchronises the device).
     nstreams = max(1, args.streams)
-    vids = [synth_video_cuda(torch, 2000 + 100 * rank + k, F, B, C, dev, args.scores) for k in range(nstreams)]
+    # inputs: BASELINE.md section 3's HOST generator, np.random.RandomState(1000 * config + video) -- integer boxes, scores tie-free
+    # per (frame, class), so every timed list is visited in the reference's own order (its unstable argsort has no ties to
+    # break); `--inputs device`: the fast torch device generator of rounds 1-4 (f32 U(0,1): ~3 tied pairs per 10 000-entry list)
+    if args.inputs == "reference" and args.scores == "rand":
+        vids = [synth_video_reference_stream(torch, 1000 * 2 + 100 * rank + k, F, B, C, dev) for k in range(nstreams)]
+    else:
+        vids = [synth_video_cuda(torch, 2000 + 100 * rank + k, F, B, C, dev, args.scores) for k in range(nstreams)]
     boxes, scores = vids[0]
     ctx = _lib.get_context(local)
     gathered = None
@@ -1085,13 +1094,14 @@ def main():
                 c1_dict = c1_dict_api_leg()
             except Exception as e:
                 c1_dict = {"error": repr(e)[:300]}
-        # ---- one full-size video from BASELINE.md section 3's HOST generator (RandomState(1000 * 2 + 0), tie-free scores per
-        # (frame, class): the reference's own visiting order): the same step, timed one video at a time, its NMS lists of two
-        # frames against the oracle.  Never part of `value`.
+        # ---- the same step on the OTHER input generator (reference host stream <-> torch device generator), one video at a time,
+        # with its NMS lists of two frames against the oracle.  Never part of `value`.
         ref_inputs = None
         if not args.no_cpu and world == 1:
             try:
-                rb, rsc = synth_video_reference_stream(torch, 2000, F, B, C, dev)
+                other_kind = "device" if (args.inputs == "reference" and args.scores == "rand") else "reference"
+                rb, rsc = (synth_video_cuda(torch, 2000, F, B, C, dev, "rand") if other_kind == "device"
+                           else synth_video_reference_stream(torch, 2000, F, B, C, dev))
                 keep_v = vids[0]
                 vids[0] = (rb, rsc)
                 for _ in range(2):
@@ -1111,9 +1121,8 @@ def main():
                                                threads=len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 1)
                 gi, gc = o_[0][fr].cpu().numpy(), o_[1][fr].cpu().numpy()
                 live = np.arange(gi.shape[2])[None, None, :] < gc[:, :, None]
-                ref_inputs = {"single_video_ms": rms, "generator": "tests/synth.video(2000, %d, %d, %d) == np.random.RandomState(1000 * 2 + 0): integer "
-                                                                   "boxes, scores (rank + 0.5) / B tie-free per (frame, class)" % (F, B, C),
-                              "oracle_nms_lists": len(fr) * C, "oracle_nms_ok": bool(np.array_equal(gc, wcnt) and np.array_equal(np.where(live, gi, -1), widx))}
+                ref_inputs = {"inputs": other_kind, "single_video_ms": rms, "lsd_fallback_lists": ctx.query(9), "oracle_nms_lists": len(fr) * C,
+                              "oracle_nms_ok": bool(np.array_equal(gc, wcnt) and np.array_equal(np.where(live, gi, -1), widx))}
                 vids[0] = keep_v
                 del rb, rsc, o_, keep_v
             except Exception as e:
@@ -1180,10 +1189,12 @@ def main():
             "c1_reference_flow": c1_flow,
             "dropin_latency": dropin,                    # per-call latency of utils.cython_nms (the boundary T-CNN calls)
             "c1_dict_api": c1_dict,                      # configs[0] end to end through `vdetlib.*` beside the reference's seconds
-            "value_reference_inputs": ref_inputs,        # the step on BASELINE.md section 3's host-generated, tie-free video
+            "value_other_inputs": ref_inputs,            # the step on the other input generator (device <-> reference host stream)
             "sharded64": sharded,                        # configs[3] at its written size (one exchange per pass, oracle-checked)
             "timed_check": timed_check,
-            "inputs": "HBM-resident (the PCIe-fed rate is upload_pipeline.boxes_per_s, never `value`)",
+            "inputs": ("BASELINE.md section 3 host generator: np.random.RandomState(1000 * 2 + video), integer boxes, scores tie-free per "
+                       "(frame, class)" if (args.inputs == "reference" and args.scores == "rand") else "torch device generator, scores " + args.scores) +
+                      "; HBM-resident when the timed region starts (the PCIe-fed rate is upload_pipeline.boxes_per_s, never `value`)",
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_allcores": cpu_all, "map_parity": map_par, "pcie": pcie,
             "upload_pipeline": upload,
         }
