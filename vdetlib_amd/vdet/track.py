@@ -57,45 +57,54 @@ def _run_tracker(track_method, vid_proto, anchor_frame_id, anchor_bbox, opts):
         return track_method(vid_proto, anchor_frame_id, anchor_bbox, opts)
 
 
-def _greedy_loop(vid_proto, det_info, frame_keys, scores_for_stop, anchor_of, track_method, opts):
-    """Shared loop of :140-186 / :207-252.  det_info: float32 [N,6] rows (frame,x1,y1,x2,y2,score)
-    already in descending score order."""
+def _prune_frame_dets(tracklets, rows_of_frame, alive, det_rows, nms_thres):
+    """What a new track explains goes (reference :170-184 / :236-250): for every box of every new tracklet, the still-alive
+    detections of that box's frame are put through ``track_det_nms`` against the box; whatever it does not return is dead.
+    ``rows_of_frame``: frame id -> row numbers of that frame (ascending = descending score); ``alive`` is updated in place."""
+    for tracklet in tracklets:
+        for box in tracklet:
+            rows = rows_of_frame.get(box['frame'])
+            if rows is None:
+                continue
+            live = rows[alive[rows]]
+            if live.size == 0:
+                continue
+            track_row = np.asarray([[box['frame']] + list(box['bbox'])], dtype=np.float32)
+            survivors = np.asarray(track_det_nms(track_row, det_rows[live], nms_thres), dtype=np.int64)   # positions inside ``live``
+            alive[live] = False
+            alive[live[survivors]] = True
+
+
+def _greedy_loop(vid_proto, det_rows, frame_keys, score_of, anchor_of, track_method, opts):
+    """The loop both entry points share (reference :140-186 / :207-252), on arrays.  ``det_rows``: float32 [N,6] rows
+    (frame, x1,y1,x2,y2, score) already in descending score order.  State = one boolean per row; the scan position only
+    moves forward (a row passed over is never an anchor again, like the reference's cursor); the loop ends when no alive
+    row is left at or after it, when ``opts.max_tracks`` tracklets exist, or at the first anchor scoring below
+    ``opts.thres``."""
     nms_thres = _nms_thres(opts)
-    frame_to_det_ids = defaultdict(list)
-    for i, k in enumerate(frame_keys):
-        frame_to_det_ids[k].append(i)
-    n = len(det_info)
-    keep = [True] * n
-    cur_top_det_id = 0
+    n = len(det_rows)
+    positions = defaultdict(list)
+    for row, key in enumerate(frame_keys):
+        positions[key].append(row)
+    rows_of_frame = {key: np.asarray(rows, dtype=np.int64) for key, rows in positions.items()}
+    alive = np.ones(n, dtype=bool)
+    scan = 0
     tracks = []
-    while np.any(keep) and len(tracks) < opts.max_tracks:
-        while cur_top_det_id < n and not keep[cur_top_det_id]:
-            cur_top_det_id += 1
-        if cur_top_det_id == n:
+    while len(tracks) < opts.max_tracks:
+        ahead = np.flatnonzero(alive[scan:])
+        if ahead.size == 0:
             break
-        top_id = cur_top_det_id
-        cur_top_det_id += 1
-        if scores_for_stop(top_id) < opts.thres:
-            logging.info("Upon low confidence: total {} tracks".format(len(tracks)))
+        anchor_row = scan + int(ahead[0])
+        scan = anchor_row + 1
+        if score_of(anchor_row) < opts.thres:
+            logging.info("anchor below thres {}: {} tracks in total".format(opts.thres, len(tracks)))
             break
-        logging.info("tracking top No.{} in {}".format(len(tracks), vid_proto['video']))
-        anchor_frame_id, anchor_bbox = anchor_of(top_id)
+        logging.info("track {} of {}".format(len(tracks), vid_proto['video']))
+        anchor_frame_id, anchor_bbox = anchor_of(anchor_row)
         new_tracks = _run_tracker(track_method, vid_proto, anchor_frame_id, anchor_bbox, opts)
         tracks.extend(new_tracks)
-        logging.info("Applying nms between new tracks ({}) and detections.".format(len(new_tracks)))
-        for tracklet in new_tracks:
-            for box in tracklet:
-                frame_id = box['frame']
-                det_ids = [i for i in frame_to_det_ids[frame_id] if keep[i]]
-                if len(det_ids) == 0:
-                    continue
-                t = np.asarray([[frame_id, ] + box['bbox']], dtype=np.float32)
-                d = det_info[det_ids]
-                kp = set(track_det_nms(t, d, nms_thres))
-                for i, det_id in enumerate(det_ids):
-                    if i not in kp:
-                        keep[det_id] = False
-        logging.info("{} / {} boxes kept.".format(np.sum(keep), len(keep)))
+        _prune_frame_dets(new_tracks, rows_of_frame, alive, det_rows, nms_thres)
+        logging.info("{} of {} detections left".format(int(alive.sum()), n))
     return tracks
 
 

@@ -18,36 +18,49 @@ from .dataset import imagenet_vdet_classes
 from .. import hot
 
 
+# per-box fields that become channel sequences of the temporal-convolution scorer: blob name -> box key
+_TCN_BOX_FIELDS = (('det_scores', 'det_score'), ('track_scores', 'track_score'), ('gt_overlaps', 'gt_overlap'))
+_TCN_OPTIONAL_FIELDS = (('all_scores', 'all_score'), ('feats', 'feat'))       # memory-heavy: read only when the net has the blob
+
+
+def _tcn_channels(tubelet, blob_names):
+    """Everything the reference offers a net per tubelet (:19-37), keyed by blob name: the per-box fields, the anchor offset
+    normalised by the tubelet length (float division) and its magnitude, the 0 / 1 labels (gt overlap >= 0.5), and the
+    tubelet-level entries `length`, `gt`, `mean_iou` (a net with blobs of those names receives them too)."""
+    boxes = tubelet['boxes']
+    length = len(boxes)
+    ch = {name: [box[key] for box in boxes] for name, key in _TCN_BOX_FIELDS}
+    rel = np.asarray([box['anchor'] for box in boxes], dtype=np.float64) / length
+    ch['anchors'] = rel
+    ch['abs_anchors'] = np.abs(rel)
+    ch['labels'] = (np.asarray(ch['gt_overlaps'], dtype=np.float64) >= 0.5).astype(np.int64)
+    ch['length'], ch['gt'] = length, tubelet['gt']
+    ch['mean_iou'] = np.mean([ch['gt_overlaps']])
+    for name, key in _TCN_OPTIONAL_FIELDS:
+        if name in blob_names:
+            ch[name] = [box[key] for box in boxes]
+    return ch, length
+
+
 def score_conv_cls(score_proto, net):
-    """:15-51 -- feeds each tubelet's channel sequences to a temporal-convolution net and stores
-    probs[:,1,:] as box['conv_score'].  ``net`` is any object with ``.blobs`` (name -> object with
-    ``.shape``, ``.reshape(*dims)``, ``.data``) and ``.forward() -> {'probs': [1,2,L]}`` -- pycaffe's
-    interface; ``vdetlib_amd.vdet.tcn.TCNNet`` is a gfx950 implementation of it."""
-    new_score_proto = copy.copy(score_proto)
-    print("{}: {} tubelet(s).".format(score_proto['video'], len(new_score_proto['tubelets'])))
-    for tubelet in new_score_proto['tubelets']:
-        boxes = tubelet['boxes']
-        track = {'length': len(boxes), 'gt': tubelet['gt']}
-        track['mean_iou'] = np.mean([[b['gt_overlap'] for b in boxes]])
-        track['det_scores'] = [b['det_score'] for b in boxes]
-        track['track_scores'] = [b['track_score'] for b in boxes]
-        track['anchors'] = [b['anchor'] * 1. / track['length'] for b in boxes]
-        track['abs_anchors'] = [abs(a) for a in track['anchors']]
-        track['gt_overlaps'] = [b['gt_overlap'] for b in boxes]
-        track['labels'] = [1 if ov >= 0.5 else 0 for ov in track['gt_overlaps']]
-        if 'all_scores' in net.blobs.keys():
-            track['all_scores'] = [b['all_score'] for b in boxes]
-        if 'feats' in net.blobs.keys():
-            track['feats'] = [b['feat'] for b in boxes]
-        for blob_name in set(net.blobs.keys()).intersection(set(track.keys())):
-            num_channels = net.blobs[blob_name].shape[1]
-            net.blobs[blob_name].reshape(1, num_channels, 1, track['length'])
-            net.blobs[blob_name].data[...] = np.asarray(track[blob_name], dtype='float32')
-        blobs_out = net.forward()
-        probs = blobs_out['probs'][:, 1, :]
-        for box, prob in zip(boxes, np.asarray(probs).ravel()):
-            box['conv_score'] = float(prob)
-    return new_score_proto
+    """Reference :15-51.  Contract: for every tubelet, each blob of ``net`` whose name is one of the channel names above is
+    reshaped to (1, its channel count, 1, L) and filled with the float32 sequence; ``net.forward()['probs'][:, 1, :]``
+    becomes ``box['conv_score']`` (python float) of the tubelet's boxes, in place; the returned proto is a shallow copy.
+    ``net`` is any object with ``.blobs`` (name -> object with ``.shape``, ``.reshape(*dims)``, ``.data``) and
+    ``.forward()`` -- pycaffe's interface; ``vdetlib_amd.vdet.tcn.TCNNet`` is a gfx950 implementation of it."""
+    out = copy.copy(score_proto)
+    print("{}: {} tubelet(s).".format(score_proto['video'], len(out['tubelets'])))
+    blob_names = set(net.blobs.keys())
+    for tubelet in out['tubelets']:
+        channels, length = _tcn_channels(tubelet, blob_names)
+        for name in blob_names.intersection(channels):
+            blob = net.blobs[name]
+            blob.reshape(1, blob.shape[1], 1, length)
+            blob.data[...] = np.asarray(channels[name], dtype='float32')
+        probs = np.asarray(net.forward()['probs'][:, 1, :]).ravel()
+        for box, p in zip(tubelet['boxes'], probs):
+            box['conv_score'] = float(p)
+    return out
 
 
 def scoring_tracks(vid_proto, track_proto, annot_proto, sc_method, net, class_idx):
