@@ -219,3 +219,23 @@ def test_volume_nms_rejects_lists_out_of_range(oracle):
         ops.nms_volume_ordered(tb, order, badn, 0.3)
     ki2, kc2 = ops.nms_volume_ordered(tb, order, ncand, 0.3)              # the context is usable afterwards
     assert torch.equal(kc, kc2)
+
+
+@pytest.mark.parametrize("B", [300, 2000])
+def test_volume_nms_takes_caller_lists_at_any_alignment(oracle, B):
+    """the caller's lists of vdet_nms_volume_ordered may sit at any 2-byte aligned address: the lane-per-list walk of small
+    frames reads four candidates per 8-byte load only from 8-byte aligned lists (B % 4 == 0), and falls back to single
+    entries otherwise -- same survivors either way"""
+    import synth
+    F, C = 3, 4
+    boxes, scores = synth.video(53 + B, F, B, C)
+    tb, ts = torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda()
+    order, ncand = ops.argsort_volume(ts)
+    widx, wcnt = oracle.nms_volume(boxes, scores, 0.3)
+    for shift in (0, 1, 2, 3):
+        pool = torch.zeros(F * C * B + 8, dtype=order.dtype, device="cuda")
+        view = pool[shift:shift + F * C * B].view(F, C, B)
+        view.copy_(order)
+        assert view.data_ptr() % 8 == (pool.data_ptr() + 2 * shift) % 8 and view.is_contiguous()
+        ki, kc = ops.nms_volume_ordered(tb, view, ncand, 0.3)
+        assert np.array_equal(kc.cpu().numpy(), wcnt) and np.array_equal(ki.cpu().numpy(), widx), shift
