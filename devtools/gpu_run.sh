@@ -25,7 +25,8 @@ for what in "$@"; do
     tests)   timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -60 > $O/${P}_tests.log; tail -5 $O/${P}_tests.log ;;
     tests:*) timeout 2400 python -m pytest tests -m gpu -q -k "${what#tests:}" 2>&1 | tail -60 > $O/${P}_tests.log; tail -8 $O/${P}_tests.log ;;
     smoke)   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/${P}_smoke.log 2>&1; tail -2 $O/${P}_smoke.log ;;
-    bench)   /usr/bin/time -f "bench wall %e s" -o $O/${P}_bench.time timeout 1200 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/${P}_bench.json 2> $O/${P}_bench.err; cat $O/${P}_bench.time; tail -c 600 $O/${P}_bench.err; head -c 400 $O/${P}_bench.json ;;
+    bench)   t0=$SECONDS; timeout 1200 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/${P}_bench.json 2> $O/${P}_bench.err
+             echo "bench wall $((SECONDS - t0)) s" | tee $O/${P}_bench.time; tail -c 600 $O/${P}_bench.err; head -c 400 $O/${P}_bench.json ;;
     bench:*) n=$((n+1)); a="${what#bench:}"; timeout 1200 python bench.py ${a//_/ } > $O/${P}_bench_$n.json 2> $O/${P}_bench_$n.err; head -c 300 $O/${P}_bench_$n.json ;;
     kstats)  (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $R/$O/p_k -o k -- $STEP --steps 3 --warmup 2 > $R/$O/${P}_p_k.log 2>&1)
              python profiles/summarize.py $O/p_k/k_results.db $O/${P}_kernel_stats.csv "python bench.py --profile --no-sharded-leg --streams 1 --steps 3 --warmup 2 (one video at a time)" > /dev/null 2>> $O/${P}_sum.err
