@@ -68,9 +68,26 @@ def _vid_nms_rows(detections, class_index):
     if n:
         rows[:, 0] = np.fromiter((d['frame'] for d in detections), dtype=np.float64, count=n)
         rows[:, 1:5] = np.asarray([d['bbox'] for d in detections], dtype=np.float64).reshape(n, 4)
-        rows[:, 5] = np.fromiter((next((s['score'] for s in d['scores'] if s['class_index'] == class_index), float('-inf'))
-                                  for d in detections), dtype=np.float64, count=n)
+        # ``score_proto`` (utils/protocol.py:307-320) lists the classes in index order, so a detection's entry for the class is
+        # normally AT position class_index: one positional pass, checked; the per-detection scan of ``det_score`` otherwise
+        try:
+            entries = [d['scores'][class_index] for d in detections] if class_index >= 0 else None
+        except IndexError:
+            entries = None
+        if entries is not None and all(e['class_index'] == class_index for e in entries):
+            rows[:, 5] = np.fromiter((e['score'] for e in entries), dtype=np.float64, count=n)
+        else:
+            rows[:, 5] = np.fromiter((_class_score(d['scores'], class_index) for d in detections), dtype=np.float64, count=n)
     return rows
+
+
+def _class_score(scores, class_index):
+    """``det_score`` (utils/protocol.py:323-327): the score whose 'class_index' equals ``class_index`` (first match), -inf when
+    the detection has none."""
+    for e in scores:
+        if e['class_index'] == class_index:
+            return e['score']
+    return float('-inf')
 
 
 def apply_vid_nms(det_proto, class_index, thres=0.3):
