@@ -128,3 +128,17 @@ def test_track_plugins_are_external():
     with pytest.raises(RuntimeError):
         track.fcn_tracker(None, 1, [0, 0, 1, 1], None)
     assert track.fcn_tracker.__name__ == 'fcn_tracker'
+
+
+def test_timer_contract():
+    """utils/timer.py:10-32: attributes and return values of tic / toc"""
+    import time
+    from vdetlib_amd.utils.timer import Timer
+    t = Timer()
+    assert (t.total_time, t.calls, t.start_time, t.diff, t.average_time) == (0.0, 0, 0.0, 0.0, 0.0)
+    t.tic(); time.sleep(0.01)
+    a = t.toc()
+    assert t.calls == 1 and a == t.average_time == t.total_time == t.diff and a >= 0.009
+    t.tic()
+    d = t.toc(average=False)
+    assert t.calls == 2 and d == t.diff and abs(t.average_time - t.total_time / 2) < 1e-12

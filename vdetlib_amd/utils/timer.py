@@ -1,23 +1,26 @@
-"""tic/toc timer with the attributes T-CNN scripts read (reference utils/timer.py:10-32):
-total_time, calls, start_time, diff, average_time."""
+"""tic/toc timer with the attributes T-CNN scripts read (reference utils/timer.py:10-32): ``total_time``, ``calls``,
+``start_time``, ``diff`` (the last interval) and ``average_time`` (derived: total_time / calls, 0 before the first toc);
+``toc(average=True)`` returns the running average, ``toc(False)`` the last interval."""
 import time
 
 
 class Timer(object):
     def __init__(self):
-        self.total_time = 0.
+        self.reset()
+
+    def reset(self):
+        self.total_time = self.start_time = self.diff = 0.0
         self.calls = 0
-        self.start_time = 0.
-        self.diff = 0.
-        self.average_time = 0.
+
+    @property
+    def average_time(self):
+        return self.total_time / self.calls if self.calls else 0.0
 
     def tic(self):
-        self.start_time = time.time()
+        self.start_time = time.time()      # (wall clock, like the reference: intervals may span threads)
 
     def toc(self, average=True):
-        now = time.time()
-        self.diff = now - self.start_time
-        self.calls += 1
+        self.diff = time.time() - self.start_time
         self.total_time += self.diff
-        self.average_time = self.total_time / self.calls
+        self.calls += 1
         return self.average_time if average else self.diff
