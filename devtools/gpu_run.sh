@@ -29,7 +29,7 @@ for what in "$@"; do
              echo "bench wall $((SECONDS - t0)) s" | tee $O/${P}_bench.time; tail -c 600 $O/${P}_bench.err; head -c 400 $O/${P}_bench.json ;;
     bench:*) n=$((n+1)); a="${what#bench:}"; timeout 1200 python bench.py ${a//_/ } > $O/${P}_bench_$n.json 2> $O/${P}_bench_$n.err; head -c 300 $O/${P}_bench_$n.json ;;
     kstats)  (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $R/$O/p_k -o k -- $STEP --steps 3 --warmup 2 > $R/$O/${P}_p_k.log 2>&1)
-             python profiles/summarize.py $O/p_k/k_results.db $O/${P}_kernel_stats.csv "python bench.py --profile --no-sharded-leg --streams 1 --steps 3 --warmup 2 (one video at a time)" > /dev/null 2>> $O/${P}_sum.err
+             python profiles/summarize.py $O/p_k/k_results.db $O/${P}_kernel_stats.csv "python bench.py --profile --no-sharded-leg --streams 1 --steps 3 --warmup 2 (one video at a time; rocprim:: / at:: rows = the input generator and torch glue outside the timed region)" > /dev/null 2>> $O/${P}_sum.err
              rm -rf $O/p_k; head -14 $O/${P}_kernel_stats.csv | cut -c1-160 ;;
     hbm)     (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/$O/p_f -o f -- $STEP --steps 1 --warmup 1 > $R/$O/${P}_p_f.log 2>&1
               timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/$O/p_w -o w -- $STEP --steps 1 --warmup 1 > $R/$O/${P}_p_w.log 2>&1)
