@@ -221,3 +221,30 @@ def test_sharded_16_videos_c2_quarter_oracle_checked():
     assert oc["nms_ok"] is True and oc["tubelets_ok"] is True and oc["nms_lists"] == len(oc["nms_frames"]) * 200 and oc["tubelets"] > 0
     assert len(r["lpt_loads_world8_boxes"]) == 8 and 1.0 <= r["lpt_imbalance_world8"] < 1.2
     assert r["protocol_dicts"]["tracks"] > 0 and r["protocol_dicts"]["detections"] > 0
+
+
+def test_bench_eight_ranks_one_gpu_dry_run():
+    """the driver's 8-GPU launch line -- torch.distributed.run --nproc-per-node 8 bench.py --gpus 8 -- with all eight ranks on
+    device 0 over gloo (VDET_BENCH_ONE_GPU=1, miniature videos): every rank steps its own videos, the exchange gathers eight
+    slots, rank 0 prints the one line with eight per-rank times; and the same for `--videos 19` (LPT over eight ranks)"""
+    env = dict(os.environ, VDET_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    base = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1"]
+    cmd = base + ["--master-port", "29561", os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "2",
+                  "--frames", "8", "--boxes", "1200", "--classes", "8", "--streams", "2", "--cap", "512", "--no-cpu"]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 8 and r["scaling"] == "weak" and len(r["per_rank"]["ms_per_step"]) == 8
+    assert abs(r["value"] - 8 * 8 * 1200 * 2 / (r["ms_per_step"] * 2e-3)) / r["value"] < 1e-6
+    assert r["exchange"]["world"] == 8 and r["exchange"]["own_slot_matches"] is True
+    cmd = base + ["--master-port", "29563", os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "1", "--videos", "19",
+                  "--frames", "8", "--boxes", "1200", "--classes", "6", "--max-tracks", "3", "--streams", "2", "--cap", "512", "--no-cpu"]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    r = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    sh = r["config"]["shards"]
+    assert r["n_gpus"] == 8 and len(sh) == 8 and sorted(v for o in sh for v in o) == list(range(19)) and all(sh)
+    assert r["exchange"]["world"] == 8 and r["exchange"]["all_videos_present"] is True and r["exchange"]["videos_gathered"] == 19
+    assert len(r["per_rank"]["seconds"]) == 8 and r["protocol_dicts"]["from_rank"] == 7
