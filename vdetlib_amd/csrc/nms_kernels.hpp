@@ -737,10 +737,7 @@ struct WalkMeta {
 
 constexpr int kMaxWordRows = 320;       // 64-box word-rows of a regular frame (B <= 17 408: 272)
 constexpr int kAdjRows = 128;
-#ifndef VDET_ADJ_BATCH
-#define VDET_ADJ_BATCH 8
-#endif
-constexpr int kAdjBatch = VDET_ADJ_BATCH;   // bit-matrix words loaded per memory round trip (a row's window is ~42 words)
+constexpr int kAdjBatch = 8;         // bit-matrix words loaded per memory round trip (a row's window is ~42 words)
 constexpr int kAdjStage = 16384;     // u16 entries staged in LDS per block (32 KB)
 
 // ROWS = rows per block: kAdjRows (two blocks per 256-row tile), or kRowsPerTile on small frames (one block per tile: a third

@@ -175,29 +175,18 @@ __global__ __launch_bounds__(256) void temporal_both_vec4_kernel(const float4 *_
 // conflicts) and leave as 16-byte stores, TB*4 contiguous bytes per class row.
 // ------------------------------------------------------------------------------------------------
 // the outputs are written once and read by other kernels much later: streaming (non-temporal) stores
-// (measured: pass 1.9-2.0 -> 1.7-1.9 ms one video at a time; 0 = plain stores, 1 = pooled / convolved outputs only)
-#ifndef VDET_VPASS_NT
-#define VDET_VPASS_NT 2
-#endif
+// (measured: pass 1.9-2.0 -> 1.7-1.9 ms one video at a time against plain stores)
 typedef float vp_f4 __attribute__((ext_vector_type(4)));
 typedef uint32_t vp_u4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void vp_store(float4 *p, const float4 v)
 {
-#if VDET_VPASS_NT
     vp_f4 t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
     __builtin_nontemporal_store(t, reinterpret_cast<vp_f4 *>(p));
-#else
-    *p = v;
-#endif
 }
 __device__ __forceinline__ void vp_store_u4(uint4 *p, const uint4 v)
 {
-#if VDET_VPASS_NT == 2
     vp_u4 t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
     __builtin_nontemporal_store(t, reinterpret_cast<vp_u4 *>(p));
-#else
-    *p = v;
-#endif
 }
 
 template <int W, int ITEMS, bool CONV, int NT>
@@ -309,7 +298,6 @@ __global__ __launch_bounds__(NT) void volume_pass_kernel(const float4 *__restric
             }
             tb[loff[i]] = k4.x; tb[loff[i] + TB] = k4.y; tb[loff[i] + 2 * TB] = k4.z; tb[loff[i] + 3 * TB] = k4.w;
         }
-        if (!keys) continue;   // (timing experiments only: VDET_VPASS_NOKEYS)
         __syncthreads();       // (the other buffer was last read one iteration ago, before this barrier's predecessor)
         uint32_t *kf = keys + (int64_t)f * C4 * 4 * B + b0;
         const bool vec_ok = (B & 3) == 0;                        // every key row starts 16-byte aligned
@@ -321,11 +309,7 @@ __global__ __launch_bounds__(NT) void volume_pass_kernel(const float4 *__restric
                 const uint4 k4 = *reinterpret_cast<const uint4 *>(tb + cc * TB + ((4 * q) ^ (((cc >> 2) & qmask) << 2)));
                 const int o = cc * B + 4 * q;
                 if (vec_ok && 4 * q + 3 < rows) {
-#if VDET_VPASS_NT == 2
                     vp_store_u4(reinterpret_cast<uint4 *>(kf + o), k4);
-#else
-                    *reinterpret_cast<uint4 *>(kf + o) = k4;       // (the sort reads the keys next: keep them cached)
-#endif
                 } else {
                     kf[o] = k4.x;
                     if (4 * q + 1 < rows) kf[o + 1] = k4.y;
