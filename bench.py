@@ -32,6 +32,19 @@ HBM_PEAK = 8.0e12          # B/s, MI355X spec (/opt/skills/guides/MI355X_MICROAR
 METRIC = "boxes/sec whole-node (NMS+temporal-conv+link), 300f\u00d710k-box synth; mAP parity"   # BASELINE.json
 
 
+def emit_line(result):
+    """the ONE JSON line, as the LAST thing on stdout: whatever C libraries hold in their stdio buffers (RCCL prints a version
+    banner at communicator creation) is flushed first"""
+    import ctypes
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.write(json.dumps(result) + "\n")
+    sys.stdout.flush()
+
+
 def synth_video_cuda(torch, seed, F, B, C, device, kind="rand"):
     """boxes [F,B,4] (integer-valued f32, 1280x720, SURVEY 8d recipe), scores [F,B,C] f32 ~U(0,1) (softmax-like) or,
     kind="randn", ~N(0,1) (SVM-margin-like: both signs, many exponents -- another radix-digit distribution for the sort)."""
@@ -307,7 +320,7 @@ def run_sharded(args):
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(result))
+        emit_line(result)
 
 
 def dropin_latency_leg(reps_small=200):
@@ -1202,7 +1215,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(result))
+        emit_line(result)
 
 
 if __name__ == "__main__":
