@@ -32,15 +32,25 @@ HBM_PEAK = 8.0e12          # B/s, MI355X spec (/opt/skills/guides/MI355X_MICROAR
 METRIC = "boxes/sec whole-node (NMS+temporal-conv+link), 300f\u00d710k-box synth; mAP parity"   # BASELINE.json
 
 
-def emit_line(result):
-    """the ONE JSON line, as the LAST thing on stdout: whatever C libraries hold in their stdio buffers (RCCL prints a version
-    banner at communicator creation) is flushed first"""
+def drop_c_stdio():
+    """RCCL prints a version banner at communicator creation with C stdio (this build: unconditionally; it sits in libc's
+    buffer until exit when stdout is a pipe or a file).  The bench's stdout is ONE JSON line: python's own buffer goes out
+    first, then libc's pending output is flushed into /dev/null."""
     import ctypes
     sys.stdout.flush()
     try:
+        keep = os.dup(1)
+        null = os.open(os.devnull, os.O_WRONLY)
+        os.dup2(null, 1)
         ctypes.CDLL(None).fflush(None)
+        os.dup2(keep, 1)
+        os.close(null); os.close(keep)
     except Exception:
         pass
+
+
+def emit_line(result):
+    drop_c_stdio()
     sys.stdout.write(json.dumps(result) + "\n")
     sys.stdout.flush()
 
@@ -321,6 +331,8 @@ def run_sharded(args):
         dist.destroy_process_group()
     if rank == 0:
         emit_line(result)
+    else:
+        drop_c_stdio()
 
 
 def dropin_latency_leg(reps_small=200):
@@ -1216,6 +1228,8 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         emit_line(result)
+    else:
+        drop_c_stdio()
 
 
 if __name__ == "__main__":
