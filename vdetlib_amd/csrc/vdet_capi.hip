@@ -162,7 +162,8 @@ struct vdet_ctx {
     struct NodeKey { const void *tracks = nullptr, *boxes = nullptr; int64_t F = 0, B = 0, C = 0; int T = 0; double nms_thres = 0; } nodekey;
     bool nodes_valid = false;
     // single-launch drop-in calls (vdet_nms_f32 / vdet_track_det_nms_f32 on <= kFusedMax rows): host-mapped staging
-    void *fused_in = nullptr, *fused_out = nullptr;
+    void *fused_in = nullptr, *fused_out = nullptr;          // host addresses
+    void *fused_in_dev = nullptr, *fused_out_dev = nullptr;  // ... and what the device calls them
     size_t dyn_lds_max = 0;
 };
 
@@ -858,7 +859,12 @@ int fused_call(vdet_ctx *c, const float *h_rows, int64_t n, int64_t ld, int ncol
                 return fail(c, VDET_EHIP, "hipFuncSetAttribute(fused_nms_kernel) failed: %s", hipGetErrorString(e));
             }
         }
-        c->fused_in = pi; c->fused_out = po;
+        void *di = nullptr, *dq = nullptr;
+        if (hipHostGetDevicePointer(&di, pi, 0) != hipSuccess || hipHostGetDevicePointer(&dq, po, 0) != hipSuccess) {
+            (void)hipHostFree(pi); (void)hipHostFree(po);
+            return fail(c, VDET_EHIP, "hipHostGetDevicePointer failed for the single-launch staging memory");
+        }
+        c->fused_in = pi; c->fused_out = po; c->fused_in_dev = di; c->fused_out_dev = dq;
     }
     float *rows = static_cast<float *>(c->fused_in);
     int32_t *rank = reinterpret_cast<int32_t *>(rows + (size_t)kFusedMax * 6);
@@ -875,16 +881,13 @@ int fused_call(vdet_ctx *c, const float *h_rows, int64_t n, int64_t ld, int ncol
         }
     }
     for (int64_t j = 0; j < t; ++j) memcpy(trk + j * 5, h_tracks + j * ldt, 20);
-    void *d_in = nullptr, *d_out = nullptr;
-    HIPCHK(c, hipHostGetDevicePointer(&d_in, c->fused_in, 0));
-    HIPCHK(c, hipHostGetDevicePointer(&d_out, c->fused_out, 0));
     FusedParams fp{};
-    fp.rows = static_cast<const float *>(d_in);
+    fp.rows = static_cast<const float *>(c->fused_in_dev);
     fp.rank = h_order ? reinterpret_cast<const int32_t *>(fp.rows + (size_t)kFusedMax * 6) : nullptr;
     fp.tracks = h_tracks ? reinterpret_cast<const float *>(reinterpret_cast<const int32_t *>(fp.rows + (size_t)kFusedMax * 6) + kFusedMax) : nullptr;
     fp.n = (int)n; fp.ncols = ncols; fp.t = (int)t;
     fp.t32 = thresh_to_f32(thresh);
-    fp.out = static_cast<int32_t *>(d_out);
+    fp.out = static_cast<int32_t *>(c->fused_out_dev);
     int n2 = 64;
     while (n2 < n) n2 <<= 1;
     const size_t lds = fused_lds_bytes((int)n, n2);
