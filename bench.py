@@ -470,6 +470,38 @@ def vid_shape_leg(torch, ops, _lib, dev, taps, V=64, B=300, C=30, T=4):
                       "max-pool / convolution + %d tubelets per class + re-scoring; oracle: video 5, classes 0-1" % T}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no torchrun environment: re-execute under torch.distributed.run with N ranks on
+    127.0.0.1 (one rank per GPU over RCCL) -- the same command line the driver would write.  Fewer than N visible devices is an
+    error (exit 2), never a silent one-rank run.  Under torchrun the world size comes from the environment; a `--gpus` that
+    disagrees with it is reported on stderr and the environment wins (the line's `n_gpus` is always the real world size)."""
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is not None:
+        if int(world_env) != args.gpus:
+            sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%s: running %s ranks\n" % (args.gpus, world_env, world_env))
+        return
+    if args.gpus <= 1:
+        return
+    if os.environ.get("VDET_BENCH_ONE_GPU") != "1":       # (test hook: every rank on device 0 over gloo)
+        import torch
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            sys.stderr.write("bench.py: --gpus %d requested but %d HIP device(s) visible; not running fewer ranks than asked\n"
+                             % (args.gpus, have))
+            sys.exit(2)
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC only on this driver (RCCL peers)
+    os.environ.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os.execv(sys.executable, cmd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -516,6 +548,7 @@ def main():
                     help="run the N > 1 exchange step -- process group, RCCL communicator, all-gather of device tensors from "
                          "every stream -- also in a world of ONE (what a single-GPU box can execute of configs[3])")
     args = ap.parse_args()
+    self_launch(args)            # plain `python bench.py --gpus N` (no torchrun): becomes N ranks, one per GPU, over RCCL
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
         args.no_cpu = True       # the CPU baseline / mAP-parity / PCIe legs are reported at N = 1 only
     if args.profile:

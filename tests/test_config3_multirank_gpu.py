@@ -38,6 +38,35 @@ def test_bench_two_ranks_one_gpu_dry_run():
     assert r["exchange"]["world"] == 2 and r["exchange"]["exchange_ms"] > 0
 
 
+def test_plain_python_bench_gpus_2_launches_two_ranks_by_itself():
+    """`python bench.py --gpus 2` WITHOUT torchrun (the driver's scaling command line may be exactly this): bench.py re-executes
+    itself under torch.distributed.run with two ranks; the line says n_gpus == 2 and carries a two-rank exchange.  Both for the
+    headline step and for configs[3]'s `--videos` form.  (VDET_BENCH_ONE_GPU=1: both ranks on device 0 over gloo.)"""
+    env = dict(os.environ, VDET_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+            "--frames", "12", "--boxes", "2000", "--classes", "16", "--no-cpu"]
+    for extra, scaling in (([], "weak"), (["--videos", "4"], "strong")):
+        p = subprocess.run(base + extra, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, p.stdout[-2000:]
+        r = json.loads(lines[0])
+        assert r["n_gpus"] == 2 and r["exchange"]["world"] == 2 and r["scaling"] == scaling
+
+
+def test_plain_python_bench_refuses_more_gpus_than_visible():
+    """--gpus N with fewer than N devices: exit code 2 and a message, never a silent one-rank run."""
+    import torch
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "VDET_BENCH_ONE_GPU")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "1"],
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 2 and "visible" in p.stderr
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
+
+
 def test_rccl_exchange_executes_in_a_world_of_one():
     """bench.py --force-exchange under torch.distributed.run with ONE rank: init_process_group("nccl", device_id=...),
     the fixed-shape all-gathers of the tubelet payload and the kept counts from every stream in flight, inside the timed

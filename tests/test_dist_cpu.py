@@ -117,3 +117,19 @@ def test_frame_offsets_are_validated():
     for bad in ([1, 3, 7], [0, 3, 3, 7], [0, 8], [0], [0, 3, 6]):
         with pytest.raises(ValueError):
             ops._frame_offsets(bad, 7)
+
+
+def test_bench_gpus_n_without_devices_exits_2():
+    """`python bench.py --gpus N` launches N ranks by itself (bench.self_launch); with fewer than N devices visible -- this
+    container has none -- it exits with code 2 and says why, instead of printing an n_gpus: 1 line."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "VDET_BENCH_ONE_GPU")}
+    import torch
+    if torch.cuda.device_count() >= 9:
+        pytest.skip("more devices than any node has")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "9", "--steps", "1", "--warmup", "1"],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 2 and "--gpus 9" in p.stderr and "visible" in p.stderr
+    assert "{" not in p.stdout
