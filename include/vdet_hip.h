@@ -161,6 +161,19 @@ int vdet_track_det_nms_f32(vdet_ctx *ctx, const float *h_tracks, int64_t t, int6
                            const float *h_dets, int64_t m, int64_t ldd, double thresh,
                            int64_t *h_keep, int64_t *n_keep);
 
+/*
+ * The reference's per-tracked-box pattern (vdet/track.py:236-250 and :170-184: one track_det_nms call per box of every new
+ * tracklet, each against the still-kept detections of that box's frame) as ONE call: K independent problems, problem k =
+ * track_det_nms(h_tracks[h_toff[k] .. h_toff[k+1]), h_dets[h_off[k] .. h_off[k+1]), thresh).  h_toff == NULL: exactly one
+ * track row per problem (row k).  h_keep (capacity h_off[K]): problem k's kept indices -- positions inside ITS rows,
+ * descending score -- start at h_keep[h_off[k]]; h_nkeep[k] their count.  Problems of <= 640 rows run as one launch of K
+ * workgroups and one host wait; otherwise the problems are taken one after the other.  The caller guarantees the problems
+ * are independent (the boxes of one tracklet sit on different frames); a frame that repeats belongs in the next call.
+ */
+int vdet_track_det_nms_batch(vdet_ctx *ctx, const float *h_tracks, const int64_t *h_toff, int64_t ldt,
+                             const float *h_dets, const int64_t *h_off, int64_t K, int64_t ldd, double thresh,
+                             int64_t *h_keep, int64_t *h_nkeep);
+
 /* iou (utils/common.py:451-468): float64 IoU matrix out[n1,n2] of boxes1[n1,4] x boxes2[n2,4]. */
 int vdet_iou_f64(vdet_ctx *ctx, const double *h_boxes1, int64_t n1, const double *h_boxes2,
                  int64_t n2, double *h_out);

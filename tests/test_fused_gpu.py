@@ -104,3 +104,63 @@ def test_track_det_nms_tracks_and_sizes(cnms, oracle, m, t):
         d[5, 1:5] = [10, 10, 9, 30]
         tr = np.array([[1, 10, 10, 9, 30]], np.float32)
         _same(lambda: cnms.track_det_nms(tr, d, 0.3), lambda: oracle.track_det_nms(tr, d, 0.3))
+
+
+def _batch_case(rng, sizes, seed, nf=1):
+    """K problems (the reference's per-tracked-box calls, vdet/track.py:236-250): problem k = one track row on frame k + 1 and
+    the m_k detections of that frame"""
+    dets, tracks = [], []
+    for k, m in enumerate(sizes):
+        d = synth.dets6(seed + 31 * k + m, m, 1) if m else np.zeros((0, 6), np.float32)
+        d[:, 0] = k + 1
+        dets.append(d)
+        tr = np.zeros((1, 5), np.float32)
+        tr[0, 0] = k + 1
+        tr[0, 1:5] = (d[rng.randint(m), 1:5] + rng.randint(-6, 7, 4)) if m else [0, 0, 10, 10]
+        tracks.append(tr)
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    return np.concatenate(tracks), np.concatenate(dets), off
+
+
+@pytest.mark.parametrize("sizes", [[1], [0, 5, 0], [7, 128, 129, 64, 1, 300], [640, 639, 2], [100] * 37, [641, 10], [200, 0, 200, 33]])
+def test_track_det_nms_batch_equals_one_call_per_problem(cnms, oracle, sizes):
+    rng = np.random.RandomState(sum(sizes) + len(sizes))
+    tracks, dets, off = _batch_case(rng, sizes, 16000)
+    keep, counts = cnms.track_det_nms_batch(tracks, dets, off, 0.3)
+    assert counts.shape == (len(sizes),)
+    for k in range(len(sizes)):
+        want = oracle.track_det_nms(tracks[k:k + 1], np.ascontiguousarray(dets[off[k]:off[k + 1]]), 0.3)
+        assert keep[off[k]:off[k] + counts[k]].tolist() == want, k
+        assert want == cnms.track_det_nms(tracks[k:k + 1], dets[off[k]:off[k + 1]], 0.3)
+    # several track rows per problem (track_offsets), incl. a problem without any
+    toff = np.asarray([0] + list(np.cumsum([k % 3 for k in range(len(sizes))])), np.int64)
+    tr2 = np.zeros((int(toff[-1]), 5), np.float32)
+    for k in range(len(sizes)):
+        for q in range(int(toff[k]), int(toff[k + 1])):
+            m = sizes[k]
+            tr2[q, 0] = k + 1
+            tr2[q, 1:5] = (dets[off[k] + rng.randint(m), 1:5] + rng.randint(-9, 10, 4)) if m else [1, 1, 5, 5]
+    keep, counts = cnms.track_det_nms_batch(tr2, dets, off, 0.3, track_offsets=toff)
+    for k in range(len(sizes)):
+        want = oracle.track_det_nms(np.ascontiguousarray(tr2[toff[k]:toff[k + 1]]), np.ascontiguousarray(dets[off[k]:off[k + 1]]), 0.3)
+        assert keep[off[k]:off[k] + counts[k]].tolist() == want, k
+
+
+def test_track_det_nms_batch_errors(cnms, oracle):
+    rng = np.random.RandomState(3)
+    tracks, dets, off = _batch_case(rng, [20, 30, 25], 17000)
+    # the reference's ZeroDivisionError from ANY problem of the batch
+    dets[off[1] + 5, 1:5] = [10, 10, 9, 30]
+    tracks[1, 1:5] = [10, 10, 9, 30]
+    with pytest.raises(ZeroDivisionError):
+        oracle.track_det_nms(tracks[1:2], np.ascontiguousarray(dets[off[1]:off[2]]), 0.3)
+    with pytest.raises(ZeroDivisionError):
+        cnms.track_det_nms_batch(tracks, dets, off, 0.3)
+    with pytest.raises(ValueError):
+        cnms.track_det_nms_batch(tracks, dets, [0, 20, 50], 0.3)              # offsets do not cover the rows
+    with pytest.raises(ValueError):
+        cnms.track_det_nms_batch(tracks[:2], dets, off, 0.3)                  # one track row per problem
+    with pytest.raises(ValueError):
+        cnms.track_det_nms_batch(tracks.astype(np.float64), dets, off, 0.3)
+    keep, counts = cnms.track_det_nms_batch(np.zeros((0, 5), np.float32), np.zeros((0, 6), np.float32), [0], 0.3)
+    assert len(counts) == 0

@@ -33,6 +33,7 @@ SYMBOLS = {
     "vdet_set_async": (_ci, [_vp, _ci]),
     "vdet_nms_f32": (_ci, [_vp, _vp, _i64, _i64, _ci, _f64, _vp, _vp, ctypes.POINTER(_i64)]),
     "vdet_track_det_nms_f32": (_ci, [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _f64, _vp, ctypes.POINTER(_i64)]),
+    "vdet_track_det_nms_batch": (_ci, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _f64, _vp, _vp]),
     "vdet_iou_f64": (_ci, [_vp, _vp, _i64, _vp, _i64, _vp]),
     "vdet_svm_scores_f64": (_ci, [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _vp]),
     "vdet_svm_scores_f32": (_ci, [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _vp]),

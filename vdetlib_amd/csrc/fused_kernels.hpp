@@ -34,7 +34,18 @@ struct FusedParams {
     const float *tracks;      // [t, 5] (frame,x1,y1,x2,y2) or null: track_det_nms round 1
     int n, ncols, t;
     float t32;
-    int32_t *out;             // [0] status bits (kStDivZero), [1] number kept, [2 ..] kept row indices, descending priority
+    int32_t *hdr;             // [0] status bits (kStDivZero), [1] number kept
+    int32_t *kept;            // kept row indices, descending priority
+};
+
+// A batch of independent track_det_nms problems in one launch (vdet_track_det_nms_batch): block k takes rows off[k] .. off[k+1]
+// of the packed rows and track rows toff[k] .. toff[k+1]; its header is hdr[2k .. 2k+1], its kept list starts at kept[off[k]].
+struct FusedBatchParams {
+    const float *rows;        // [off[K], 6]
+    const float *tracks;      // [toff[K], 5]
+    const int32_t *off, *toff;
+    float t32;
+    int32_t *hdr, *kept;
 };
 
 __host__ __device__ __forceinline__ int fused_tri_words(int W) { return 16 * W * (W + 1); }
@@ -48,10 +59,8 @@ __host__ __device__ __forceinline__ size_t fused_lds_bytes(int n, int n2)
 }
 
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void fused_nms_kernel(const FusedParams prm)
+__device__ __forceinline__ void fused_nms_body(const FusedParams &prm, unsigned char *smem, int &s_ncand, int &s_bad)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ int s_ncand, s_bad;
     const int tid = threadIdx.x;
     const int n = prm.n;
     int n2 = 64;
@@ -165,7 +174,7 @@ __global__ __launch_bounds__(BLOCK) void fused_nms_kernel(const FusedParams prm)
         const int g = i >> 5;
         const uint32_t dw = (uint32_t)__builtin_amdgcn_readlane((int)dead, g);
         if ((dw >> (i & 31)) & 1u) continue;
-        if (lane == 0) prm.out[2 + nk] = sidx[i];
+        if (lane == 0) prm.kept[nk] = sidx[i];
         ++nk;
         const int wn = W - g;
         const int base = 32 * (g * W - (g * (g - 1)) / 2) + (i & 31) * wn;
@@ -183,10 +192,41 @@ __global__ __launch_bounds__(BLOCK) void fused_nms_kernel(const FusedParams prm)
     }
     const bool anybad = __ballot(bad != 0) != 0ull;
     if (lane == 0) {
-        prm.out[1] = nk;
-        prm.out[0] = (anybad || s_bad) ? kStDivZero : 0;
+        prm.hdr[1] = nk;
+        prm.hdr[0] = (anybad || s_bad) ? kStDivZero : 0;
         __threadfence_system();
     }
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void fused_nms_kernel(const FusedParams prm)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int s_ncand, s_bad;
+    fused_nms_body<BLOCK>(prm, smem, s_ncand, s_bad);
+}
+
+// one block per problem; an empty problem writes an empty header
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void fused_nms_batch_kernel(const FusedBatchParams bp)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int s_ncand, s_bad;
+    const int k = blockIdx.x;
+    const int r0 = bp.off[k], r1 = bp.off[k + 1], t0 = bp.toff[k], t1 = bp.toff[k + 1];
+    FusedParams prm;
+    prm.rows = bp.rows + (size_t)r0 * 6;
+    prm.rank = nullptr;
+    prm.tracks = t1 > t0 ? bp.tracks + (size_t)t0 * 5 : nullptr;
+    prm.n = r1 - r0; prm.ncols = 6; prm.t = t1 - t0;
+    prm.t32 = bp.t32;
+    prm.hdr = bp.hdr + 2 * (size_t)k;
+    prm.kept = bp.kept + r0;
+    if (prm.n <= 0) {
+        if (threadIdx.x == 0) { prm.hdr[0] = 0; prm.hdr[1] = 0; __threadfence_system(); }
+        return;
+    }
+    fused_nms_body<BLOCK>(prm, smem, s_ncand, s_bad);
 }
 
 }  // namespace vdet

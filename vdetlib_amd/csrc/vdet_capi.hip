@@ -164,6 +164,9 @@ struct vdet_ctx {
     // single-launch drop-in calls (vdet_nms_f32 / vdet_track_det_nms_f32 on <= kFusedMax rows): host-mapped staging
     void *fused_in = nullptr, *fused_out = nullptr;          // host addresses
     void *fused_in_dev = nullptr, *fused_out_dev = nullptr;  // ... and what the device calls them
+    void *fbatch_in = nullptr, *fbatch_out = nullptr, *fbatch_in_dev = nullptr, *fbatch_out_dev = nullptr;   // vdet_track_det_nms_batch (grown on demand)
+    size_t fbatch_in_cap = 0, fbatch_out_cap = 0;
+    bool fbatch_attr = false;
     size_t dyn_lds_max = 0;
 };
 
@@ -887,7 +890,8 @@ int fused_call(vdet_ctx *c, const float *h_rows, int64_t n, int64_t ld, int ncol
     fp.tracks = h_tracks ? reinterpret_cast<const float *>(reinterpret_cast<const int32_t *>(fp.rows + (size_t)kFusedMax * 6) + kFusedMax) : nullptr;
     fp.n = (int)n; fp.ncols = ncols; fp.t = (int)t;
     fp.t32 = thresh_to_f32(thresh);
-    fp.out = static_cast<int32_t *>(c->fused_out_dev);
+    fp.hdr = static_cast<int32_t *>(c->fused_out_dev);
+    fp.kept = fp.hdr + 2;
     int n2 = 64;
     while (n2 < n) n2 <<= 1;
     const size_t lds = fused_lds_bytes((int)n, n2);
@@ -903,6 +907,86 @@ int fused_call(vdet_ctx *c, const float *h_rows, int64_t n, int64_t ld, int ncol
     if (nk < 0 || nk > n) return fail(c, VDET_EHIP, "internal: single-launch NMS returned %lld of %lld rows", (long long)nk, (long long)n);
     for (int64_t k = 0; k < nk; ++k) h_keep[k] = out[2 + k];
     *n_keep = nk;
+    return VDET_OK;
+}
+
+// K independent track_det_nms problems (vdet/track.py:236-250: one per tracked box, each on its own frame's still-kept
+// detections) in ONE launch of K workgroups and ONE host wait.  Host-mapped staging, grown on demand:
+//   in : rows [M,6] f32 | tracks [T,5] f32 | off [K+1] i32 | toff [K+1] i32         out: hdr [K,2] i32 | kept [M] i32
+int fused_batch_call(vdet_ctx *c, const float *h_tracks, const int64_t *h_toff, int64_t ldt, const float *h_dets, const int64_t *h_off,
+                     int64_t K, int64_t ldd, double thresh, int64_t *h_keep, int64_t *h_nkeep, int64_t max_m)
+{
+    const int64_t M = h_off[K], T = h_toff ? h_toff[K] : K;
+    const size_t in_bytes = (((size_t)M * 24 + (size_t)T * 20 + 15) & ~(size_t)15) + 2 * (size_t)(K + 1) * 4;
+    const size_t out_bytes = (size_t)K * 8 + (size_t)M * 4;
+    if (in_bytes > c->fbatch_in_cap || out_bytes > c->fbatch_out_cap) {
+        if (c->fbatch_in) (void)hipHostFree(c->fbatch_in);
+        if (c->fbatch_out) (void)hipHostFree(c->fbatch_out);
+        c->fbatch_in = c->fbatch_out = c->fbatch_in_dev = c->fbatch_out_dev = nullptr;
+        c->fbatch_in_cap = c->fbatch_out_cap = 0;
+        const size_t ci = std::max<size_t>(in_bytes + in_bytes / 2, (size_t)1 << 20), co = std::max<size_t>(out_bytes + out_bytes / 2, (size_t)1 << 18);
+        void *pi = nullptr, *po = nullptr, *di = nullptr, *dq = nullptr;
+        if (hipHostMalloc(&pi, ci, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+            hipHostMalloc(&po, co, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+            if (pi) (void)hipHostFree(pi);
+            return fail(c, VDET_ENOMEM, "host-mapped staging memory for vdet_track_det_nms_batch");
+        }
+        if (hipHostGetDevicePointer(&di, pi, 0) != hipSuccess || hipHostGetDevicePointer(&dq, po, 0) != hipSuccess) {
+            (void)hipHostFree(pi); (void)hipHostFree(po);
+            return fail(c, VDET_EHIP, "hipHostGetDevicePointer failed for the batch staging memory");
+        }
+        c->fbatch_in = pi; c->fbatch_out = po; c->fbatch_in_dev = di; c->fbatch_out_dev = dq;
+        c->fbatch_in_cap = ci; c->fbatch_out_cap = co;
+    }
+    if (!c->fbatch_attr) {
+        for (const void *fn : {reinterpret_cast<const void *>(fused_nms_batch_kernel<256>), reinterpret_cast<const void *>(fused_nms_batch_kernel<1024>)}) {
+            hipFuncAttributes fa;
+            hipError_t e = hipFuncGetAttributes(&fa, fn);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(c->max_lds - (((size_t)fa.sharedSizeBytes + 15) & ~(size_t)15)));
+            if (e != hipSuccess) return fail(c, VDET_EHIP, "hipFuncSetAttribute(fused_nms_batch_kernel) failed: %s", hipGetErrorString(e));
+        }
+        c->fbatch_attr = true;
+    }
+    float *rows = static_cast<float *>(c->fbatch_in);
+    float *trk = rows + (size_t)M * 6;
+    const size_t tab = ((size_t)M * 24 + (size_t)T * 20 + 15) & ~(size_t)15;
+    int32_t *off = reinterpret_cast<int32_t *>(static_cast<unsigned char *>(c->fbatch_in) + tab);
+    int32_t *toff = off + (K + 1);
+    if (ldd == 6) memcpy(rows, h_dets, (size_t)M * 24);
+    else for (int64_t i = 0; i < M; ++i) memcpy(rows + i * 6, h_dets + i * ldd, 24);
+    for (int64_t j = 0; j < T; ++j) memcpy(trk + j * 5, h_tracks + j * ldt, 20);
+    for (int64_t k = 0; k <= K; ++k) { off[k] = (int32_t)h_off[k]; toff[k] = (int32_t)(h_toff ? h_toff[k] : k); }
+    volatile int32_t *hdr = static_cast<volatile int32_t *>(c->fbatch_out);
+    volatile int32_t *kept = hdr + 2 * K;
+    FusedBatchParams bp{};
+    const unsigned char *din = static_cast<const unsigned char *>(c->fbatch_in_dev);
+    bp.rows = reinterpret_cast<const float *>(din);
+    bp.tracks = bp.rows + (size_t)M * 6;
+    bp.off = reinterpret_cast<const int32_t *>(din + tab);
+    bp.toff = bp.off + (K + 1);
+    bp.t32 = thresh_to_f32(thresh);
+    bp.hdr = static_cast<int32_t *>(c->fbatch_out_dev);
+    bp.kept = bp.hdr + 2 * K;
+    int n2 = 64;
+    while (n2 < max_m) n2 <<= 1;
+    const size_t lds = fused_lds_bytes((int)std::max<int64_t>(max_m, 1), n2);
+    {
+        StageTimer tm(c, ST_WALK);
+        if (max_m <= 128) hipLaunchKernelGGL(fused_nms_batch_kernel<256>, dim3((unsigned)K), dim3(256), lds, c->stream, bp);
+        else hipLaunchKernelGGL(fused_nms_batch_kernel<1024>, dim3((unsigned)K), dim3(1024), lds, c->stream, bp);
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, host_sync(c));
+    bool divz = false;
+    for (int64_t k = 0; k < K; ++k) {
+        const int64_t m = h_off[k + 1] - h_off[k], nk = hdr[2 * k + 1];
+        if (hdr[2 * k] & kStDivZero) divz = true;
+        if (nk < 0 || nk > m) return fail(c, VDET_EHIP, "internal: batched single-launch NMS returned %lld of %lld rows", (long long)nk, (long long)m);
+        h_nkeep[k] = nk;
+        for (int64_t q = 0; q < nk; ++q) h_keep[h_off[k] + q] = kept[h_off[k] + q];
+    }
+    if (divz) return fail(c, VDET_EDIVZERO, "float division (zero union)");
     return VDET_OK;
 }
 
@@ -1031,6 +1115,8 @@ int vdet_destroy(vdet_ctx *c)
     if (c->d_cnt) (void)hipFree(c->d_cnt);
     if (c->fused_in) (void)hipHostFree(c->fused_in);
     if (c->fused_out) (void)hipHostFree(c->fused_out);
+    if (c->fbatch_in) (void)hipHostFree(c->fbatch_in);
+    if (c->fbatch_out) (void)hipHostFree(c->fbatch_out);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return VDET_OK;
@@ -1288,6 +1374,41 @@ int vdet_track_det_nms_f32(vdet_ctx *c, const float *h_tracks, int64_t t, int64_
     }
     HIPCHK(c, hipGetLastError());
     return nms_grouped_tail(c, pl, c->scores.as<float>(), nullptr, c->excl.as<uint8_t>(), h_keep, n_keep);
+}
+
+
+int vdet_track_det_nms_batch(vdet_ctx *c, const float *h_tracks, const int64_t *h_toff, int64_t ldt, const float *h_dets,
+                             const int64_t *h_off, int64_t K, int64_t ldd, double thresh, int64_t *h_keep, int64_t *h_nkeep)
+{
+    if (!c) return VDET_EINVAL;
+    if (K < 0 || (K > 0 && (!h_off || !h_nkeep))) return fail(c, VDET_EINVAL, "need K >= 0 problems with offsets and a count per problem");
+    if (K == 0) return VDET_OK;
+    if (K > 0x3FFFFFFF || h_off[0] != 0 || (h_toff && h_toff[0] != 0)) return fail(c, VDET_EINVAL, "offsets must start at 0");
+    int64_t max_m = 0, max_t = 0;
+    for (int64_t k = 0; k < K; ++k) {
+        const int64_t m = h_off[k + 1] - h_off[k], t = h_toff ? h_toff[k + 1] - h_toff[k] : 1;
+        if (m < 0 || t < 0) return fail(c, VDET_EINVAL, "offsets must not decrease");
+        max_m = std::max(max_m, m); max_t = std::max(max_t, t);
+        h_nkeep[k] = 0;
+    }
+    const int64_t M = h_off[K], T = h_toff ? h_toff[K] : K;
+    if (M > 0x7FFFFFFF || T > 0x7FFFFFFF) return fail(c, VDET_EINVAL, "too many rows");
+    if ((T > 0 && (!h_tracks || ldt < 5)) || (M > 0 && (!h_dets || !h_keep || ldd < 6)))
+        return fail(c, VDET_EINVAL, "tracks must be float32 [T,5], dets float32 [M,6]");
+    if (M == 0) return VDET_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (max_m <= kFusedMax && max_t <= kFusedMaxTracks && !c->no_fused) {
+        timing_reset(c);
+        return fused_batch_call(c, h_tracks, h_toff, ldt, h_dets, h_off, K, ldd, thresh, h_keep, h_nkeep, max_m);
+    }
+    // a problem beyond the single-launch sizes (or VDET_NO_FUSED=1): the problems one by one through the general chain
+    for (int64_t k = 0; k < K; ++k) {
+        const int64_t t0 = h_toff ? h_toff[k] : k, t = h_toff ? h_toff[k + 1] - h_toff[k] : 1;
+        const int rc = vdet_track_det_nms_f32(c, h_tracks ? h_tracks + t0 * ldt : nullptr, t, ldt, h_dets + h_off[k] * ldd, h_off[k + 1] - h_off[k], ldd, thresh,
+                                              h_keep + h_off[k], &h_nkeep[k]);
+        if (rc) return rc;
+    }
+    return VDET_OK;
 }
 
 int vdet_iou_f64(vdet_ctx *c, const double *h_b1, int64_t n1, const double *h_b2, int64_t n2, double *h_out)
@@ -1619,7 +1740,10 @@ int vdet_nms_track_volume(vdet_ctx *c, const float *d_boxes, const float *d_scor
     const unsigned cg = (unsigned)((C + 63) / 64);
     hipLaunchKernelGGL(track_init_kernel, dim3(cg), dim3(64), 0, c->stream, st, (int)C);
     HIPCHK(c, hipMemsetAsync(d_ntracks, 0, (size_t)C * 4, c->stream));
-    if (max_tracks == 0) return VDET_OK;
+    if (max_tracks == 0) {          // nothing to track: report a launch error of the walk / init above by THIS call
+        HIPCHK(c, hipGetLastError());
+        return VDET_OK;
+    }
     SuppressParams sp{};
     sp.boxes = reinterpret_cast<const float4 *>(d_boxes);
     sp.F = (int)F; sp.B = (int)B; sp.C = (int)C; sp.max_tracks = max_tracks;
@@ -1734,7 +1858,10 @@ int vdet_video_batch(vdet_ctx *c, const float *d_boxes, const float *d_scores, c
     }
     c->lists_valid = false;          // consumed by the tracking below
     HIPCHK(c, hipMemsetAsync(d_ntracks, 0, (size_t)(V * C) * 4, c->stream));
-    if (max_tracks == 0) return VDET_OK;
+    if (max_tracks == 0) {
+        HIPCHK(c, hipGetLastError());
+        return VDET_OK;
+    }
     // ---- per video: tracking (+ re-scoring) on its frame range
     const bool regular_ok = c->sym_built;
     const float link_t32 = thresh_to_f32(link_thres);

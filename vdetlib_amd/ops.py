@@ -265,8 +265,16 @@ def volume_pass(scores, window=3, taps=None, pad_max=-1e5, bias=0.0, pad_conv=0.
             if buf.dtype != torch.float32 or not buf.is_contiguous() or buf.numel() < scores.numel() or buf.device != scores.device:
                 raise ValueError("out buffers must be contiguous float32 tensors of >= scores.numel() elements on the scores' device")
             return buf.view(-1)[:scores.numel()].view(scores.shape)
+        if len(out) != 2 or out[0] is None or (t is not None and out[1] is None):
+            raise ValueError("out = (pooled buffer, conv buffer): the conv buffer is needed when taps are given")
         out_m = view(out[0])
         out_c = view(out[1]) if t is not None else None
+        # the kernel reads ``scores`` while it streams both outputs: overlapping buffers would give silently wrong results
+        spans = [(b.data_ptr(), b.data_ptr() + scores.numel() * 4) for b in (scores, out_m, out_c) if b is not None]
+        for i in range(len(spans)):
+            for j in range(i + 1, len(spans)):
+                if spans[i][0] < spans[j][1] and spans[j][0] < spans[i][1]:
+                    raise ValueError("out buffers must not overlap each other or scores")
     tail = (int(window), float(pad_max), t.ctypes.data if t is not None else None, float(bias), float(pad_conv),
             out_m.data_ptr(), out_c.data_ptr() if out_c is not None else None, 0 if score_thresh is None else 1,
             0.0 if score_thresh is None else float(score_thresh))

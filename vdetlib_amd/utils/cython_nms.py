@@ -86,3 +86,36 @@ def track_det_nms(tracks, dets, thresh):
     ctx.check(ctx.lib.vdet_track_det_nms_f32(ctx.h, t.ctypes.data if t.shape[0] else None, t.shape[0], ldt,
                                              d.ctypes.data, m, ldd, th, keep.ctypes.data, ctypes.byref(nk)))
     return keep[:nk.value].tolist()
+
+
+def track_det_nms_batch(tracks, dets, offsets, thresh, track_offsets=None):
+    """K independent ``track_det_nms`` problems in ONE call (extension; include/vdet_hip.h: vdet_track_det_nms_batch) -- the
+    reference's per-tracked-box pattern of vdet/track.py:236-250, where the boxes of a tracklet sit on different frames.
+    Problem k = ``track_det_nms(tracks[to[k]:to[k+1]], dets[offsets[k]:offsets[k+1]], thresh)``; without ``track_offsets``
+    problem k has the ONE track row ``tracks[k]``.  Returns (keep, counts): int64 arrays; problem k's kept positions (inside
+    its own rows, descending score) are ``keep[offsets[k] : offsets[k] + counts[k]]``."""
+    t = _as_f32_2d(tracks, 'tracks', 5)
+    d = _as_f32_2d(dets, 'dets', 6)
+    th = _thresh(thresh)
+    off = np.ascontiguousarray(offsets, dtype=np.int64).reshape(-1)
+    K = off.size - 1
+    if K < 0 or off[0] != 0 or off[-1] != d.shape[0] or np.any(np.diff(off) < 0):
+        raise ValueError("offsets must run 0 = o[0] <= o[1] <= ... <= o[K] = len(dets)")
+    toff = None
+    if track_offsets is not None:
+        toff = np.ascontiguousarray(track_offsets, dtype=np.int64).reshape(-1)
+        if toff.size != K + 1 or toff[0] != 0 or toff[-1] != t.shape[0] or np.any(np.diff(toff) < 0):
+            raise ValueError("track_offsets must run 0 = o[0] <= ... <= o[K] = len(tracks)")
+    elif t.shape[0] != K:
+        raise ValueError("one track row per problem (or pass track_offsets)")
+    keep = np.empty(max(d.shape[0], 1), dtype=np.int64)
+    counts = np.zeros(max(K, 1), dtype=np.int64)
+    if K == 0 or d.shape[0] == 0:
+        return keep[:0] if d.shape[0] == 0 else keep, counts[:K]
+    ctx = _lib.get_context()
+    ctx.reset_stream()
+    ldt = t.strides[0] // 4 if t.shape[0] > 1 else max(t.shape[1], 5)
+    ldd = d.strides[0] // 4 if d.shape[0] > 1 else d.shape[1]
+    ctx.check(ctx.lib.vdet_track_det_nms_batch(ctx.h, t.ctypes.data if t.shape[0] else None, toff.ctypes.data if toff is not None else None,
+                                               ldt, d.ctypes.data, off.ctypes.data, K, ldd, th, keep.ctypes.data, counts.ctypes.data))
+    return keep, counts[:K]

@@ -1,5 +1,6 @@
 """tic/toc timer with the attributes T-CNN scripts read (reference utils/timer.py:10-32): ``total_time``, ``calls``,
-``start_time``, ``diff`` (the last interval) and ``average_time`` (derived: total_time / calls, 0 before the first toc);
+``start_time``, ``diff`` (the last interval) and ``average_time`` (a plain attribute like the reference's, assigned by
+``toc`` = total_time / calls, 0 after ``reset``: scripts may set it, copy it or pickle the timer through ``__dict__``);
 ``toc(average=True)`` returns the running average, ``toc(False)`` the last interval."""
 import time
 
@@ -9,12 +10,8 @@ class Timer(object):
         self.reset()
 
     def reset(self):
-        self.total_time = self.start_time = self.diff = 0.0
+        self.total_time = self.start_time = self.diff = self.average_time = 0.0
         self.calls = 0
-
-    @property
-    def average_time(self):
-        return self.total_time / self.calls if self.calls else 0.0
 
     def tic(self):
         self.start_time = time.time()      # (wall clock, like the reference: intervals may span threads)
@@ -23,4 +20,5 @@ class Timer(object):
         self.diff = time.time() - self.start_time
         self.total_time += self.diff
         self.calls += 1
+        self.average_time = self.total_time / self.calls
         return self.average_time if average else self.diff

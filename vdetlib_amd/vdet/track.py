@@ -11,7 +11,7 @@ from collections import defaultdict
 
 import numpy as np
 
-from ..utils.cython_nms import track_det_nms
+from ..utils.cython_nms import track_det_nms, track_det_nms_batch     # noqa: F401 (track_det_nms: the reference's import)
 from ..utils.log import logger as logging
 
 
@@ -60,19 +60,60 @@ def _run_tracker(track_method, vid_proto, anchor_frame_id, anchor_bbox, opts):
 def _prune_frame_dets(tracklets, rows_of_frame, alive, det_rows, nms_thres):
     """What a new track explains goes (reference :170-184 / :236-250): for every box of every new tracklet, the still-alive
     detections of that box's frame are put through ``track_det_nms`` against the box; whatever it does not return is dead.
+    The reference makes one call per box; the boxes of a tracklet sit on different frames, so their problems are independent
+    and run as ONE ``vdet_track_det_nms_batch`` call (one launch, one host wait).  A frame that comes up a second time (a
+    tracker returning overlapping tracklets) depends on the first visit's result: the batch collected so far is flushed first,
+    which keeps the reference's sequential order exactly.
     ``rows_of_frame``: frame id -> row numbers of that frame (ascending = descending score); ``alive`` is updated in place."""
+    pending, in_batch = [], set()
+
+    def flush():
+        lives, track_rows = [], []
+        for frame, bbox, rows in pending:
+            live = rows[alive[rows]]
+            if live.size:
+                lives.append(live)
+                track_rows.append([frame] + list(bbox))
+        del pending[:]
+        in_batch.clear()
+        if not lives:
+            return
+        sizes = np.fromiter(map(len, lives), dtype=np.int64, count=len(lives))
+        off = np.zeros(len(lives) + 1, dtype=np.int64)
+        np.cumsum(sizes, out=off[1:])
+        cat = np.concatenate(lives)
+        keep, counts = track_det_nms_batch(np.asarray(track_rows, dtype=np.float32), det_rows[cat], off, nms_thres)
+        start = np.repeat(off[:-1], sizes)                        # first row of every row's problem
+        kept = (np.arange(cat.size) - start) < np.repeat(counts, sizes)     # entry q of problem k is a kept position iff q < counts[k]
+        alive[cat] = False
+        alive[cat[(keep[:cat.size] + start)[kept]]] = True
+
     for tracklet in tracklets:
         for box in tracklet:
-            rows = rows_of_frame.get(box['frame'])
+            frame = box['frame']
+            rows = rows_of_frame.get(frame)
             if rows is None:
                 continue
-            live = rows[alive[rows]]
-            if live.size == 0:
-                continue
-            track_row = np.asarray([[box['frame']] + list(box['bbox'])], dtype=np.float32)
-            survivors = np.asarray(track_det_nms(track_row, det_rows[live], nms_thres), dtype=np.int64)   # positions inside ``live``
-            alive[live] = False
-            alive[live[survivors]] = True
+            if frame in in_batch:
+                flush()
+            in_batch.add(frame)
+            pending.append((frame, box['bbox'], rows))
+    flush()
+
+
+def _rows_by_frame(frame_keys):
+    """{frame key: ascending row numbers of that frame} (the reference's ``frame_to_det_ids``, :203-205 / :137-139)."""
+    keys = np.asarray(frame_keys)
+    if keys.ndim == 1 and keys.size and keys.dtype.kind in 'iuf' and not (keys.dtype.kind == 'f' and np.isnan(keys).any()):
+        uniq, inv = np.unique(keys, return_inverse=True)
+        order = np.argsort(inv, kind='stable')
+        bounds = np.searchsorted(inv[order], np.arange(len(uniq) + 1))
+        # python numbers as keys: 5.0 == 5 and hash(5.0) == hash(5), so a tracklet's int frame id finds a float32 frame column
+        return {uniq[k].item(): order[bounds[k]:bounds[k + 1]] for k in range(len(uniq))}
+    positions = defaultdict(list)          # (frame ids that are not plain numbers: grouped the reference's way)
+    for row, key in enumerate(frame_keys):
+        positions[key].append(row)
+    return {key: np.asarray(rows, dtype=np.int64) for key, rows in positions.items()}
 
 
 def _greedy_loop(vid_proto, det_rows, frame_keys, score_of, anchor_of, track_method, opts):
@@ -83,10 +124,7 @@ def _greedy_loop(vid_proto, det_rows, frame_keys, score_of, anchor_of, track_met
     ``opts.thres``."""
     nms_thres = _nms_thres(opts)
     n = len(det_rows)
-    positions = defaultdict(list)
-    for row, key in enumerate(frame_keys):
-        positions[key].append(row)
-    rows_of_frame = {key: np.asarray(rows, dtype=np.int64) for key, rows in positions.items()}
+    rows_of_frame = _rows_by_frame(frame_keys)
     alive = np.ones(n, dtype=bool)
     scan = 0
     tracks = []
@@ -131,7 +169,7 @@ def greedily_track_from_raw_dets(vid_proto, det_info, track_method, class_idx, o
     order = np.argsort(-sel[:, 5], kind='stable')       # == sorted(..., key=score, reverse=True)
     sel = np.asarray(sel[order], dtype=np.float32)
     tracks = _greedy_loop(
-        vid_proto, sel, [row[0] for row in sel],
+        vid_proto, sel, sel[:, 0],
         lambda i: sel[i][-1],
         lambda i: (int(sel[i][0]), [int(v) for v in sel[i][1:5]]),
         track_method, opts)

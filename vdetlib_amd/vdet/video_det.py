@@ -5,8 +5,11 @@ and the per-class candidate selection of every frame runs on the GPU (``hot.thre
 ``vdet_threshold_topk``; for device-resident score volumes the whole threshold -> top-k -> NMS chain is
 ``ops.nms_volume(..., score_thresh=, topk=)``).  The CNN (``det_fun`` / ``net``) and the image reader are
 external plug-ins, exactly as in the reference."""
+import operator
 import os
 from collections import defaultdict
+from itertools import chain, islice, repeat
+from operator import itemgetter
 
 import numpy as np
 
@@ -17,6 +20,11 @@ from ..utils.log import logger as logging
 from ..utils.timer import Timer
 from ..utils.cython_nms import vid_nms
 from .. import hot
+
+try:                      # host-side marshalling helper (plain C, built by csrc/build.sh); the itertools form below is the same loop
+    from .. import _protofast
+except ImportError:       # pragma: no cover
+    _protofast = None
 
 
 def _by_frame(items):
@@ -60,25 +68,52 @@ def det_vid_score(vid_proto, det_fun, net, box_proto=None, class_names=imagenet_
 
 
 def _vid_nms_rows(detections, class_index):
-    """float32 [N,6] rows (frame, x1,y1,x2,y2, score of ``class_index``) of a det_proto, assembled by column.
-    The class score is looked up BY KEY; a detection without that class scores -inf
-    (utils/protocol.py:323-327)."""
+    """float32 [N,6] rows (frame, x1,y1,x2,y2, score of ``class_index``) of a det_proto, assembled by column with C-level
+    iteration (itemgetter / chain: no python-level loop over the detections).  The class score is ``det_score``'s
+    (utils/protocol.py:323-327): the FIRST entry whose 'class_index' equals ``class_index``, -inf when there is none."""
     n = len(detections)
     rows = np.empty((n, 6), dtype=np.float32)
+    if n and _protofast is not None:     # the same dict reads through the C API (csrc/protofast.c): same keys, same first-match rule
+        _protofast.vid_nms_rows(detections, class_index, rows)
+        return rows
     if n:
-        rows[:, 0] = np.fromiter((d['frame'] for d in detections), dtype=np.float64, count=n)
-        rows[:, 1:5] = np.asarray([d['bbox'] for d in detections], dtype=np.float64).reshape(n, 4)
-        # ``score_proto`` (utils/protocol.py:307-320) lists the classes in index order, so a detection's entry for the class is
-        # normally AT position class_index: one positional pass, checked; the per-detection scan of ``det_score`` otherwise
+        rows[:, 0] = np.fromiter(map(_FRAME, detections), dtype=np.float64, count=n)
         try:
-            entries = [d['scores'][class_index] for d in detections] if class_index >= 0 else None
-        except IndexError:
-            entries = None
-        if entries is not None and all(e['class_index'] == class_index for e in entries):
-            rows[:, 5] = np.fromiter((e['score'] for e in entries), dtype=np.float64, count=n)
+            rows[:, 1:5] = np.fromiter(chain.from_iterable(map(_BBOX, detections)), dtype=np.float64, count=4 * n).reshape(n, 4)
+        except (ValueError, TypeError):      # (a bbox that is not four plain numbers: numpy's own conversion and errors)
+            rows[:, 1:5] = np.asarray([d['bbox'] for d in detections], dtype=np.float64).reshape(n, 4)
+        entries = _positional_entries(detections, class_index)
+        if entries is not None:
+            rows[:, 5] = np.fromiter(map(_SCORE, entries), dtype=np.float64, count=n)
         else:
             rows[:, 5] = np.fromiter((_class_score(d['scores'], class_index) for d in detections), dtype=np.float64, count=n)
     return rows
+
+
+_FRAME, _BBOX, _SCORES, _SCORE, _CLASS_INDEX = (itemgetter(k) for k in ('frame', 'bbox', 'scores', 'score', 'class_index'))
+
+
+def _positional_entries(detections, class_index):
+    """``score_proto`` (utils/protocol.py:307-320) lists the classes in index order, so a detection's entry for class k normally
+    sits AT position k.  Returns those entries when that is ``det_score``'s answer for EVERY detection -- the entry at the
+    position has the class index and no EARLIER entry has it too (first match wins in the reference) -- else None (the caller
+    then scans per detection like the reference)."""
+    try:
+        k = operator.index(class_index)
+    except TypeError:
+        return None
+    if k < 0:
+        return None
+    try:
+        lists = list(map(_SCORES, detections))
+        entries = list(map(itemgetter(k), lists))
+        if not all(map(operator.eq, map(_CLASS_INDEX, entries), repeat(class_index))):
+            return None
+        if k and class_index in map(_CLASS_INDEX, chain.from_iterable(map(islice, lists, repeat(k)))):
+            return None
+    except (IndexError, TypeError, KeyError):
+        return None
+    return entries
 
 
 def _class_score(scores, class_index):
