@@ -479,8 +479,73 @@ def g17_c1_flow(R):
     print('  c1 flow:', {k: round(v, 3) for k, v in best.items()})
 
 
+XMLTODICT_STANDIN = r'''
+"""Stand-in for the third-party `xmltodict` (absent from this image; same status as the cv2 / matlab / easydict stubs of the
+recipe above): parse(text) -> nested dicts with xmltodict's default conventions for the element-only documents of ILSVRC2015-VID
+-- {root tag: content}; an element with children is a dict, repeated child tags become a list, a leaf is its text (None when
+empty).  Built on xml.etree; it exists only so that the REFERENCE's tool can be executed to record its output."""
+import xml.etree.ElementTree as ET
+
+
+def _content(el):
+    kids = list(el)
+    if not kids:
+        text = (el.text or '').strip()
+        return text if text else None
+    out = {}
+    for k in kids:
+        v = _content(k)
+        if k.tag in out:
+            if not isinstance(out[k.tag], list):
+                out[k.tag] = [out[k.tag]]
+            out[k.tag].append(v)
+        else:
+            out[k.tag] = v
+    return out
+
+
+def parse(text):
+    root = ET.fromstring(text)
+    return {root.tag: _content(root)}
+'''
+
+
+def g18_vid_xml(R):
+    """G18 (round 6): the reference's OWN tools/imagenet_annotation_processor.py (:53-118, a script: everything runs under
+    `__main__`) executed on the committed VID-style XML directory; its .annot is recorded as
+    tests/golden/vid_xml/<video>.reference.annot.  The tool imports `xmltodict` (:6), which this image lacks: it runs on the
+    xml.etree stand-in above (written to the /tmp stub directory next to the cv2 / easydict stubs), so what is pinned is the
+    tool's own logic -- frame = int(filename) + 1, tracks in order of first appearance, the object / no-object / single-object
+    branches, the field set and types -- not xmltodict's parser.  `glob.glob` is forced to sorted order for the run (the
+    reference takes whatever order the file system lists; sorted is one such order and the build's rule)."""
+    import glob
+    import runpy
+    with open(os.path.join(O, 'stubs', 'xmltodict.py'), 'w') as f:
+        f.write(XMLTODICT_STANDIN)
+    src = os.path.join(HERE, 'vid_xml')
+    tool = os.path.join(O, 'py3', 'vdetlib', 'tools', 'imagenet_annotation_processor.py')
+    real_glob, argv = glob.glob, sys.argv
+    for vid in sorted(d for d in os.listdir(src) if os.path.isdir(os.path.join(src, d))):
+        with tempfile.TemporaryDirectory() as tmp:
+            save = os.path.join(tmp, 'out', vid + '.annot')
+            glob.glob = lambda pat, **kw: sorted(real_glob(pat, **kw))
+            sys.argv = [tool, os.path.join(src, vid), save]
+            try:
+                runpy.run_path(tool, run_name='__main__')
+            finally:
+                glob.glob, sys.argv = real_glob, argv
+            with open(save) as f:
+                text = f.read()
+        with open(os.path.join(src, vid + '.reference.annot'), 'w') as f:
+            f.write(text)
+        print('  vid_xml:', vid, len(json.loads(text)['annotations']), 'tracks')
+
+
 def main():
     R = load_reference()
+    if '--xml-only' in sys.argv:
+        g18_vid_xml(R)
+        return
     if '--c1-only' in sys.argv:
         g17_c1_flow(R)
         return
@@ -509,6 +574,7 @@ def main():
     g15_exotic(R)
     g16_mat(R)
     g17_c1_flow(R)
+    g18_vid_xml(R)
     for fn in sorted(os.listdir(HERE)):
         print('%8d  %s' % (os.path.getsize(os.path.join(HERE, fn)), fn))
 

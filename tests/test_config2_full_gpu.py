@@ -183,7 +183,8 @@ def test_full_volume_fallback_paths_equal_the_default(full_run, monkeypatch):
 def test_full_volume_reference_generator_inputs(oracle, tmp_path):
     """BASELINE.md section 3's host generator at full size: RandomState(1000 * config + video) = RandomState(2000), integer
     boxes, scores tie-free per (frame, class) -- on such lists the build's order IS the reference's (its argsort has no
-    ties to break, utils/nms.pyx:25).  NMS survivors of every 7th frame x all classes, tubelets + re-scoring of 4 classes."""
+    ties to break, utils/nms.pyx:25).  This is the video `python bench.py` times: the WHOLE of it is checked (round 6) -- the
+    NMS survivors of all 300 frames x 200 classes, both temporal outputs on every box, all tubelets + re-scoring of 24 classes."""
     import torch
     import oracle_pool
     from vdetlib_amd import ops, _lib
@@ -196,14 +197,19 @@ def test_full_volume_reference_generator_inputs(oracle, tmp_path):
     del srt
     cx = _lib.Context(dev.index)
     cx.set_cache(True)
+    pooled, conv = ops.volume_pass(scores, 3, TAPS, ctx=cx)               # the bench's step, call for call
     keep_idx, keep_cnt, tracks, anchors, ntracks = ops.nms_track_volume(
         boxes, scores, nms_thres=0.3, thres=0.9, max_tracks=10, link_thres=0.5, cap=2048, ctx=cx)
     det, tpool, tboxes = ops.rescore_tracks(tracks, ntracks, boxes, scores, overlap_thres=0.7, window=3, ctx=cx)
-    frames = list(range(0, F, 7))
-    nthr = max(1, len(os.sched_getaffinity(0)))
-    widx, wcnt = oracle.nms_volume(boxes[frames].cpu().numpy(), scores[frames].contiguous().cpu().numpy(), 0.3, cap=2048, threads=nthr)
-    assert np.array_equal(keep_cnt[frames].cpu().numpy(), wcnt) and np.array_equal(keep_idx[frames].cpu().numpy(), widx)
-    classes = [3, 77, 150, 199]
+    r = dict(boxes=boxes, scores=scores, keep_idx=keep_idx, keep_cnt=keep_cnt)
+    mean = _check_nms_all_frames(r, oracle)                               # all 60 000 lists
+    assert 1000 < mean < 2048
+    for b0 in range(0, B, 1000):                                          # both temporal outputs on every box
+        hs = scores[:, b0:b0 + 1000].contiguous().cpu().numpy()
+        assert np.array_equal(pooled[:, b0:b0 + 1000].cpu().numpy(), oracle.temporal_maxpool(hs, 3)), b0
+        np.testing.assert_allclose(conv[:, b0:b0 + 1000].cpu().numpy(), oracle.temporal_conv(hs, TAPS, 0.0, 0.0), rtol=0, atol=1e-6)
+    del pooled, conv
+    classes = [0, 199] + list(range(3, C, 9))[:22]
     hb = boxes.cpu().numpy()
     cols = {c: scores[:, :, c].contiguous().cpu().numpy() for c in classes}
     want = oracle_pool.rescored_tubelets_per_class(hb, cols, dict(nms_thres=0.3, thres=0.9, max_tracks=10, link_thres=0.5, pool_thres=0.7,

@@ -181,17 +181,18 @@ def test_bench_reference_stream_generator_is_synth_video():
 def test_annotation_processor_on_committed_vid_xml(tmp_path):
     """Four ILSVRC2015-VID style XML files (tests/golden/vid_xml: the dataset's own layout -- folder / filename / source /
     size / object{trackid, name, bndbox{xmax, xmin, ymax, ymin}, occluded, generated}, one file without objects, tracks
-    that start late and interleave) against ILSVRC2015_val_00007000.expected.annot.
-    PINNING STATUS: the expectation was written by hand from the reference's rules
-    (tools/imagenet_annotation_processor.py:53-118: frame = int(filename) + 1, tracks in order of first appearance, bbox
-    [xmin, ymin, xmax, ymax] as ints, frame_size [height, width], json indent=2), NOT produced by running the reference: its
-    module imports `xmltodict` at the top (:6), which this image does not have, and the rules forbid a stand-in.  The build
-    reads the files in sorted name order (the reference takes glob's order, which is the filesystem's)."""
+    that start late and interleave) against ILSVRC2015_val_00007000.reference.annot.
+    PINNING STATUS (round 6): that file is the OUTPUT OF THE REFERENCE'S OWN TOOL (tools/imagenet_annotation_processor.py:53-118,
+    run by tests/golden/make_golden.py --xml-only on these XML files).  The tool imports the third-party `xmltodict` (:6), which
+    this image lacks; the run used an xml.etree stand-in for `xmltodict.parse` placed in the /tmp stub directory (same status as
+    the cv2 / matlab / easydict stubs of the golden recipe), so the pin covers the tool's logic -- frame = int(filename) + 1,
+    tracks in order of first appearance, single / several / no objects, field set, types, json indent=2 -- not xmltodict's
+    parser.  The reference reads the files in glob's (file-system) order; the recorded run and the build use sorted order."""
     src = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'vid_xml')
     d = os.path.join(src, 'ILSVRC2015_val_00007000')
-    want = json.load(open(os.path.join(src, 'ILSVRC2015_val_00007000.expected.annot')))
+    want = json.load(open(os.path.join(src, 'ILSVRC2015_val_00007000.reference.annot')))
     assert iap.annot_proto_from_dir(d) == want
     out = tmp_path / 'a' / 'v.annot'
     assert iap.main([d, str(out)]) == 0
-    assert open(out).read() == open(os.path.join(src, 'ILSVRC2015_val_00007000.expected.annot')).read()      # byte for byte (indent=2)
+    assert open(out).read() == open(os.path.join(src, 'ILSVRC2015_val_00007000.reference.annot')).read()      # byte for byte (indent=2)
     assert [t['id'] for t in want['annotations']] == ['0', '1', '2'] and want['annotations'][1]['track'][0]['frame'] == 2
