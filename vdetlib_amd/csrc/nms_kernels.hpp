@@ -754,8 +754,11 @@ __global__ __launch_bounds__(ROWS) void adj_build_kernel(const float4 *__restric
                                                         unsigned long long pool_cap, int *__restrict__ status,
                                                         const uint32_t *__restrict__ group_flags,
                                                         const FrameIndex ix, float one_minus_t, int pool_bits,
-                                                        WalkMeta *__restrict__ wmeta, const float2 *__restrict__ reach_table)
+                                                        WalkMeta *__restrict__ wmeta, const float2 *__restrict__ reach_table,
+                                                        int skip_regular)
 {
+    // (skip_regular: the regular groups of this launch are adj_rows_kernel's, adjrows_kernels.hpp -- block-uniform exit)
+    if (skip_regular && group_flags && (group_flags[tiles[ROWS == kAdjRows ? (blockIdx.x >> 1) : blockIdx.x].group] & kFlagRegular)) return;
     __shared__ float2 srt[kMaxWordRows];       // regular group: its reach table (which words of a row were written at all)
     __shared__ uint32_t sscan[8];
     __shared__ unsigned long long sbase;

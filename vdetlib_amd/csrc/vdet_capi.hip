@@ -19,6 +19,7 @@
 #include "small_kernels.hpp"
 #include "detnms_kernels.hpp"
 #include "fused_kernels.hpp"
+#include "adjrows_kernels.hpp"
 #include "temporal_kernels.hpp"
 #include "tubelet_kernels.hpp"
 #include "track_kernels.hpp"
@@ -130,6 +131,7 @@ struct vdet_ctx {
     bool force_general = false;   // VDET_FORCE_GENERAL=1: the general predicate kernel K1 on every frame (the irregular-frame path)
     bool atomic_rank = false;     // LDS returning atomics serve same-address lanes in lane order (probed; VDET_ATOMIC_RANK=0: ballot match)
     bool small_lists = true;      // VDET_SMALL_LISTS=0: frames of <= 384 boxes through the large-list sort and walk too (small_kernels.hpp)
+    bool adj_rows = true;         // VDET_ADJ_ROWS=0: adj_build_kernel (a lane per row) also for the regular frames of large volumes
     bool no_fused = false;        // VDET_NO_FUSED=1: the host-buffer calls of <= 640 rows through the general kernel chain too (the path of larger inputs)
     bool binsort = true;          // VDET_BINSORT=0: the LSD radix kernel (the fallback of tied / thresholded columns) for every column
     const std::vector<GroupDesc> *host_groups = nullptr;   // group table of the call in flight (mode 2)
@@ -476,6 +478,7 @@ int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32, doub
             {
                 StageTimer tm(c, ST_ADJ);
                 const bool k2_tile = pl.nmax <= 384;      // small frames: one block per tile
+                const bool rows_path = use_sym && c->adj_rows && !k2_tile;
                 hipLaunchKernelGGL(k2_tile ? adj_build_kernel<kRowsPerTile> : adj_build_kernel<kAdjRows>, dim3(k2_tile ? nt : 2 * nt),
                                    dim3(k2_tile ? kRowsPerTile : kAdjRows), 0, c->stream, d_boxes,
                                    c->groups.as<GroupDesc>(), c->tiles.as<TileDesc>() + bt.first,
@@ -485,7 +488,14 @@ int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32, doub
                                    use_sym ? frame_index_of(c) : FrameIndex{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0}, one_minus_t,
                                    async ? (kStPool | kStPoolAsync) : kStPool,
                                    c->wmeta_built ? c->wmeta.as<WalkMeta>() : (WalkMeta *)nullptr,
-                                   use_sym ? c->reachtab.as<float2>() : (const float2 *)nullptr);
+                                   use_sym ? c->reachtab.as<float2>() : (const float2 *)nullptr, rows_path ? 1 : 0);
+                // regular groups of large frames: one workgroup per 64-row strip, half a wave per row (adjrows_kernels.hpp)
+                if (rows_path)
+                    hipLaunchKernelGGL(adj_rows_kernel, dim3(4 * nt), dim3(256), 0, c->stream, c->groups.as<GroupDesc>(),
+                                       c->tiles.as<TileDesc>() + bt.first, bits_b, c->rowz.as<uint32_t>(), c->rowmeta.as<uint2>(),
+                                       c->adj.as<uint16_t>(), &c->d_cnt->pool_used, pool_cap, &c->d_cnt->status, c->gflags.as<uint32_t>(),
+                                       c->xbox.as<float4>(), c->xord.as<uint16_t>(), async ? (kStPool | kStPoolAsync) : kStPool,
+                                       c->wmeta_built ? c->wmeta.as<WalkMeta>() : (WalkMeta *)nullptr, c->reachtab.as<float2>());
             }
         }
         HIPCHK(c, hipGetLastError());
@@ -1036,6 +1046,7 @@ int vdet_create(vdet_ctx **out, int device)
     if (const char *e = getenv("VDET_NO_INDEX")) c->no_index = atoi(e) != 0;
     if (const char *e = getenv("VDET_NO_LAZY")) c->no_lazy = atoi(e) != 0;
     if (const char *e = getenv("VDET_NO_FUSED")) c->no_fused = atoi(e) != 0;
+    if (const char *e = getenv("VDET_ADJ_ROWS")) c->adj_rows = atoi(e) != 0;
     if (const char *e = getenv("VDET_BINSORT")) c->binsort = atoi(e) != 0;
     if (const char *e = getenv("VDET_SMALL_LISTS")) c->small_lists = atoi(e) != 0;
     {   // probe: do returning LDS atomics resolve same-address lanes in ascending lane order?
