@@ -34,10 +34,58 @@ constexpr int kRowsChunk = 16;      // existing words staged per pass
 constexpr int kRowsStage = 8192;    // u16 entries of the strip's slab staged in LDS (16 KB; 64 lists of ~104 entries at config 2)
 constexpr int kRowsStride = 72;     // u64 words between two staged words: 64 rows + padding (lane (a, b) of a step reads bank 16 a + 2 b)
 
+// Where every strip's slab starts, WITHOUT an atomic per strip: with one returning atomicAdd on the pool counter per block, the
+// ~1 300 resident blocks queue on ONE address of the L2's atomic unit (~13 ns each, measured: a strip's block sat 16 of its 22 us
+// in that queue -- 0.61 of the kernel's 0.88 ms per video were its start-up).  strip_totals_kernel sums the padded list lengths
+// of every strip of the launch (degrees are final once iou_bits_sym_kernel is done), strip_scan_kernel -- one block -- turns them
+// into offsets behind ONE reservation, and the lists of a video land at reproducible places.
+__global__ __launch_bounds__(256) void strip_totals_kernel(const GroupDesc *__restrict__ groups, const TileDesc *__restrict__ tiles,
+                                                           int nstrips, const uint32_t *__restrict__ row_deg,
+                                                           const uint32_t *__restrict__ group_flags, uint32_t *__restrict__ totals)
+{
+    const int lane = threadIdx.x & 63;
+    const int sidx = blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (sidx >= nstrips) return;
+    const TileDesc td = tiles[sidx >> 2];
+    const GroupDesc gd = groups[td.group];
+    const int v = (td.row_tile * (kRowsPerTile / 64) + (sidx & 3)) * 64 + lane;
+    uint32_t t = 0u;
+    if ((group_flags[td.group] & kFlagRegular) && v < gd.nbox) t = (row_deg[gd.box_off + v] + 7u) & ~7u;
+    t = wave_incl_scan_u32(t);
+    if (lane == 63) totals[sidx] = t;
+}
+
+__global__ __launch_bounds__(1024) void strip_scan_kernel(const uint32_t *__restrict__ totals, int n, unsigned long long *__restrict__ offsets,
+                                                          unsigned long long *__restrict__ pool_used)
+{
+    __shared__ unsigned long long wsum[16];
+    __shared__ unsigned long long sbase;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int per = (n + 1023) / 1024;
+    const int i0 = tid * per, i1 = min(n, i0 + per);
+    unsigned long long sum = 0ull;
+    for (int i = i0; i < i1; ++i) sum += totals[i];
+    unsigned long long incl = sum;
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long o = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long run = 0ull;
+        for (int k = 0; k < 16; ++k) { const unsigned long long x = wsum[k]; wsum[k] = run; run += x; }
+        sbase = atomicAdd(pool_used, run);
+    }
+    __syncthreads();
+    unsigned long long run = sbase + wsum[w] + incl - sum;
+    for (int i = i0; i < i1; ++i) { offsets[i] = run; run += totals[i]; }
+}
+
 __global__ __launch_bounds__(256) void adj_rows_kernel(const GroupDesc *__restrict__ groups, const TileDesc *__restrict__ tiles,
                                                        const uint64_t *__restrict__ bits, const uint32_t *__restrict__ row_deg,
                                                        uint2 *__restrict__ row_meta, uint16_t *__restrict__ adj,
-                                                       unsigned long long *__restrict__ pool_used, unsigned long long pool_cap,
+                                                       const unsigned long long *__restrict__ slab_off, unsigned long long pool_cap,
                                                        int *__restrict__ status, const uint32_t *__restrict__ group_flags,
                                                        const float4 *__restrict__ xbox_all, const uint16_t *__restrict__ xord_all,
                                                        int pool_bits, WalkMeta *__restrict__ wmeta, const float2 *__restrict__ reach_table)
@@ -67,6 +115,8 @@ __global__ __launch_bounds__(256) void adj_rows_kernel(const GroupDesc *__restri
     uint32_t deg = 0u;
     int vo = 0;
     float4 bx = make_float4(0.f, 0.f, 0.f, 0.f);
+    unsigned long long sbase0 = 0ull;
+    if (w == 1) sbase0 = slab_off[blockIdx.x];
     if (w == 1 && v < B) {
         deg = row_deg[gd.box_off + v];
         vo = (int)tr[v];
@@ -81,10 +131,7 @@ __global__ __launch_bounds__(256) void adj_rows_kernel(const GroupDesc *__restri
         const uint32_t tot_al = (deg + 7u) & ~7u;
         const uint32_t incl = wave_incl_scan_u32(tot_al);
         const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        unsigned long long base = 0ull;
-        if (lane == 63) base = atomicAdd(pool_used, (unsigned long long)total);
-        base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(base >> 32), 63) << 32) |
-               (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)base, 63);
+        const unsigned long long base = sbase0;                 // strip_scan_kernel: no atomic here
         const bool over = base + total > pool_cap || base + total > 0xFFFFFFFFull;
         if (over && lane == 0) atomicOr(status, pool_bits);
         const uint32_t p = over ? 0u : (uint32_t)base + incl - tot_al;

@@ -103,7 +103,7 @@ struct vdet_ctx {
     int n_cu = 256;
     // scratch
     DevBuf boxes, scores, keys, excl, frames, groups, tiles, bits, rowz, rowmeta, groupz, adj, comp, origidx,
-        out64, trk_frames, trk_boxes, b1, b2, iou_out, order, ncand, keepidx, keepcnt, gflags, pairs, tkeys, tstate, visited, heads, xkeys, xord, wmeta, reachtab, xncand, xbox, xbox16, xord16, xcum, xinfo, tmp[8];
+        out64, trk_frames, trk_boxes, b1, b2, iou_out, order, ncand, keepidx, keepcnt, gflags, pairs, tkeys, tstate, visited, heads, xkeys, xord, wmeta, reachtab, striptot, stripoff, xncand, xbox, xbox16, xord16, xcum, xinfo, tmp[8];
     // timing
     bool timing = false;
     bool timing_accumulate = false;   // vdet_set_timing(ctx, 2): keep events across calls until read
@@ -490,12 +490,21 @@ int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32, doub
                                    c->wmeta_built ? c->wmeta.as<WalkMeta>() : (WalkMeta *)nullptr,
                                    use_sym ? c->reachtab.as<float2>() : (const float2 *)nullptr, rows_path ? 1 : 0);
                 // regular groups of large frames: one workgroup per 64-row strip, half a wave per row (adjrows_kernels.hpp)
-                if (rows_path)
+                if (rows_path) {
+                    // every strip's slab offset first (two small launches instead of an atomic per strip on one address)
+                    HIPCHK(c, c->striptot.reserve((size_t)4 * nt * 4));
+                    HIPCHK(c, c->stripoff.reserve((size_t)4 * nt * 8));
+                    hipLaunchKernelGGL(strip_totals_kernel, dim3(nt), dim3(256), 0, c->stream, c->groups.as<GroupDesc>(),
+                                       c->tiles.as<TileDesc>() + bt.first, 4 * nt, c->rowz.as<uint32_t>(), c->gflags.as<uint32_t>(),
+                                       c->striptot.as<uint32_t>());
+                    hipLaunchKernelGGL(strip_scan_kernel, dim3(1), dim3(1024), 0, c->stream, c->striptot.as<uint32_t>(), 4 * nt,
+                                       c->stripoff.as<unsigned long long>(), &c->d_cnt->pool_used);
                     hipLaunchKernelGGL(adj_rows_kernel, dim3(4 * nt), dim3(256), 0, c->stream, c->groups.as<GroupDesc>(),
                                        c->tiles.as<TileDesc>() + bt.first, bits_b, c->rowz.as<uint32_t>(), c->rowmeta.as<uint2>(),
-                                       c->adj.as<uint16_t>(), &c->d_cnt->pool_used, pool_cap, &c->d_cnt->status, c->gflags.as<uint32_t>(),
+                                       c->adj.as<uint16_t>(), c->stripoff.as<unsigned long long>(), pool_cap, &c->d_cnt->status, c->gflags.as<uint32_t>(),
                                        c->xbox.as<float4>(), c->xord.as<uint16_t>(), async ? (kStPool | kStPoolAsync) : kStPool,
                                        c->wmeta_built ? c->wmeta.as<WalkMeta>() : (WalkMeta *)nullptr, c->reachtab.as<float2>());
+                }
             }
         }
         HIPCHK(c, hipGetLastError());
@@ -1119,7 +1128,7 @@ int vdet_destroy(vdet_ctx *c)
                       &c->rowz, &c->rowmeta, &c->groupz, &c->adj, &c->comp, &c->origidx, &c->out64,
                       &c->trk_frames, &c->trk_boxes, &c->b1, &c->b2, &c->iou_out, &c->order, &c->ncand, &c->keepidx,
                       &c->keepcnt, &c->gflags, &c->pairs, &c->tkeys, &c->tstate, &c->visited, &c->heads, &c->xkeys, &c->xord, &c->xncand, &c->linkmemo, &c->linkstats, &c->linkwarm, &c->linkorder, &c->linkchains, &c->linknodes, &c->tracknode, &c->rtodo,
-                      &c->xbox, &c->xbox16, &c->xord16, &c->xcum, &c->xinfo, &c->wmeta, &c->reachtab, &c->sortctl, &c->segtab, &c->vidtab, &c->nover, &c->ordncand};
+                      &c->xbox, &c->xbox16, &c->xord16, &c->xcum, &c->xinfo, &c->wmeta, &c->reachtab, &c->striptot, &c->stripoff, &c->sortctl, &c->segtab, &c->vidtab, &c->nover, &c->ordncand};
     for (DevBuf *b : bufs) b->release();
     for (DevBuf &b : c->tmp) b.release();
     for (auto &e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
