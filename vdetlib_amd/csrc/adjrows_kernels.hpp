@@ -14,9 +14,13 @@
 //   * the strip's 64 lists are built in a 16 KB LDS stage at their offsets inside the strip's slab and leave in one coalesced copy
 //     (a slab that does not fit -- a frame several times denser than config 2 -- is written entry by entry).
 // Measured on the way (config-2 video, ms per video; adj_build_kernel 1.38): half a wave per row, lane = word, places from a DPP
-// prefix sum, entries stored straight to the pool 1.17; words of similar density per step (above), still straight to the pool
-// 1.24 -- both bound by the ~1 000 partial-line write requests per wave and pass, not by their loops; with the LDS stage: see
-// DESIGN section 7.
+// prefix sum, entries stored straight to the pool 1.17; words of similar density per step, still straight to the pool 1.24 (both
+// bound by ~1 000 partial-line write requests per wave and pass); + the LDS stage 0.97; + the block's start-up loads in one go,
+// two entries per turn 0.91; + a strip's words in one round trip 0.93; + slab offsets from a pre-pass instead of an atomic per
+// strip 0.86 (+ 0.09 for the pre-pass).  One block per 256-row TILE, strips one after the other with the next strip's words in
+// flight: 1.48 (a quarter of the blocks, the same number of atomics).  Where the 0.86 go (timing experiments: an extra launch
+// with a piece left out in front of the real one): start-up 0.10, word loads + staging + barriers 0.37 (2.1 GB of existing words
+// at 5.5 TB/s: the HBM floor of reading the bit matrix), the bit loops 0.29, the copy-out 0.06.
 // 32 KB of LDS per block: 5 blocks (20 waves) per CU.  List order inside a row differs from adj_build_kernel's (lists are sets: the
 // walk ORs them into a mask, the re-scoring scans them with an index tie-break); offsets, degrees, padding (multiples of 8
 // entries, copies of an entry of the list) and the walk's records are the same.  Row degrees come from iou_bits_sym_kernel's
