@@ -177,26 +177,48 @@ def sharded_core(args, torch, dist, vdist, dev, local, world, rank, V, steps, wa
             return {"v": v, "tub": tub, "anchors": an.reshape(C * T, 3), "ntracks": nt, "kept": kept, "kcnt": kc.reshape(Fv * C)}
 
     exch_ms = []
+    # The exchange: ROUNDS of one fixed-capacity all-gather (vdist.PackedExchange).  Round j carries every rank's j-th video; a
+    # record = header + the video's five result arrays back to back, capacity = the longest video of the run, so a round needs no
+    # count exchange and no host wait: it is enqueued on a side stream the moment the video's results exist and travels while the
+    # rank's streams compute the next videos.  Only the last round of a pass can be exposed (reported: exposed_ms).
+    do_x = world > 1 or force_x
+    rounds = max(len(o) for o in owned)
+    fcap = max(frames)
+    FIELDS = (("tub", torch.float32, lambda Fv: C * T * Fv * 10), ("anchors", torch.float32, lambda Fv: C * T * 3), ("ntracks", torch.int32, lambda Fv: C),
+              ("kept", torch.int32, lambda Fv: Fv * C * TOPK), ("kcnt", torch.int32, lambda Fv: Fv * C))
+    nbytes = lambda Fv: [fn(Fv) * 4 for _, _, fn in FIELDS]
+    xch = vdist.PackedExchange(sum((n + 15) // 16 * 16 for n in nbytes(fcap)), rounds, dev, force=force_x) if do_x else None
+    if xch is not None:
+        for j in range(rounds):
+            if j < len(mine):
+                xch.set_record(j, mine[j], frames[mine[j]], nbytes(frames[mine[j]]))
+            else:
+                xch.set_record(j, -1, 0, [])
 
     def one_pass(exchange=True):
-        res = [process(v, i % nstreams) for i, v in enumerate(mine)]
+        res = []
+        for j in range(rounds):
+            k = j % nstreams
+            if j < len(mine):
+                r = process(mine[j], k)
+                res.append(r)
+                if exchange and xch is not None:
+                    with torch.cuda.stream(streams[k]):
+                        xch.pack(j, [r["tub"], r["anchors"], r["ntracks"].to(torch.int32), r["kept"], r["kcnt"]])
+            if exchange and xch is not None:
+                ev = torch.cuda.Event()
+                ev.record(streams[k])
+                xch.launch(j, ev)
         for s_ in streams:
             torch.cuda.current_stream().wait_stream(s_)
         out = None
-        if exchange and (world > 1 or force_x):
+        if exchange and xch is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            cat = (lambda key, shape: torch.cat([r[key] for r in res], 0) if res else torch.zeros(shape, device=dev))
-            meta = torch.tensor([[r["v"], frames[r["v"]]] for r in res], dtype=torch.int64, device=dev).reshape(-1, 2)
-            out = {"meta": vdist.all_gather_ragged(meta, force=force_x),
-                   "tub": vdist.all_gather_ragged(cat("tub", (0, 10)), force=force_x),
-                   "anchors": vdist.all_gather_ragged(cat("anchors", (0, 3)), force=force_x),
-                   "ntracks": vdist.all_gather_ragged(cat("ntracks", (0,)).to(torch.int32), force=force_x),
-                   "kept": vdist.all_gather_ragged(cat("kept", (0, TOPK)), force=force_x),
-                   "kcnt": vdist.all_gather_ragged(cat("kcnt", (0,)), force=force_x)}
-            e1.record()
+            e0.record()          # every video of the pass is computed ...
+            xch.join()
+            e1.record()          # ... and every round has arrived: what lies between is the exchange NOT hidden behind compute
             exch_ms.append((e0, e1))
-            out["bytes"] = sum(r[k].numel() * r[k].element_size() for r in res for k in ("tub", "anchors", "ntracks", "kept", "kcnt"))
+            out = {"bytes": sum(r[k].numel() * r[k].element_size() for r in res for k in ("tub", "anchors", "ntracks", "kept", "kcnt"))}
         return res, out
 
     def fence():
@@ -234,25 +256,29 @@ def sharded_core(args, torch, dist, vdist, dev, local, world, rank, V, steps, wa
         xinfo, protos, oracle_check = None, None, None
         if gathered is not None:
             xms = [a.elapsed_time(b) for a, b in exch_ms]
-            got = sorted(int(m[0]) for part in gathered["meta"] for m in part.tolist())
-            xinfo = {"exchange_ms": sum(xms) / len(xms), "exchange_ms_max": max(xms), "payload_bytes_per_rank": gathered["bytes"],
-                     "backend": dist.get_backend(), "world": dist.get_world_size(), "videos_gathered": len(got),
-                     "all_videos_present": got == list(range(V))}
+            heads = [[xch.record_of(j, r_)[0] for r_ in range(xch.world)] for j in range(rounds)]
+            got = sorted(int(h[0]) for row in heads for h in row if h[0] >= 0)
+            xinfo = {"exposed_ms": sum(xms) / len(xms), "exposed_ms_max": max(xms), "exchange_ms": sum(xms) / len(xms),
+                     "payload_bytes_per_rank": gathered["bytes"], "padded_bytes_per_rank": rounds * xch.cap, "rounds": rounds,
+                     "record_capacity_bytes": xch.cap, "backend": dist.get_backend(), "world": dist.get_world_size(),
+                     "videos_gathered": len(got), "all_videos_present": got == list(range(V)),
+                     "how": "one fixed-capacity all_gather_into_tensor per round (every rank's j-th video), enqueued on a side stream when the "
+                            "video's results exist; exposed_ms = what is left after the pass's last video is computed"}
             # one video of the LAST rank's shard -> protocol dicts on rank 0 (boxes / scores of a remote video: regenerated
             # from its seed here; a deployment has the box protos on the host).  The shortest one: the oracle check below is
             # single-threaded python + C
-            r_ = len(gathered["meta"]) - 1
-            while r_ > 0 and gathered["meta"][r_].shape[0] == 0:
+            r_ = xch.world - 1
+            while r_ > 0 and not owned[r_]:
                 r_ -= 1
-            metas = gathered["meta"][r_].tolist()
-            slot = min(range(len(metas)), key=lambda q: (metas[q][1], q))
-            v, Fv = int(metas[slot][0]), int(metas[slot][1])
-            f_before = sum(int(m[1]) for m in metas[:slot])
-            tub = gathered["tub"][r_][C * T * f_before:C * T * (f_before + Fv)].reshape(C, T, Fv, 10)
-            anc = gathered["anchors"][r_][C * T * slot:C * T * (slot + 1)].reshape(C, T, 3)
-            ntr = gathered["ntracks"][r_][C * slot:C * (slot + 1)]
-            kept = gathered["kept"][r_][f_before * C:(f_before + Fv) * C].reshape(Fv, C, TOPK).cpu().numpy()
-            kcnt = gathered["kcnt"][r_][f_before * C:(f_before + Fv) * C].reshape(Fv, C).cpu().numpy()
+            slot = min(range(len(owned[r_])), key=lambda q: (frames[owned[r_][q]], q))
+            hdr, fld = xch.record_of(slot, r_)
+            v, Fv = int(hdr[0]), int(hdr[1])
+            assert v == owned[r_][slot] and Fv == frames[v], (v, Fv, owned[r_][slot])
+            tub = fld[0].view(torch.float32).reshape(C, T, Fv, 10)
+            anc = fld[1].view(torch.float32).reshape(C, T, 3)
+            ntr = fld[2].view(torch.int32)
+            kept = fld[3].view(torch.int32).reshape(Fv, C, TOPK).cpu().numpy()
+            kcnt = fld[4].view(torch.int32).reshape(Fv, C).cpu().numpy()
             c_best = int(torch.argmax(ntr).item())
             tp = ops.tracks_to_proto("synth_%d" % v, tub[c_best, :, :, :5].contiguous(), anc[c_best], int(ntr[c_best]))
             hb, hs = [t.cpu().numpy() for t in (vids[v] if v in vids else synth_video_cuda(torch, 3000 + v, Fv, B, C, dev, args.scores))]
@@ -312,7 +338,7 @@ def sharded_core(args, torch, dist, vdist, dev, local, world, rank, V, steps, wa
 
 
 def run_sharded(args):
-    """`python bench.py --videos N` (and `torchrun --nproc-per-node 8 bench.py --gpus 8 --videos 64`): BASELINE configs[3]"""
+    """`python bench.py --videos N` (8 GPUs: `python bench.py --gpus 8 --videos 64`, which launches the ranks itself): BASELINE configs[3]"""
     import torch
     import torch.distributed as dist
     from vdetlib_amd import dist as vdist
@@ -1206,7 +1232,7 @@ def main():
                     sharded = {k: sharded[k] for k in ("value", "ms_per_step", "ms_per_video", "steps", "config", "exchange", "protocol_dicts",
                                                        "oracle_check", "lpt_loads_world8_boxes", "lpt_imbalance_world8", "roofline")}
                     sharded["config"] = {k: v for k, v in sharded["config"].items() if k not in ("frames", "shards")}
-                    sharded["how_to_run_on_8_gpus"] = "torchrun --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 bench.py --gpus 8 --videos 64"
+                    sharded["how_to_run_on_8_gpus"] = "python bench.py --gpus 8 --videos 64   (launches 8 ranks by itself; or torchrun --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 bench.py --gpus 8 --videos 64)"
                 if made_pg:
                     dist.barrier()
                     dist.destroy_process_group()

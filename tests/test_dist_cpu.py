@@ -133,3 +133,58 @@ def test_bench_gpus_n_without_devices_exits_2():
                        env=env, cwd=root, capture_output=True, text=True, timeout=300)
     assert p.returncode == 2 and "--gpus 9" in p.stderr and "visible" in p.stderr
     assert "{" not in p.stdout
+
+
+def _packed_worker(rank, world, port, ret):
+    """PackedExchange (the configs[3] exchange: rounds of one fixed-capacity all-gather) on two gloo ranks: rank 0 owns videos
+    {0, 2, 4} of 3 / 5 / 2 frames, rank 1 owns {1, 3} -- so round 2 carries an EMPTY record from rank 1 -- and two passes reuse the
+    buffers."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank))
+    vd.init(backend="gloo")
+    frames = {0: 3, 1: 4, 2: 5, 3: 1, 4: 2}
+    owned = [[0, 2, 4], [1, 3]]
+    rounds = max(len(o) for o in owned)
+
+    def fields(v, salt):
+        f = frames[v]
+        return [torch.arange(f * 7, dtype=torch.float32) + 100 * v + salt, torch.full((f, 2), v + salt, dtype=torch.int32)]
+    cap = 5 * 7 * 4 + 16 + 5 * 2 * 4 + 16
+    x = vd.PackedExchange(cap, rounds, "cpu")
+    mine = owned[rank]
+    for j in range(rounds):
+        if j < len(mine):
+            x.set_record(j, mine[j], frames[mine[j]], [t.numel() * 4 for t in fields(mine[j], 0)])
+        else:
+            x.set_record(j, -1, 0, [])
+    ok = True
+    for salt in (0, 1000):                       # two passes through the same buffers
+        for j in range(rounds):
+            if j < len(mine):
+                x.pack(j, fields(mine[j], salt))
+            x.launch(j)
+        x.join()
+        for j in range(rounds):
+            for r_ in range(world):
+                hdr, fl = x.record_of(j, r_)
+                if j < len(owned[r_]):
+                    v = owned[r_][j]
+                    want = fields(v, salt)
+                    ok = ok and hdr[:3] == [v, frames[v], 2]
+                    ok = ok and torch.equal(fl[0].view(torch.float32), want[0]) and torch.equal(fl[1].view(torch.int32).reshape(-1, 2), want[1])
+                else:
+                    ok = ok and hdr[0] == -1 and fl == []
+    try:
+        x.set_record(0, 9, 99, [cap + 64])
+        ok = False
+    except ValueError:
+        pass
+    ret[rank] = bool(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world2_gloo_packed_exchange_rounds():
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_packed_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    assert dict(ret) == {0: True, 1: True}

@@ -129,3 +129,97 @@ def gather_video_results(video_ids, keep_idx, keep_cnt, group=None, force=False)
         for k, vid in enumerate(g_ids[r].tolist()):
             out[int(vid)] = (g_idx[r][k], g_cnt[r][k])
     return out
+
+
+class PackedExchange(object):
+    """The result exchange of BASELINE configs[3] as it should run on a node: ROUNDS of one fixed-capacity all-gather.
+
+    Round j carries every rank's j-th video (ranks with fewer videos send an empty record).  A record = a small int64 header
+    (video id, frames, element count of every field) + the fields back to back in ONE uint8 buffer of ``capacity`` bytes, the same
+    on every rank -- so a round is a single ``all_gather_into_tensor`` with no count exchange and therefore NO host
+    synchronisation: it is enqueued on a side stream as soon as the video's results exist (an event) and runs over xGMI while
+    the rank's other streams compute the next videos.  Only the last round of a pass can be exposed.  ``all_gather_ragged``
+    above stays the general-purpose form (counts first, one padded payload, host-synchronous).
+
+    CPU tensors (gloo tests) take the same path without streams."""
+
+    HDR = 16          # int64 words of header: [0] video id (-1: empty record), [1] frames, [2] n fields, [3 ..] bytes per field
+
+    def __init__(self, capacity, rounds, device, group=None, force=False):
+        self.cap = (int(capacity) + 8 * self.HDR + 15) // 16 * 16
+        self.rounds, self.device, self.group, self.force = int(rounds), torch.device(device), group, force
+        self.on = _collective(group, force)
+        self.world = dist.get_world_size(group) if self.on else 1
+        self.cuda = self.device.type == "cuda"
+        self.send = [torch.zeros(self.cap, dtype=torch.uint8, device=self.device) for _ in range(self.rounds)]
+        self.recv = [torch.zeros(self.world * self.cap, dtype=torch.uint8, device=self.device) for _ in range(self.rounds)] if self.on else None
+        self.comm = torch.cuda.Stream(device=self.device) if self.cuda else None
+        self.done = [None] * self.rounds          # event: round j's collective of the previous pass has left send[j] / recv[j]
+        self.gloo = self.on and dist.get_backend(group) == "gloo"
+
+    def set_record(self, j, video, frames, field_nbytes):
+        """Once per geometry: the header of this rank's record of round j (``video`` = -1 and no fields: an empty record).  The
+        header is written here, on the host's time, so that ``pack`` only enqueues device-to-device copies."""
+        if len(field_nbytes) > self.HDR - 3:
+            raise ValueError("too many fields for the record header")
+        off = 8 * self.HDR
+        for n in field_nbytes:
+            off = (off + int(n) + 15) // 16 * 16
+        if off > self.cap:
+            raise ValueError("record exceeds the exchange capacity (%d > %d bytes)" % (off, self.cap))
+        hdr = [int(video), int(frames), len(field_nbytes)] + [int(n) for n in field_nbytes] + [0] * (self.HDR - 3 - len(field_nbytes))
+        self.send[j][:8 * self.HDR].view(torch.int64).copy_(torch.tensor(hdr, dtype=torch.int64))
+        if self.cuda:
+            torch.cuda.synchronize(self.device)
+
+    def pack(self, j, tensors):
+        """The fields of round j's record into its send buffer, on the CURRENT stream (after the previous pass's collective on
+        that buffer): device-to-device copies only.  Sizes must match ``set_record``."""
+        if self.cuda and self.done[j] is not None:
+            torch.cuda.current_stream(self.device).wait_event(self.done[j])
+        buf = self.send[j]
+        off = 8 * self.HDR
+        for t in tensors:
+            n = t.numel() * t.element_size()
+            buf[off:off + n].view(t.dtype).copy_(t.reshape(-1), non_blocking=True)
+            off = (off + n + 15) // 16 * 16
+        return off
+
+    def launch(self, j, after=None):
+        """Enqueue round j's all-gather on the side stream, after ``after`` (an event recorded where the record was packed)."""
+        if not self.on:
+            return
+        if self.gloo and self.cuda:            # (single-GPU dry runs: gloo moves host memory)
+            if after is not None:
+                after.synchronize()
+            out = torch.empty(self.world * self.cap, dtype=torch.uint8)
+            dist.all_gather_into_tensor(out, self.send[j].cpu(), group=self.group)
+            self.recv[j].copy_(out)
+            return
+        if not self.cuda:
+            dist.all_gather_into_tensor(self.recv[j], self.send[j], group=self.group)
+            return
+        if after is not None:
+            self.comm.wait_event(after)
+        with torch.cuda.stream(self.comm):
+            dist.all_gather_into_tensor(self.recv[j], self.send[j], group=self.group)
+            ev = torch.cuda.Event()
+            ev.record(self.comm)
+        self.done[j] = ev
+
+    def join(self):
+        """Make the current stream wait for every collective enqueued so far (no host wait)."""
+        if self.on and self.cuda and not self.gloo:
+            torch.cuda.current_stream(self.device).wait_stream(self.comm)
+
+    def record_of(self, j, r):
+        """Rank r's record of round j: (header list, {k: field k as a flat uint8 view}); host-synchronous (reads the header).
+        header = [video id (-1: empty), frames, n fields, bytes of field 0, bytes of field 1, ...]."""
+        buf = (self.recv[j][r * self.cap:(r + 1) * self.cap] if self.on else self.send[j])
+        hdr = buf[:8 * self.HDR].view(torch.int64).tolist()
+        fields, off = [], 8 * self.HDR
+        for k in range(int(hdr[2])):
+            n = int(hdr[3 + k])
+            fields.append(buf[off:off + n])
+            off = (off + n + 15) // 16 * 16
+        return hdr, fields
