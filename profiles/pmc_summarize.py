@@ -16,7 +16,7 @@ import json
 import sqlite3
 import sys
 
-STAGES = [("iou_bits_sym_kernel", "iou_bits"), ("iou_bits_kernel", "iou_bits_general"), ("adj_build_kernel", "adj_build"),
+STAGES = [("iou_bits_sym_kernel", "iou_bits"), ("iou_bits_kernel", "iou_bits_general"), ("adj_build_kernel", "adj_build"), ("adj_rows_kernel", "adj_build"), ("strip_scan_kernel", "adj_prepass"), ("strip_totals_kernel", "adj_prepass"),
           ("sort_kernel", "sort"), ("walk_kernel", "walk"), ("volume_pass_kernel", "temporal"), ("temporal_both_vec4_kernel", "temporal"), ("temporal_vec4_kernel", "temporal"),
           ("transpose_keys_kernel", "transpose_keys"), ("track_pick_kernel", "track_pick"),
           ("track_link_kernel", "track_link"), ("track_suppress_kernel", "track_suppress"),
