@@ -440,9 +440,18 @@ def test_link_memo_shares_steps_across_chains(oracle):
     # (how many steps were SERVED by the memo depends on which of two chains through one node gets there first: reported,
     #  not asserted -- what is asserted is that sharing steps changes no tubelet)
     print("link steps served by the memo / scanned:", hits, misses)
+    links = set()
     for c in (0, 5):
         wt, wa, wn = oracle.greedy_track_volume(boxes, scores[:, :, c], 0.3, 0.0, 12, 0.5, 0)
         assert int(nt[c]) == wn and np.array_equal(tr[c, :wn].cpu().numpy(), wt[:wn], equal_nan=True)
+        for t in range(wn):          # the distinct links (frame, box, next box) these tubelets are made of
+            for f in range(wt.shape[1] - 1):
+                if not (np.isnan(wt[t, f, 0]) or np.isnan(wt[t, f + 1, 0])):
+                    links.add((f, tuple(wt[t, f, :4]), tuple(wt[t, f + 1, :4])))
+    # deterministic whatever the chains' timing: every distinct link of the result was either scanned or found in the memo
+    # at least once (a disabled memo or a broken step counter shows here), and nothing is counted that no chain could take
+    assert hits + misses >= len(links) > 0
+    assert hits + misses <= 2 * 16 * (12 + 16) * boxes.shape[0] + 2 * boxes.shape[0] * boxes.shape[1]
     cx.close()
 
 

@@ -192,9 +192,11 @@ __device__ __forceinline__ void fused_nms_body(const FusedParams &prm, unsigned 
     }
     const bool anybad = __ballot(bad != 0) != 0ull;
     if (lane == 0) {
-        prm.hdr[1] = nk;
+        // the count doubles as the "done" word the host polls (fused_wait, vdet_capi.hip): kept list and status first, a
+        // system-scope fence, then the count with release semantics
         prm.hdr[0] = (anybad || s_bad) ? kStDivZero : 0;
         __threadfence_system();
+        __hip_atomic_store(&prm.hdr[1], nk, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -223,7 +225,7 @@ __global__ __launch_bounds__(BLOCK) void fused_nms_batch_kernel(const FusedBatch
     prm.hdr = bp.hdr + 2 * (size_t)k;
     prm.kept = bp.kept + r0;
     if (prm.n <= 0) {
-        if (threadIdx.x == 0) { prm.hdr[0] = 0; prm.hdr[1] = 0; __threadfence_system(); }
+        if (threadIdx.x == 0) { prm.hdr[0] = 0; __threadfence_system(); __hip_atomic_store(&prm.hdr[1], 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
         return;
     }
     fused_nms_body<BLOCK>(prm, smem, s_ncand, s_bad);

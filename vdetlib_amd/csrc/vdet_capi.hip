@@ -3,6 +3,8 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared
 // (-ffp-contract=off is load-bearing: the f32 operation order of the IoU predicate is the spec).
 #include <hip/hip_runtime.h>
+#include <atomic>
+#include <chrono>
 
 #include <algorithm>
 #include <cmath>
@@ -861,6 +863,29 @@ int group_by_frame(vdet_ctx *c, const float *frames, int64_t n, int64_t ld, std:
 constexpr size_t kFusedInBytes = (size_t)kFusedMax * 6 * 4 + (size_t)kFusedMax * 4 + (size_t)kFusedMaxTracks * 5 * 4;
 constexpr size_t kFusedOutBytes = (size_t)(2 + kFusedMax) * 4;
 
+// Wait for a single-launch call by POLLING its "done" words in host-mapped memory (the kernels publish the kept count last,
+// release / system scope) instead of hipStreamSynchronize: at T-CNN's call sizes the kernel runs ~15 us and the runtime's
+// wake-up was a third of the call (measured through the python module: nms of 100 rows 0.050 -> see INTEGRATION.md).  The done
+// words are set to -1 before the launch; hipStreamQuery pushes the launch out; after 2 ms of polling (a long kernel, a busy
+// device) the wait falls back to the stream synchronisation, which is also what reports a failed launch.
+hipError_t fused_wait(vdet_ctx *c, volatile int32_t *hdr, int64_t K)
+{
+    ++c->n_host_syncs;
+    (void)hipStreamQuery(c->stream);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int64_t k = 0; k < K; ++k) {
+        unsigned spins = 0;
+        while (hdr[2 * k + 1] == -1) {
+            __builtin_ia32_pause();
+            if ((++spins & 255u) == 0u &&
+                std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2))
+                return hipStreamSynchronize(c->stream);
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return hipSuccess;
+}
+
 int fused_call(vdet_ctx *c, const float *h_rows, int64_t n, int64_t ld, int ncols, double thresh, const int64_t *h_order,
                const float *h_tracks, int64_t t, int64_t ldt, int64_t *h_keep, int64_t *n_keep)
 {
@@ -914,13 +939,14 @@ int fused_call(vdet_ctx *c, const float *h_rows, int64_t n, int64_t ld, int ncol
     int n2 = 64;
     while (n2 < n) n2 <<= 1;
     const size_t lds = fused_lds_bytes((int)n, n2);
+    out[1] = -1;                      // the "done" word: the kernel stores the kept count there last
     {
         StageTimer tm(c, ST_WALK);
         if (n <= 128) hipLaunchKernelGGL(fused_nms_kernel<256>, dim3(1), dim3(256), lds, c->stream, fp);
         else hipLaunchKernelGGL(fused_nms_kernel<1024>, dim3(1), dim3(1024), lds, c->stream, fp);
     }
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, host_sync(c));
+    HIPCHK(c, fused_wait(c, out, 1));
     if (out[0] & kStDivZero) return fail(c, VDET_EDIVZERO, "float division (zero union)");
     const int64_t nk = out[1];
     if (nk < 0 || nk > n) return fail(c, VDET_EHIP, "internal: single-launch NMS returned %lld of %lld rows", (long long)nk, (long long)n);
@@ -990,13 +1016,14 @@ int fused_batch_call(vdet_ctx *c, const float *h_tracks, const int64_t *h_toff, 
     int n2 = 64;
     while (n2 < max_m) n2 <<= 1;
     const size_t lds = fused_lds_bytes((int)std::max<int64_t>(max_m, 1), n2);
+    for (int64_t k = 0; k < K; ++k) hdr[2 * k + 1] = -1;      // the problems' "done" words
     {
         StageTimer tm(c, ST_WALK);
         if (max_m <= 128) hipLaunchKernelGGL(fused_nms_batch_kernel<256>, dim3((unsigned)K), dim3(256), lds, c->stream, bp);
         else hipLaunchKernelGGL(fused_nms_batch_kernel<1024>, dim3((unsigned)K), dim3(1024), lds, c->stream, bp);
     }
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, host_sync(c));
+    HIPCHK(c, fused_wait(c, hdr, K));
     bool divz = false;
     for (int64_t k = 0; k < K; ++k) {
         const int64_t m = h_off[k + 1] - h_off[k], nk = hdr[2 * k + 1];
