@@ -2,7 +2,8 @@
 """bench.py -- whole-job throughput of the hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL)
+    (N > 1: one rank per GPU over RCCL -- under the driver's torch.distributed.run line, or plain `python bench.py --gpus N`, which
+     launches its N ranks itself: self_launch)
 
 A "step" = one pass of the hot path over one synthetic video per GPU, inputs already resident in
 HBM:
