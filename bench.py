@@ -503,12 +503,17 @@ def self_launch(args):
     error (exit 2), never a silent one-rank run.  Under torchrun the world size comes from the environment; a `--gpus` that
     disagrees with it is reported on stderr and the environment wins (the line's `n_gpus` is always the real world size)."""
     world_env = os.environ.get("WORLD_SIZE")
-    if world_env is not None:
+    # under torch.distributed.run every rank has WORLD_SIZE, RANK and LOCAL_RANK; a stray WORLD_SIZE=1 exported by a harness is not
+    # a launcher (the ranks are then still ours to start)
+    launched = world_env is not None and "LOCAL_RANK" in os.environ and "RANK" in os.environ
+    if launched:
         if int(world_env) != args.gpus:
             sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%s: running %s ranks\n" % (args.gpus, world_env, world_env))
         return
     if args.gpus <= 1:
         return
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        os.environ.pop(k, None)
     if os.environ.get("VDET_BENCH_ONE_GPU") != "1":       # (test hook: every rank on device 0 over gloo)
         import torch
         have = torch.cuda.device_count()
