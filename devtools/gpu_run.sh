@@ -10,6 +10,7 @@
 #   kstats           rocprofv3 --kernel-trace --stats of the one-video-at-a-time step  -> <tag>_kernel_stats.csv
 #   hbm              two PMC passes (FETCH_SIZE, WRITE_SIZE)                              -> <tag>_pmc_hbm_traffic.csv + <tag>_pmc_traffic.json
 #   sq               two SQ counter passes of the same step                               -> <tag>_pmc_sq.csv, <tag>_pmc_sq2.csv
+#   tcp              L1 / address-unit counters of the same step                                 -> <tag>_pmc_tcp.csv
 #   tcc              L2 hit / miss / request counters of the same step (per-kernel L2 hit rate)    -> <tag>_pmc_tcc.csv
 #   vidstats         kernel stats of the VID-shape batch (devtools/bench_vid.py 64)       -> <tag>_vid_batch_kernel_stats.csv
 # Counters are collected in their own runs with --kernel-trace only (gpurun refuses other trace domains next to --pmc).
@@ -44,6 +45,9 @@ for what in "$@"; do
     tcc)     (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum -d $R/$O/p_t -o t -- $STEP --steps 1 --warmup 1 > $R/$O/${P}_p_t.log 2>&1)
              python profiles/sq_summarize.py $O/p_t/t_results.db $O/${P}_pmc_tcc.csv > /dev/null 2>> $O/${P}_sum.err
              rm -rf $O/p_t; head -8 $O/${P}_pmc_tcc.csv | cut -c1-200 ;;
+    tcp)     (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --pmc TA_BUSY_avr TA_FLAT_READ_WAVEFRONTS_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum GRBM_GUI_ACTIVE -d $R/$O/p_c -o c -- $STEP --steps 1 --warmup 1 > $R/$O/${P}_p_c.log 2>&1)
+             python profiles/sq_summarize.py $O/p_c/c_results.db $O/${P}_pmc_tcp.csv > /dev/null 2>> $O/${P}_sum.err
+             rm -rf $O/p_c; head -8 $O/${P}_pmc_tcp.csv | cut -c1-200 ;;
     vidstats) (cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $R/$O/p_v -o k -- python $R/devtools/bench_vid.py 64 > $R/$O/${P}_p_v.log 2>&1)
              python profiles/summarize.py $O/p_v/k_results.db $O/${P}_vid_batch_kernel_stats.csv "python devtools/bench_vid.py 64 (2 batched runs of 64 VID-shaped videos + 2 single-video runs)" > /dev/null 2>> $O/${P}_sum.err
              rm -rf $O/p_v ;;

@@ -92,7 +92,8 @@ __global__ __launch_bounds__(256) void adj_rows_kernel(const GroupDesc *__restri
                                                        const unsigned long long *__restrict__ slab_off, unsigned long long pool_cap,
                                                        int *__restrict__ status, const uint32_t *__restrict__ group_flags,
                                                        const float4 *__restrict__ xbox_all, const uint16_t *__restrict__ xord_all,
-                                                       int pool_bits, WalkMeta *__restrict__ wmeta, const float2 *__restrict__ reach_table)
+                                                       int pool_bits, WalkMeta *__restrict__ wmeta, const float2 *__restrict__ reach_table,
+                                                       uint4 *__restrict__ wmeta16)
 {
     __shared__ float2 srt[kMaxWordRows];
     __shared__ uint16_t scol[kMaxWordRows];
@@ -148,6 +149,10 @@ __global__ __launch_bounds__(256) void adj_rows_kernel(const GroupDesc *__restri
                 wmeta[gd.box_off + vo].box = over ? make_float4(0.f, 0.f, 0.f, 0.f) : bx;
                 wmeta[gd.box_off + vo].row = over ? make_uint4(0u, 0u, 0u, 0u) : make_uint4(p, deg, 0u, 0u);
             }
+            // frames of integer coordinates in [0, 65535]: the same record in 16 bytes (the walk's one load per candidate)
+            if (wmeta16 && (group_flags[td.group] & kFlagU16))
+                wmeta16[gd.box_off + vo] = over ? make_uint4(0u, 0u, 0u, 0u)
+                                                : make_uint4((uint32_t)bx.x | ((uint32_t)bx.y << 16), (uint32_t)bx.z | ((uint32_t)bx.w << 16), p, deg);
         }
     }
     __syncthreads();

@@ -1400,6 +1400,8 @@ struct WalkParams {
     int packed;               // regular frames take walk_list_packed (eight candidates per pass)
     const WalkMeta *wmeta;    // per box: coordinates + list (adj_build_kernel), and the graph's threshold: the packed walk
     float t32;                // tests the members of a group against each other geometrically
+    const uint4 *wmeta16;     // frames of integer coordinates (kFlagU16) whose records adj_rows_kernel wrote: the same record in 16
+                              // bytes {x1 | y1 << 16, x2 | y2 << 16, list offset, degree} (null: none)
 };
 
 // LDS words through which the lanes of one wave talk to each other (the walks' dead masks): every
@@ -1606,6 +1608,11 @@ __device__ __forceinline__ void walk_ring_drain(const WalkParams &prm, lds_mask_
     }
 }
 
+// U16: the records come from wmeta16 -- ONE 16-byte load per candidate and chunk instead of two.  The walk's busiest unit is the
+// address unit of the L1 (TA_BUSY 71 % of the kernel's cycles, profiles/r06_pmc_tcp.csv), and the record prefetch -- issued for all
+// 64 lanes of every one of the 157 chunks -- is ~40 % of the bytes it generates addresses for.  The raw words stay in registers
+// until the candidate is queued (a conversion at load time would wait for the load on the spot).
+template <bool U16>
 __device__ __forceinline__ void walk_list_packed(const WalkParams &prm, lds_mask_t mask, const int lane, const int rb,
                                                  const uint16_t *__restrict__ order, const int ncand,
                                                  int32_t *__restrict__ out, const int64_t cap, int &nk_out)
@@ -1613,6 +1620,7 @@ __device__ __forceinline__ void walk_list_packed(const WalkParams &prm, lds_mask
     lds_mask_t ring = mask + prm.mask_words;
     lds_f4_t ringb = (lds_f4_t)ring;                              // slot s: words 8s .. 8s+3 = meta, float4 2s+1 = box
     const WalkMeta *__restrict__ wmeta = prm.wmeta + rb;
+    const uint4 *__restrict__ wm16 = U16 ? prm.wmeta16 + rb : nullptr;
     const float t32 = prm.t32;
     int qh = 0, qn = 0, nk = 0;                                   // ring head, queued candidates, survivors (wave-uniform)
     const int last = max(ncand - 1, 0);
@@ -1625,14 +1633,16 @@ __device__ __forceinline__ void walk_list_packed(const WalkParams &prm, lds_mask
     int cc[3];
     uint2 mm[3];
     float4 bb[3];
+    uint4 rr[3];                                                  // U16: the raw 16-byte records
     cc[0] = (int)order[(uint32_t)min(lane, last)];
     cc[1] = (int)order[(uint32_t)min(64 + lane, last)];
     cc[2] = 0;
     mm[0] = mm[1] = mm[2] = make_uint2(0u, 0u);
     bb[0] = bb[1] = bb[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+    rr[0] = rr[1] = rr[2] = make_uint4(0u, 0u, 0u, 0u);
     if (lane < ncand) {                                           // chunk 0: everything is alive
-        const WalkMeta *wm = wmeta + (uint32_t)cc[0];
-        bb[0] = wm->box; const uint4 rw = wm->row; mm[0] = make_uint2(rw.x, rw.y);
+        if (U16) rr[0] = wm16[(uint32_t)cc[0]];
+        else { const WalkMeta *wm = wmeta + (uint32_t)cc[0]; bb[0] = wm->box; const uint4 rw = wm->row; mm[0] = make_uint2(rw.x, rw.y); }
     }
 #define VDET_WALK_PASS(Q0, CUR, NXT, NN)                                                                                             \
     {                                                                                                                                \
@@ -1642,17 +1652,28 @@ __device__ __forceinline__ void walk_list_packed(const WalkParams &prm, lds_mask
         {   /* (no branch around the loads: a lane that needs no record reads record 0 -- one shared line -- so that the number */ \
             /*  of loads in flight does not depend on the path and hipcc can wait for exactly the older ones)                   */ \
             const bool want = (q0_ + 64 + lane) < ncand && !((mask[cc[NXT] >> 5] >> (cc[NXT] & 31)) & 1u);                           \
-            const WalkMeta *wm = wmeta + (want ? (uint32_t)cc[NXT] : 0u);                                                            \
-            bb[NXT] = wm->box; const uint4 rw = wm->row; mm[NXT] = make_uint2(rw.x, rw.y);                                           \
+            if (U16) rr[NXT] = wm16[want ? (uint32_t)cc[NXT] : 0u];                                                                  \
+            else {                                                                                                                   \
+                const WalkMeta *wm = wmeta + (want ? (uint32_t)cc[NXT] : 0u);                                                        \
+                bb[NXT] = wm->box; const uint4 rw = wm->row; mm[NXT] = make_uint2(rw.x, rw.y);                                       \
+            }                                                                                                                        \
         }                                                                                                                            \
         const bool alive = (q0_ + lane) < ncand && !((mask[c >> 5] >> (c & 31)) & 1u);                                               \
         const unsigned long long am = __ballot(alive);                                                                               \
         if (alive) {                                                                                                                 \
             const int s = ring_wrap(qh + qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u))); \
             ring[8 * s] = (uint32_t)c;                                                                                               \
-            ring[8 * s + 1] = mm[CUR].x;                                                                                             \
-            ring[8 * s + 2] = mm[CUR].y;                                                                                             \
-            lds_f4v bv; bv.x = bb[CUR].x; bv.y = bb[CUR].y; bv.z = bb[CUR].z; bv.w = bb[CUR].w;                                      \
+            lds_f4v bv;                                                                                                              \
+            if (U16) {                                                                                                               \
+                ring[8 * s + 1] = rr[CUR].z;                                                                                         \
+                ring[8 * s + 2] = rr[CUR].w;                                                                                         \
+                bv.x = (float)(rr[CUR].x & 0xFFFFu); bv.y = (float)(rr[CUR].x >> 16);                                                \
+                bv.z = (float)(rr[CUR].y & 0xFFFFu); bv.w = (float)(rr[CUR].y >> 16);                                                \
+            } else {                                                                                                                 \
+                ring[8 * s + 1] = mm[CUR].x;                                                                                         \
+                ring[8 * s + 2] = mm[CUR].y;                                                                                         \
+                bv.x = bb[CUR].x; bv.y = bb[CUR].y; bv.z = bb[CUR].z; bv.w = bb[CUR].w;                                              \
+            }                                                                                                                        \
             ringb[2 * s + 1] = bv;                                                                                                   \
         }                                                                                                                            \
         qn += __popcll(am);                                                                                                          \
@@ -1695,7 +1716,9 @@ __device__ __forceinline__ void walk_one(const WalkParams &prm, const int p, uns
     int nk = 0;
     int bad = 0;
     if (regular && prm.packed && N >= 2) {     // (singleton groups have no graph: adj_build_kernel never saw them)
-        walk_list_packed(prm, mask, lane, rb, order, ncand, out, cap, nk);
+        // (wave-uniform) integer frames whose records exist in 16 bytes take them
+        if (prm.wmeta16 && (prm.group_flags[pr.g] & kFlagU16)) walk_list_packed<true>(prm, mask, lane, rb, order, ncand, out, cap, nk);
+        else walk_list_packed<false>(prm, mask, lane, rb, order, ncand, out, cap, nk);
         if (lane == 0) prm.keep_cnt[p] = nk;
         if ((int64_t)nk > cap && lane == 0) atomicOr(prm.status, kStCap);
         return;

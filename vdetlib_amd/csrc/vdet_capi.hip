@@ -105,7 +105,7 @@ struct vdet_ctx {
     int n_cu = 256;
     // scratch
     DevBuf boxes, scores, keys, excl, frames, groups, tiles, bits, rowz, rowmeta, groupz, adj, comp, origidx,
-        out64, trk_frames, trk_boxes, b1, b2, iou_out, order, ncand, keepidx, keepcnt, gflags, pairs, tkeys, tstate, visited, heads, xkeys, xord, wmeta, reachtab, striptot, stripoff, xncand, xbox, xbox16, xord16, xcum, xinfo, tmp[8];
+        out64, trk_frames, trk_boxes, b1, b2, iou_out, order, ncand, keepidx, keepcnt, gflags, pairs, tkeys, tstate, visited, heads, xkeys, xord, wmeta, wmeta16, reachtab, striptot, stripoff, xncand, xbox, xbox16, xord16, xcum, xinfo, tmp[8];
     // timing
     bool timing = false;
     bool timing_accumulate = false;   // vdet_set_timing(ctx, 2): keep events across calls until read
@@ -150,6 +150,7 @@ struct vdet_ctx {
     unsigned long long pool_hint = 0;   // adjacency entries used by the largest graph built so far
     bool topk_attr_set = false;
     float gt32 = 0.f;             // threshold of the last graph build (the packed walk's in-group test)
+    bool wmeta16_built = false;   // ... and adj_rows_kernel the 16-byte form of the records of integer frames
     bool wmeta_built = false;     // ... which also wrote the packed walk's records (WalkMeta) of the regular frames
     bool last_sort_binned = false;   // the last per-(frame, class) sort went through binsort_kernel (vdet_query 9)
     DevBuf vidtab;                // batched videos: {first frame, frames} per video
@@ -370,6 +371,7 @@ int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32, doub
     c->sym_built = false;
     c->gt32 = t32;
     c->wmeta_built = false;
+    c->wmeta16_built = false;
     c->nodes_valid = false;      // the adjacency lists the recorded track nodes point into are rewritten
     HIPCHK(c, c->groups.reserve(G * sizeof(GroupDesc)));
     HIPCHK(c, c->tiles.reserve(std::max<size_t>(pl.tiles.size(), 1) * sizeof(TileDesc)));
@@ -422,6 +424,7 @@ int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32, doub
         c->sym_built = use_sym;
         c->wmeta_built = use_sym;
         if (c->wmeta_built) HIPCHK(c, c->wmeta.reserve((size_t)pl.ntot * sizeof(WalkMeta)));
+        if (c->wmeta_built && c->adj_rows && pl.nmax > 384) HIPCHK(c, c->wmeta16.reserve((size_t)pl.ntot * sizeof(uint4)));
         if (use_sym) {
             {
                 StageTimer tm(c, ST_OTHER);
@@ -505,7 +508,9 @@ int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32, doub
                                        c->tiles.as<TileDesc>() + bt.first, bits_b, c->rowz.as<uint32_t>(), c->rowmeta.as<uint2>(),
                                        c->adj.as<uint16_t>(), c->stripoff.as<unsigned long long>(), pool_cap, &c->d_cnt->status, c->gflags.as<uint32_t>(),
                                        c->xbox.as<float4>(), c->xord.as<uint16_t>(), async ? (kStPool | kStPoolAsync) : kStPool,
-                                       c->wmeta_built ? c->wmeta.as<WalkMeta>() : (WalkMeta *)nullptr, c->reachtab.as<float2>());
+                                       c->wmeta_built ? c->wmeta.as<WalkMeta>() : (WalkMeta *)nullptr, c->reachtab.as<float2>(),
+                                       c->wmeta_built ? c->wmeta16.as<uint4>() : (uint4 *)nullptr);
+                    c->wmeta16_built = c->wmeta_built;
                 }
             }
         }
@@ -720,6 +725,7 @@ int launch_sort_walk(vdet_ctx *c, const SortWalkArgs &a, int nmax, int64_t order
     wp.wave_words = wp.mask_words + (wp.packed ? 8 * kPackRing : 0);      // + the ring of alive candidates
     wp.wmeta = c->wmeta.as<WalkMeta>();
     wp.t32 = c->gt32;
+    wp.wmeta16 = (wp.packed && c->wmeta16_built) ? c->wmeta16.as<uint4>() : nullptr;
     // frames of at most 384 boxes: one LANE per list, the frames' rows in LDS (small_kernels.hpp); the lists of irregular frames
     // are left to the general walk (walk_rest_kernel: normally nothing)
     const bool small_walk = c->small_lists && a.mode != 2 && nmax <= kSmallMax && wp.group_flags && a.C > 0 && a.P % a.C == 0;
@@ -1155,7 +1161,7 @@ int vdet_destroy(vdet_ctx *c)
                       &c->rowz, &c->rowmeta, &c->groupz, &c->adj, &c->comp, &c->origidx, &c->out64,
                       &c->trk_frames, &c->trk_boxes, &c->b1, &c->b2, &c->iou_out, &c->order, &c->ncand, &c->keepidx,
                       &c->keepcnt, &c->gflags, &c->pairs, &c->tkeys, &c->tstate, &c->visited, &c->heads, &c->xkeys, &c->xord, &c->xncand, &c->linkmemo, &c->linkstats, &c->linkwarm, &c->linkorder, &c->linkchains, &c->linknodes, &c->tracknode, &c->rtodo,
-                      &c->xbox, &c->xbox16, &c->xord16, &c->xcum, &c->xinfo, &c->wmeta, &c->reachtab, &c->striptot, &c->stripoff, &c->sortctl, &c->segtab, &c->vidtab, &c->nover, &c->ordncand};
+                      &c->xbox, &c->xbox16, &c->xord16, &c->xcum, &c->xinfo, &c->wmeta, &c->wmeta16, &c->reachtab, &c->striptot, &c->stripoff, &c->sortctl, &c->segtab, &c->vidtab, &c->nover, &c->ordncand};
     for (DevBuf *b : bufs) b->release();
     for (DevBuf &b : c->tmp) b.release();
     for (auto &e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
