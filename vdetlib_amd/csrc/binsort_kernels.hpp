@@ -261,78 +261,72 @@ __global__ __launch_bounds__(512, CPW <= 20 ? 4 : 2) void binsort_kernel(const B
             }
         }
         lds_only_barrier();
-        // ---- 6. fix-up + store; the counters are cleared for the next problem meanwhile
-        for (int i = fresh_tid(); i < kBinWords / 4; i += BLOCK) reinterpret_cast<uint4 *>(hist)[i] = make_uint4(0u, 0u, 0u, 0u);
+        // ---- 6. the bins in exact order, then the store; the counters are cleared for the next problem meanwhile.
+        // Bins are contiguous runs of entries in ARRIVAL order, three quarters of them a single key.  (Round 6: until then every
+        // entry looked at three neighbours to its left and four to its right and counted which of them belong on its other side
+        // -- 8 LDS reads and ~55 VALU instructions per entry, 1.0 of the kernel's 2.36 ms by cut-off launches.)  Now: (a) the lane
+        // at a position that STARTS a bin of two or more entries (its entry is flagged, the next one is not) becomes the bin's
+        // owner; (b) owners put their bins in order in place -- an insertion sort on 2-3 (at most kBinMax) LDS words: by fraction,
+        // equal fractions (equal keys, or an exponent with < 128 sub-bins) by the full key from global memory, equal keys by
+        // descending index; (c) one coalesced store of the whole list.  A barrier before (b): a lane must not take an entry an
+        // owner has already moved for the start of a bin.
         {
             const int lane6 = fresh_tid() & 63;
             uint16_t *out = prm.order + (int64_t)p * N;
             const uint32_t *row = prm.raw + (int64_t)p * N;
+            // (the counter words are free once the scatter has read them: until they are cleared at the end of this phase their
+            //  first N bytes hold, at an owner's position, the length of its bin -- an owner must know where its bin ends BEFORE
+            //  the owner of the next bin starts moving that bin's flagged first entry)
+            uint8_t *blen = reinterpret_cast<uint8_t *>(hist);
             auto key_of = [&](uint32_t idx) -> uint32_t { return ~ikey(row, idx); };
-            // the general form: walk my bin to the left and to the right, one entry per step
-            auto fix_general = [&](int q, uint32_t me) -> int {
-                const uint32_t mfr = me >> 16, midx = me & 0x7FFFu;
-                int npos = q;
-                bool lopen = !(me & 0x8000u), ropen = true;          // (entry N is a flagged sentinel)
-                for (int k = 1; lopen || ropen; ++k) {
-                    uint32_t l = 0u, r = 0x8000u;
-                    if (lopen) l = ent[q - k];
-                    if (ropen) r = ent[q + k];
-                    ropen = ropen && !(r & 0x8000u);
-                    bool l_after = lopen && (l >> 16) > mfr, r_before = ropen && (r >> 16) < mfr;
-                    if ((lopen && (l >> 16) == mfr) || (ropen && (r >> 16) == mfr)) {     // equal fractions: the keys themselves
-                        const uint32_t km = key_of(midx);
-                        if (lopen && (l >> 16) == mfr) { const uint32_t kl = key_of(l & 0x7FFFu); l_after = kl < km || (kl == km && (l & 0x7FFFu) < midx); }
-                        if (ropen && (r >> 16) == mfr) { const uint32_t kr = key_of(r & 0x7FFFu); r_before = kr > km || (kr == km && (r & 0x7FFFu) > midx); }
-                    }
-                    npos += (r_before ? 1 : 0) - (l_after ? 1 : 0);
-                    lopen = lopen && !(l & 0x8000u);
-                }
-                return npos;
+            // does entry a belong in front of entry b?  (smaller fraction of the inverted key = larger key = earlier)
+            auto before = [&](uint32_t a, uint32_t b) -> bool {
+                const uint32_t fa = a >> 16, fb = b >> 16;
+                if (fa != fb) return fa < fb;
+                const uint32_t ia = a & 0x7FFFu, ib = b & 0x7FFFu;
+                const uint32_t ka = key_of(ia), kb = key_of(ib);
+                if (ka != kb) return ka > kb;
+                return ia > ib;
             };
-            // An entry of my bin on my left that belongs after me moves me one place forward, one on my right that belongs
-            // before me one place back.  Fast form: three neighbours to the left, four to the right, all read at once with
-            // immediate offsets (bins hold 1-3 entries; the entries behind the last one are flagged sentinels); a lane
-            // whose bin reaches further, or that meets an equal fraction (equal keys; an exponent with < 128 sub-bins),
-            // takes the general form -- rare.  Two chunks per round: twice the reads in flight.
-#pragma unroll 1
-            for (int ch = 0; ch < CPW; ch += 2) {
-                const int q0 = (w * CPW + ch) * 64;
-                if (q0 >= N) break;
-                const uint32_t *pe = ent + q0 + lane6;
-                uint32_t me[2], l1[2], l2[2], l3[2], r1[2], r2[2], r3[2], r4[2];
+            unsigned long long own = 0ull;       // bit ch: my position of chunk ch starts a bin of >= 2 entries (CPW <= 36 chunks)
+            static_assert(CPW <= 64, "one bit per chunk");
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    me[u] = pe[u * 64];
-                    l1[u] = pe[u * 64 - 1]; l2[u] = pe[u * 64 - 2]; l3[u] = pe[u * 64 - 3];      // (q = 0 .. 2: the 16 B in front of the
-                    r1[u] = pe[u * 64 + 1]; r2[u] = pe[u * 64 + 2]; r3[u] = pe[u * 64 + 3];      //  entries; never used -- entry 0 is flagged)
-                    r4[u] = pe[u * 64 + 4];
+            for (int ch = 0; ch < CPW; ++ch) {
+                const int q = (w * CPW + ch) * 64 + lane6;
+                const uint32_t me = ent[min(q, N)], r1 = ent[min(q, N) + 1];        // (entries N .. are flagged sentinels)
+                const bool owner = q < N && (me & 0x8000u) != 0u && (r1 & 0x8000u) == 0u;
+                own |= owner ? (1ull << ch) : 0ull;
+                if (owner) {
+                    int n = 2;
+                    while (n < kBinMax && (ent[q + n] & 0x8000u) == 0u) ++n;       // (a bin holds at most kBinMax entries)
+                    blen[q] = (uint8_t)n;
                 }
-                int npos[2];
-                bool slow[2];
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    // (bitwise & / | on purpose: with && / || hipcc builds a forest of exec-masked branches -- seen in the ISA)
-                    const uint32_t hi = me[u] | 0xFFFFu, lo = me[u] & 0xFFFF0000u;     // x > hi: larger fraction; x < lo: smaller
-                    const bool o1 = (me[u] & 0x8000u) == 0u, o2 = o1 & ((l1[u] & 0x8000u) == 0u), o3 = o2 & ((l2[u] & 0x8000u) == 0u);
-                    const bool p1 = (r1[u] & 0x8000u) == 0u, p2 = p1 & ((r2[u] & 0x8000u) == 0u), p3 = p2 & ((r3[u] & 0x8000u) == 0u);
-                    const bool a1 = l1[u] > hi, a2 = l2[u] > hi, a3 = l3[u] > hi;          // left neighbour belongs after me
-                    const bool b1 = r1[u] < lo, b2 = r2[u] < lo, b3 = r3[u] < lo;          // right neighbour belongs before me
-                    const int d = (int)(p1 & b1) + (int)(p2 & b2) + (int)(p3 & b3) - (int)(o1 & a1) - (int)(o2 & a2) - (int)(o3 & a3);
-                    // an in-bin neighbour that is neither: equal fraction
-                    const bool tie = (o1 & !a1 & !(l1[u] < lo)) | (o2 & !a2 & !(l2[u] < lo)) | (o3 & !a3 & !(l3[u] < lo)) |
-                                     (p1 & !b1 & !(r1[u] > hi)) | (p2 & !b2 & !(r2[u] > hi)) | (p3 & !b3 & !(r3[u] > hi));
-                    const int q = q0 + u * 64 + lane6;
-                    npos[u] = q + d;
-                    slow[u] = (q < N) & (tie | (o3 & ((l3[u] & 0x8000u) == 0u)) | (p3 & ((r4[u] & 0x8000u) == 0u)));
+            }
+            lds_only_barrier();
+            while (own) {
+                const int ch = __ffsll(own) - 1;
+                own &= own - 1ull;
+                const int q = (w * CPW + ch) * 64 + lane6;
+                uint32_t *bin = ent + q;
+                const int n = (int)blen[q];
+                for (int i = 1; i < n; ++i) {
+                    const uint32_t x = bin[i];
+                    int j = i;
+                    while (j > 0) {
+                        const uint32_t y = bin[j - 1];
+                        if (!before(x, y)) break;
+                        bin[j] = y;
+                        --j;
+                    }
+                    bin[j] = x;
                 }
-                if (__ballot(slow[0] | slow[1]) != 0ull) {
+            }
+            lds_only_barrier();
+            for (int i = fresh_tid(); i < kBinWords / 4; i += BLOCK) reinterpret_cast<uint4 *>(hist)[i] = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
-                    for (int u = 0; u < 2; ++u)
-                        if (slow[u]) npos[u] = fix_general(q0 + u * 64 + lane6, me[u]);
-                }
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-                    if (q0 + u * 64 + lane6 < N) out[npos[u]] = (uint16_t)(me[u] & 0x7FFFu);
+            for (int ch = 0; ch < CPW; ++ch) {
+                const int q = (w * CPW + ch) * 64 + lane6;
+                if (q < N) out[q] = (uint16_t)(ent[q] & 0x7FFFu);
             }
             // every key of the list is a candidate HERE: a list with an excluded key (NaN score, key 0xFFFFFFFF -- `bad` in
             // phase 1, decided on the device, not by the host's gating) was handed to the LSD kernel, which counts its own
