@@ -32,9 +32,11 @@
 
 namespace vdet {
 
-constexpr int kBinWords = 8192;          // 32 768 byte counters
-constexpr int kBinTotal = 4 * kBinWords;
-constexpr int kBinSub = kBinTotal - 512; // sub-bins handed out proportionally (every exponent value adds < 1 by rounding up)
+// counter words of a list of up to 512 * CPW keys (4 byte-wide bins each).  Round 6: half as many bins as before for lists of <=
+// 10 240 keys (16 384 bins, ~0.6 keys per bin at config 2): since the bins are put in order by their owners (phase 6) a
+// multi-key bin costs little, and the scan and the clears are half as long (1.70 -> 1.54 ms per c2 video).  Floors: the
+// level-1 histogram needs 4 096 words, phase 6 keeps one byte per list position in them (>= N bytes).
+__host__ __device__ constexpr int binsort_words(int cpw) { return cpw <= 20 ? 4096 : 8192; }
 constexpr int kBinMax = 10;              // keys per bin (three of them must fit a 5-bit field of the scanned counter word)
 
 struct BinSortCtl {
@@ -52,9 +54,8 @@ struct BinSortParams {
 };
 
 // dynamic LDS: [counter words: 32 KB][16 B][entries: N + kBinTail words]
-constexpr int kBinEntOff = 4 * kBinWords + 16;
 constexpr int kBinTail = 72;             // flagged sentinels behind the last entry + slack for the last chunk's window reads
-inline size_t binsort_lds_bytes(int n) { return (size_t)kBinEntOff + (size_t)4 * (size_t)(((n + 63) & ~63) + kBinTail); }
+inline size_t binsort_lds_bytes(int n, int cpw) { return (size_t)(4 * binsort_words(cpw) + 16) + (size_t)4 * (size_t)(((n + 63) & ~63) + kBinTail); }
 
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t x)
 {
@@ -75,7 +76,10 @@ __global__ __launch_bounds__(512, CPW <= 20 ? 4 : 2) void binsort_kernel(const B
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int BLOCK = 512, NW = BLOCK / 64;
-    constexpr int WPT = kBinWords / BLOCK;          // counter words per thread in the scan (16)
+    constexpr int kBinWords = binsort_words(CPW), kBinTotal = 4 * kBinWords, kBinEntOff = 4 * kBinWords + 16;
+    constexpr int kBinSub = kBinTotal - 512;        // sub-bins handed out proportionally (every exponent value adds < 1 by rounding up)
+    static_assert(kBinWords >= 4096 && 4 * kBinWords >= 512 * (CPW <= 20 ? 20 : 36), "level-1 table and one byte per position");
+    constexpr int WPT = kBinWords / BLOCK;          // counter words per thread in the scan
     static_assert(CPW % 2 == 0, "the fix-up takes two chunks per round");
     uint32_t *hist = reinterpret_cast<uint32_t *>(smem);                        // [kBinWords]; level-1 table in its first 4 096 words
     uint32_t *ent = reinterpret_cast<uint32_t *>(smem + kBinEntOff);            // [N] fraction << 16 | first << 15 | index

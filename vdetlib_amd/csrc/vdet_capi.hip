@@ -659,8 +659,8 @@ int launch_sort_walk(vdet_ctx *c, const SortWalkArgs &a, int nmax, int64_t order
     } else if (!a.walk_only) {
         // volumes of untied scores: the equalised counting sort (binsort_kernels.hpp); what it can not spread -- decided per
         // problem on the device -- lands on a list the LSD kernel works off afterwards (normally empty)
-        const size_t bin_lds = binsort_lds_bytes(std::max(nmax, 1));
         const int bin_cpw = nmax <= 4096 ? 8 : nmax <= 10240 ? 20 : 36;      // keys per thread, 512 threads
+        const size_t bin_lds = binsort_lds_bytes(std::max(nmax, 1), bin_cpw);
         // (threshold / top-k / exclusion lists change ncand: those go to the LSD kernel; a NaN inside an otherwise plain list is
         //  caught per list on the device, binsort_kernels.hpp phase 1)
         const bool use_bin = c->binsort && (sp.mode == 1 || sp.mode == 3) && a.topk == 0 && !a.use_thr && !a.excl && block == 1024 &&
