@@ -55,7 +55,7 @@ struct BinSortParams {
 
 // dynamic LDS: [counter words: 32 KB][16 B][entries: N + kBinTail words]
 constexpr int kBinTail = 72;             // flagged sentinels behind the last entry + slack for the last chunk's window reads
-inline size_t binsort_lds_bytes(int n, int cpw) { return (size_t)(4 * binsort_words(cpw) + 16) + (size_t)4 * (size_t)(((n + 63) & ~63) + kBinTail); }
+inline size_t binsort_lds_bytes(int n, int cpw) { return (size_t)(4 * binsort_words(cpw) + 16) + (size_t)4 * (size_t)(((n + 63) & ~63) + kBinTail) + (size_t)(((n + 63) & ~63) + 16); }
 
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t x)
 {
@@ -64,6 +64,18 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t x)
     VDET_BS_STEP(0x142, 0xa) VDET_BS_STEP(0x143, 0xc)
 #undef VDET_BS_STEP
     return x;
+}
+
+// Two entries of one bin with EQUAL fractions (equal keys, or an exponent with < 128 sub-bins): the full keys decide, equal keys by
+// descending index.  Out of line on purpose: inlined, hipcc if-converts the rare branch and issues the two global loads for
+// EVERY comparison of phase 6 (a memory round trip per bin: measured 3.0 instead of 1.9 ms per video on random scores).
+template <bool FLOATS>
+__device__ __attribute__((noinline)) bool binsort_tie_before(const uint32_t *__restrict__ row, uint32_t ia, uint32_t ib)
+{
+    const uint32_t xa = row[ia], xb = row[ib];
+    const uint32_t ka = FLOATS ? score_key(__uint_as_float(xa)) : xa, kb = FLOATS ? score_key(__uint_as_float(xb)) : xb;
+    if (ka != kb) return ka > kb;
+    return ia > ib;
 }
 
 // CPW = keys per thread (key v = tid + k * BLOCK) = chunks of 64 positions per wave in the fix-up (even).
@@ -83,6 +95,7 @@ __global__ __launch_bounds__(512, CPW <= 20 ? 4 : 2) void binsort_kernel(const B
     static_assert(CPW % 2 == 0, "the fix-up takes two chunks per round");
     uint32_t *hist = reinterpret_cast<uint32_t *>(smem);                        // [kBinWords]; level-1 table in its first 4 096 words
     uint32_t *ent = reinterpret_cast<uint32_t *>(smem + kBinEntOff);            // [N] fraction << 16 | first << 15 | index
+    uint8_t *blen = reinterpret_cast<uint8_t *>(ent + (((prm.N + 63) & ~63) + kBinTail));      // [N] size of the bin that starts at a position
     __shared__ uint32_t tab[512];        // per exponent value: first bin << 16 | number of sub-bins
     __shared__ uint32_t wsum[NW];
     __shared__ int snext;
@@ -91,11 +104,7 @@ __global__ __launch_bounds__(512, CPW <= 20 ? 4 : 2) void binsort_kernel(const B
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int P = prm.P, N = prm.N;
 
-    // inverted sortable key of element idx of a row (ascending = descending score; 0xFFFFFFFF = not a candidate)
-    auto ikey = [&](const uint32_t *row, uint32_t idx) -> uint32_t {
-        const uint32_t x = row[idx];
-        return ~(FLOATS ? score_key(__uint_as_float(x)) : x);
-    };
+    // (keys are INVERTED sortable keys: ascending = descending score; 0xFFFFFFFF = not a candidate)
     // Round 4 (found in the ISA): with `ik[k] = v < N ? ikey(row, v) : ...` every key's load sat in its own basic block with an
     // s_waitcnt vmcnt(0) behind it -- CPW dependent memory round trips per list -- and the "prefetch" of the next list's keys was
     // drained by the next __syncthreads() anyway (its fence waits for every global load on gfx9).  Now the RAW words are requested
@@ -232,10 +241,12 @@ __global__ __launch_bounds__(512, CPW <= 20 ? 4 : 2) void binsort_kernel(const B
             lds_only_barrier();
             uint32_t run = incl - tot;
             for (int k = 0; k < w; ++k) run += wsum[k];
+            // word <- start (15 bits: N <= 18 432) | the four bins' counts, a nibble each (<= kBinMax): the scatter needs the keys
+            // in the word's earlier bins AND the size of the key's own bin (phase 6 sorts bins of two or more)
             auto enc = [&](uint32_t x) -> uint32_t {
-                const uint32_t s1 = x & 0xFFu, s2 = s1 + ((x >> 8) & 0xFFu), s3 = s2 + ((x >> 16) & 0xFFu);
-                const uint32_t r = run | (s1 << 17) | (s2 << 22) | (s3 << 27);
-                run += s3 + (x >> 24);
+                const uint32_t c = (x & 0xFu) | ((x >> 4) & 0xF0u) | ((x >> 8) & 0xF00u) | ((x >> 12) & 0xF000u);
+                const uint32_t r = run | (c << 15);
+                run += bytesum(x);
                 return r;
             };
             uint4 *hw2 = reinterpret_cast<uint4 *>(hist) + fresh_tid() * (WPT / 4);
@@ -258,75 +269,91 @@ __global__ __launch_bounds__(512, CPW <= 20 ? 4 : 2) void binsort_kernel(const B
             for (int k = 0; k < CPW; ++k) {
                 const uint32_t j = (cs[k] >> 16) & 3u;
                 const uint32_t r = (rr[k >> 2] >> ((k & 3) * 8)) & 0xFFu;
-                // (j = 0 reads 5 bits that lie inside the 17-bit start field: masked out by the select)
-                const uint32_t before = (e[k] >> (12u + 5u * j)) & 31u;
-                const uint32_t pos = (e[k] & 0x1FFFFu) + r + (j ? before : 0u);
-                if ((have >> k) & 1ull) ent[pos] = (cs[k] << 16) | (r == 0u ? 0x8000u : 0u) | (uint32_t)(t5 + k * BLOCK);
+                const uint32_t c = e[k] >> 15;                                  // the word's four counts
+                const uint32_t lowc = c & ((1u << (4u * j)) - 1u);             // ... of the bins in front of mine
+                const uint32_t before = (lowc & 0xFu) + ((lowc >> 4) & 0xFu) + (lowc >> 8);
+                const uint32_t cnt = (c >> (4u * j)) & 0xFu;                   // ... and of my own
+                const uint32_t pos = (e[k] & 0x7FFFu) + r + before;
+                if ((have >> k) & 1ull) {
+                    ent[pos] = (cs[k] << 16) | (r == 0u ? 0x8000u : 0u) | (uint32_t)(t5 + k * BLOCK);
+                    blen[pos] = (uint8_t)(r == 0u ? cnt : 0u);                  // at a bin's first place: its size; 0 elsewhere
+                }
             }
         }
         lds_only_barrier();
         // ---- 6. the bins in exact order, then the store; the counters are cleared for the next problem meanwhile.
-        // Bins are contiguous runs of entries in ARRIVAL order, three quarters of them a single key.  (Round 6: until then every
-        // entry looked at three neighbours to its left and four to its right and counted which of them belong on its other side
-        // -- 8 LDS reads and ~55 VALU instructions per entry, 1.0 of the kernel's 2.36 ms by cut-off launches.)  Now: (a) the lane
-        // at a position that STARTS a bin of two or more entries (its entry is flagged, the next one is not) becomes the bin's
-        // owner; (b) owners put their bins in order in place -- an insertion sort on 2-3 (at most kBinMax) LDS words: by fraction,
-        // equal fractions (equal keys, or an exponent with < 128 sub-bins) by the full key from global memory, equal keys by
-        // descending index; (c) one coalesced store of the whole list.  A barrier before (b): a lane must not take an entry an
-        // owner has already moved for the start of a bin.
+        // Bins are contiguous runs of entries in ARRIVAL order; with ~0.6 keys per bin about half of the keys share theirs.
+        // (Until round 6 every entry looked at three neighbours to its left and four to its right and counted which of them belong
+        // on its other side: 8 LDS reads and ~55 VALU instructions per entry, 1.0 of the kernel's 2.36 ms by cut-off launches.)
+        // The scatter left the size of every bin at its first place: the lane that finds a size of two or more at one of its
+        // positions puts that bin in order in place -- two or three LDS words read together, compared, written back; the rare
+        // longer bin by insertion -- by fraction, equal fractions (equal keys, or an exponent with < 128 sub-bins) by the full key
+        // from global memory, equal keys by descending index.  Then one coalesced store of the whole list.
+        for (int i = fresh_tid(); i < kBinWords / 4; i += BLOCK) reinterpret_cast<uint4 *>(hist)[i] = make_uint4(0u, 0u, 0u, 0u);
         {
             const int lane6 = fresh_tid() & 63;
             uint16_t *out = prm.order + (int64_t)p * N;
             const uint32_t *row = prm.raw + (int64_t)p * N;
-            // (the counter words are free once the scatter has read them: until they are cleared at the end of this phase their
-            //  first N bytes hold, at an owner's position, the length of its bin -- an owner must know where its bin ends BEFORE
-            //  the owner of the next bin starts moving that bin's flagged first entry)
-            uint8_t *blen = reinterpret_cast<uint8_t *>(hist);
-            auto key_of = [&](uint32_t idx) -> uint32_t { return ~ikey(row, idx); };
             // does entry a belong in front of entry b?  (smaller fraction of the inverted key = larger key = earlier)
             auto before = [&](uint32_t a, uint32_t b) -> bool {
                 const uint32_t fa = a >> 16, fb = b >> 16;
-                if (fa != fb) return fa < fb;
-                const uint32_t ia = a & 0x7FFFu, ib = b & 0x7FFFu;
-                const uint32_t ka = key_of(ia), kb = key_of(ib);
-                if (ka != kb) return ka > kb;
-                return ia > ib;
+                if (__builtin_expect(fa != fb, 1)) return fa < fb;
+                return binsort_tie_before<FLOATS>(row, a & 0x7FFFu, b & 0x7FFFu);
             };
             unsigned long long own = 0ull;       // bit ch: my position of chunk ch starts a bin of >= 2 entries (CPW <= 36 chunks)
             static_assert(CPW <= 64, "one bit per chunk");
 #pragma unroll
             for (int ch = 0; ch < CPW; ++ch) {
                 const int q = (w * CPW + ch) * 64 + lane6;
-                const uint32_t me = ent[min(q, N)], r1 = ent[min(q, N) + 1];        // (entries N .. are flagged sentinels)
-                const bool owner = q < N && (me & 0x8000u) != 0u && (r1 & 0x8000u) == 0u;
-                own |= owner ? (1ull << ch) : 0ull;
-                if (owner) {
-                    int n = 2;
-                    while (n < kBinMax && (ent[q + n] & 0x8000u) == 0u) ++n;       // (a bin holds at most kBinMax entries)
-                    blen[q] = (uint8_t)n;
-                }
+                const uint32_t nb = blen[min(q, N - 1)];
+                own |= (q < N && nb >= 2u) ? (1ull << ch) : 0ull;
             }
-            lds_only_barrier();
             while (own) {
                 const int ch = __ffsll(own) - 1;
                 own &= own - 1ull;
                 const int q = (w * CPW + ch) * 64 + lane6;
                 uint32_t *bin = ent + q;
                 const int n = (int)blen[q];
-                for (int i = 1; i < n; ++i) {
-                    const uint32_t x = bin[i];
-                    int j = i;
-                    while (j > 0) {
-                        const uint32_t y = bin[j - 1];
-                        if (!before(x, y)) break;
-                        bin[j] = y;
-                        --j;
+                uint32_t x0 = bin[0], x1 = bin[1], x2 = bin[n > 2 ? 2 : 1];       // (read together: one LDS round trip)
+                if (n <= 3) {
+                    if (before(x1, x0)) { const uint32_t t = x0; x0 = x1; x1 = t; }
+                    if (n == 3) {
+                        if (before(x2, x1)) { const uint32_t t = x1; x1 = x2; x2 = t; }
+                        if (before(x1, x0)) { const uint32_t t = x0; x0 = x1; x1 = t; }
+                        bin[2] = x2;
                     }
-                    bin[j] = x;
+                    bin[0] = x0; bin[1] = x1;
+                } else if (n <= 6) {
+                    // four to six entries (~60 bins of a 10 000-key list of random scores): all read together, insertion by
+                    // compare-exchange in registers -- as an insertion sort on LDS words this path alone cost 0.7 ms per video
+                    // (one dependent LDS round trip per comparison while the rest of the wave waits)
+                    uint32_t v[6];
+                    v[0] = x0; v[1] = x1; v[2] = x2; v[3] = bin[3]; v[4] = bin[n > 4 ? 4 : 3]; v[5] = bin[n > 5 ? 5 : 3];
+#pragma unroll
+                    for (int i = 1; i < 6; ++i) {
+#pragma unroll
+                        for (int j = i; j > 0; --j) {
+                            if (i < n && before(v[j], v[j - 1])) { const uint32_t t = v[j]; v[j] = v[j - 1]; v[j - 1] = t; }
+                        }
+                    }
+                    bin[0] = v[0]; bin[1] = v[1]; bin[2] = v[2]; bin[3] = v[3];
+                    if (n > 4) bin[4] = v[4];
+                    if (n > 5) bin[5] = v[5];
+                } else {
+                    for (int i = 1; i < n; ++i) {
+                        const uint32_t x = bin[i];
+                        int j = i;
+                        while (j > 0) {
+                            const uint32_t y = bin[j - 1];
+                            if (!before(x, y)) break;
+                            bin[j] = y;
+                            --j;
+                        }
+                        bin[j] = x;
+                    }
                 }
             }
             lds_only_barrier();
-            for (int i = fresh_tid(); i < kBinWords / 4; i += BLOCK) reinterpret_cast<uint4 *>(hist)[i] = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
             for (int ch = 0; ch < CPW; ++ch) {
                 const int q = (w * CPW + ch) * 64 + lane6;
