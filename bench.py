@@ -1076,6 +1076,41 @@ def main():
         # frames): every proposal persists from frame to frame with a few pixels of jitter and keeps most of its score, so the
         # best detections of a class are the same few objects in every frame and the tubelets of a class are DISTINCT chains
         # through all frames (on independent frames the chains of all classes merge into a few).  Never part of `value`.
+        # ---- the same step with RANDOM scores (torch U(0,1), ~3 tied pairs per list): the default inputs' scores are evenly spaced
+        # ((rank + 0.5) / B per (frame, class)), which is the counting sort's best case -- every key alone in its bin; with random
+        # scores about half of the keys share a bin and phase 6 of the sort has real work.  Never part of `value`.
+        value_random = None
+        if not args.no_coherent:
+            g0 = torch.Generator(device=dev).manual_seed(555)
+            for vb_, vs_ in vids:
+                vs_.uniform_(generator=g0)
+            step_no[0] = 0
+            for _ in range(2 * nstreams):
+                step(exchange=False)
+            for cx in ctxs:
+                try:
+                    cx.sync()
+                except _lib.RetryError:
+                    pass
+            torch.cuda.synchronize()
+            no = max(args.steps // 2, 2 * nstreams)
+            t8 = time.perf_counter()
+            for _ in range(no):
+                step(exchange=False)
+            torch.cuda.synchronize()
+            rdt = time.perf_counter() - t8
+            for cx in ctxs:
+                cx.sync()
+            ctx.set_timing(2)
+            for _ in range(2):
+                step_no[0] = 0
+                step(exchange=False)
+                torch.cuda.synchronize()
+            ctx.sync()
+            rst = {k: round(ms / 2, 3) for k, (ms, n) in ctx.last_timing().items() if n}
+            ctx.set_timing(0)
+            value_random = {"value": F * B * no / rdt, "ms_per_step": rdt / no * 1e3, "steps": no, "stage_ms_one_video": rst,
+                            "scores": "torch U(0,1) on the default boxes (ties possible; the sort's bins hold 0..6 keys)"}
         value_coherent = None
         if not args.no_coherent:
             g = torch.Generator(device=dev).manual_seed(977)
@@ -1272,6 +1307,7 @@ def main():
                 "note": "each rank's own wall time for the K timed steps (its video per step + the exchange); value uses the MAX"},
             "single_video_ms": single_video_ms,          # one video at a time (no videos in flight): the latency of one step
             "value_other_scores": value_other,           # the same step on the other synthetic score distribution
+            "value_random_scores": value_random,         # ... with random instead of evenly spaced scores (the sort has real bins to order)
             "value_coherent": value_coherent,            # ... on a coherent video (proposals persist from frame to frame)
             "hbm_traffic_per_video": hbm_total,          # sum of the PMC table (profiles/pmc_traffic.json), all kernels of one step
             "vid_shape": vid_shape,
