@@ -1,6 +1,8 @@
-"""-m gpu: the adjacency build of regular large frames (csrc/adjrows_kernels.hpp: one workgroup per 64-row strip, slab offsets
-from a pre-pass) on the shapes its paths branch on, against the oracle's per-(frame, class) NMS (utils/nms.pyx:17-68) and
-against adj_build_kernel (VDET_ADJ_ROWS=0):
+"""-m gpu: the adjacency build of regular large frames -- the DIRECT lists (iou_bits_sym_kernel<true, true>: entries straight
+from the predicate blocks into fixed slots per row + adj_finish_kernel; the default), the rows kernel behind the bit matrix
+(csrc/adjrows_kernels.hpp: one workgroup per 64-row strip, slab offsets from a pre-pass; VDET_DIRECT_LISTS=0, and what a frame
+with a row of more neighbours than a slot holds falls back to) -- on the shapes their paths branch on, against the oracle's
+per-(frame, class) NMS (utils/nms.pyx:17-68) and against adj_build_kernel (VDET_ADJ_ROWS=0):
   * a strip whose slab does not fit the 16 KB LDS stage (a dense frame: entries go straight to the pool),
   * more than 64 existing column words per strip (wide boxes in a narrow frame, low threshold: the extra round trips),
   * B not a multiple of 64 / of 256, B just above the small-frame limit (385), B = 17 400 (272 word-rows > 256 threads),
@@ -27,8 +29,9 @@ def _nms_both_kernels(monkeypatch, boxes, scores, thresh, cap):
     from vdetlib_amd import ops, _lib
     tb, ts = torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda()
     out = []
-    for flag in ("1", "0"):
-        monkeypatch.setenv("VDET_ADJ_ROWS", flag)
+    for rows, direct in (("1", "1"), ("0", "1"), ("1", "0")):       # direct lists (default) / lane per row / rows kernel
+        monkeypatch.setenv("VDET_ADJ_ROWS", rows)
+        monkeypatch.setenv("VDET_DIRECT_LISTS", direct)
         cx = _lib.Context(torch.cuda.current_device())
         idx, cnt = ops.nms_volume(tb, ts, thresh, cap=cap, ctx=cx)
         out.append((idx.cpu().numpy(), cnt.cpu().numpy(), cx.query(2)))
@@ -53,9 +56,10 @@ def test_adjacency_rows_against_oracle_and_lane_per_row_kernel(name, oracle, mon
     rng = np.random.RandomState(len(name) * 131 + B)
     boxes = np.stack([_boxes(rng, B, fw, fh, wmax, hmax) for _ in range(F)])
     scores = synth.tie_free_scores(rng, F * B * C).reshape(F, B, C).astype(np.float32)
-    (idx, cnt, reg), (idx0, cnt0, reg0) = _nms_both_kernels(monkeypatch, boxes, scores, t, cap=B)
-    assert reg == 1 and reg0 == 1                       # every frame regular: the rows kernel ran
+    (idx, cnt, reg), (idx0, cnt0, reg0), (idx1, cnt1, reg1) = _nms_both_kernels(monkeypatch, boxes, scores, t, cap=B)
+    assert reg == 1 and reg0 == 1 and reg1 == 1         # every frame regular: the direct lists / the rows kernel ran
     assert np.array_equal(cnt, cnt0) and np.array_equal(idx, idx0)
+    assert np.array_equal(cnt, cnt1) and np.array_equal(idx, idx1)
     widx, wcnt = oracle.nms_volume(boxes, scores, t, cap=B)
     assert np.array_equal(cnt, wcnt) and np.array_equal(idx, widx)
 
@@ -88,13 +92,44 @@ def test_rescoring_candidates_do_not_depend_on_list_order(monkeypatch):
     boxes, scores = synth.video(4242, 12, 2000, 6)
     tb, ts = torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda()
     res = []
-    for flag in ("1", "0"):
-        monkeypatch.setenv("VDET_ADJ_ROWS", flag)
+    for rows, direct in (("1", "1"), ("0", "1"), ("1", "0")):
+        monkeypatch.setenv("VDET_ADJ_ROWS", rows)
+        monkeypatch.setenv("VDET_DIRECT_LISTS", direct)
         cx = _lib.Context(torch.cuda.current_device())
         cx.set_cache(True)
         ki, kc, tr, an, nt = ops.nms_track_volume(tb, ts, nms_thres=0.3, thres=0.5, max_tracks=5, link_thres=0.5, cap=2000, ctx=cx)
         det, tp, tbx = ops.rescore_tracks(tr, nt, tb, ts, overlap_thres=0.7, window=3, ctx=cx)
         res.append([x.cpu().numpy() for x in (ki, kc, tr, an, nt, det, tp, tbx)])
         cx.close()
-    for a, b in zip(*res):
-        assert np.array_equal(a, b, equal_nan=True)
+    for a, b, d in zip(*res):
+        assert np.array_equal(a, b, equal_nan=True) and np.array_equal(a, d, equal_nan=True)
+
+
+@pytest.mark.parametrize("slot", [8, 96, 384])
+def test_direct_lists_slot_sizes_and_the_fallback(slot, oracle, monkeypatch):
+    """VDET_DIRECT_CAP = entries per row slot.  8 / 96: rows with more neighbours than a slot holds (degree ~ 90 here) -- the build
+    latches the overflow, the context takes the bit-matrix path for good and the results are the oracle's; 384: (nearly) everything fits.
+    Synchronous and asynchronous (the overflow of an asynchronous build is a RetryError at sync, the repeat succeeds)."""
+    import torch
+    from vdetlib_amd import ops, _lib
+    rng = np.random.RandomState(7 + slot)
+    F, B, C = 3, 2500, 3
+    boxes = np.stack([_boxes(rng, B, 640, 480, 300, 300) for _ in range(F)])
+    scores = synth.tie_free_scores(rng, F * B * C).reshape(F, B, C).astype(np.float32)
+    widx, wcnt = oracle.nms_volume(boxes, scores, 0.3, cap=B)
+    monkeypatch.setenv("VDET_DIRECT_CAP", str(slot))
+    tb, ts = torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda()
+    cx = _lib.Context(torch.cuda.current_device())
+    idx, cnt = ops.nms_volume(tb, ts, 0.3, cap=B, ctx=cx)
+    assert np.array_equal(cnt.cpu().numpy(), wcnt) and np.array_equal(idx.cpu().numpy(), widx)
+    cx.close()
+    # asynchronous: a sparse video first (its direct build fits a slot of 96 or 384 entries), then the dense one
+    cx = _lib.Context(torch.cuda.current_device())
+    cx.set_cache(True)
+    cx.set_async(True)
+    sparse = np.stack([_boxes(rng, B, 4000, 3000, 120, 120) for _ in range(F)])
+    ops.nms_volume(torch.from_numpy(sparse).cuda(), ts, 0.3, cap=B, ctx=cx)
+    cx.invalidate()
+    idx, cnt = ops.nms_volume(tb, ts, 0.3, cap=B, ctx=cx)      # sync=True: repeats the enqueue by itself after a RetryError
+    assert np.array_equal(cnt.cpu().numpy(), wcnt) and np.array_equal(idx.cpu().numpy(), widx)
+    cx.close()

@@ -268,4 +268,58 @@ __global__ __launch_bounds__(256) void adj_rows_kernel(const GroupDesc *__restri
     }
 }
 
+// The direct lists' second half (iou_bits_sym_kernel<true, true> wrote the entries into fixed slots and left every row's degree in
+// its cursor): pad each list to a multiple of 8 entries (with the row's own box) and write the rows' records (row_meta,
+// the walk's 32-byte and 16-byte records) -- exactly what adj_rows_kernel's wave 1 writes.  One thread per row, grid = the
+// batch's tiles.  A degree above the slot's capacity latches `over_bits` (the host rebuilds the graph through the bit matrix).
+__global__ __launch_bounds__(256) void adj_finish_kernel(const GroupDesc *__restrict__ groups, const TileDesc *__restrict__ tiles,
+                                                         const uint32_t *__restrict__ row_deg, uint2 *__restrict__ row_meta,
+                                                         uint16_t *__restrict__ adj, uint32_t slot_cap, int *__restrict__ status,
+                                                         const uint32_t *__restrict__ group_flags, const float4 *__restrict__ xbox_all,
+                                                         const uint16_t *__restrict__ xord_all, int over_bits,
+                                                         WalkMeta *__restrict__ wmeta, uint4 *__restrict__ wmeta16)
+{
+    const TileDesc td = tiles[blockIdx.x];
+    const uint32_t gf = group_flags[td.group];
+    if (!(gf & kFlagRegular)) return;
+    const GroupDesc gd = groups[td.group];
+    const int v = td.row_tile * kRowsPerTile + (int)threadIdx.x;
+    if (v >= gd.nbox) return;
+    const uint32_t row = (uint32_t)(gd.box_off + v);
+    const uint32_t deg = row_deg[row];
+    const int vo = (int)xord_all[row];
+    const float4 bx = xbox_all[row];
+    const bool over = deg > slot_cap;
+    if (over) atomicOr(status, over_bits);
+    const uint32_t p = over ? 0u : row * slot_cap;
+    const uint32_t d = over ? 0u : deg;
+    // padding = the row's OWN box: the walk applies whole 16-byte pieces, and a survivor that marks itself dead after it has been
+    // kept changes nothing (every candidate is looked at once); every other reader of a list stops at its degree
+    if (d & 7u) {
+        uint16_t *l = adj + (uint64_t)p;
+        for (uint32_t k = d; k < ((d + 7u) & ~7u); ++k) l[k] = (uint16_t)vo;
+    }
+    row_meta[gd.box_off + vo] = make_uint2(p, d);
+    const bool rec16 = wmeta16 && (gf & kFlagU16);       // (the walk takes the 16-byte record of such a frame: no 32-byte one)
+    if (wmeta && !rec16) {
+        wmeta[gd.box_off + vo].box = over ? make_float4(0.f, 0.f, 0.f, 0.f) : bx;
+        wmeta[gd.box_off + vo].row = make_uint4(p, d, 0u, 0u);
+    }
+    if (rec16)
+        wmeta16[gd.box_off + vo] = over ? make_uint4(0u, 0u, 0u, 0u)
+                                        : make_uint4((uint32_t)bx.x | ((uint32_t)bx.y << 16), (uint32_t)bx.z | ((uint32_t)bx.w << 16), p, d);
+}
+
+// (direct lists, failure path only) the pool the bit-matrix path needs for the same graph: the padded degrees, summed
+__global__ __launch_bounds__(256) void deg_sum_kernel(const uint32_t *__restrict__ row_deg, int64_t n, unsigned long long *__restrict__ out)
+{
+    unsigned long long s = 0ull;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += (row_deg[i] + 7u) & ~7u;
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(out, s);
+}
+
+// (direct lists) the dynamic part of the pool -- the lists of irregular frames, adj_build_kernel -- starts behind the fixed slots
+__global__ void pool_start_kernel(unsigned long long *pool_used, unsigned long long first) { *pool_used = first; }
+
 }  // namespace vdet

@@ -134,6 +134,11 @@ struct vdet_ctx {
     bool atomic_rank = false;     // LDS returning atomics serve same-address lanes in lane order (probed; VDET_ATOMIC_RANK=0: ballot match)
     bool small_lists = true;      // VDET_SMALL_LISTS=0: frames of <= 384 boxes through the large-list sort and walk too (small_kernels.hpp)
     bool adj_rows = true;         // VDET_ADJ_ROWS=0: adj_build_kernel (a lane per row) also for the regular frames of large volumes
+    bool direct_lists = true;     // VDET_DIRECT_LISTS=0: regular frames through the bit matrix + adj_rows_kernel (also taken, for good,
+                                  // once a row had more neighbours than a direct slot holds)
+    uint32_t direct_cap = 384;    // entries per row slot of the direct lists (a multiple of 8)
+    int64_t direct_ntot = 0;      // rows / fixed part of the pool of the last direct build (the failure path sizes the pool from them)
+    unsigned long long direct_fixed = 0;
     bool no_fused = false;        // VDET_NO_FUSED=1: the host-buffer calls of <= 640 rows through the general kernel chain too (the path of larger inputs)
     bool binsort = true;          // VDET_BINSORT=0: the LSD radix kernel (the fallback of tied / thresholded columns) for every column
     const std::vector<GroupDesc> *host_groups = nullptr;   // group table of the call in flight (mode 2)
@@ -391,10 +396,18 @@ int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32, doub
                                      hipMemcpyHostToDevice, c->stream));
         c->vplan_valid = volume;         // (a host-call plan overwrites the volume tables)
     }
-    const unsigned long long min_pool = (unsigned long long)pl.ntot * 32;
+    // direct lists (iou_bits_sym_kernel<true, true>): regular frames of large volumes get a fixed slot per row at the start of
+    // the pool, the dynamic part (irregular frames) follows
+    auto direct_now = [&]() {
+        return c->direct_lists && c->adj_rows && c->wave_transpose && pl.nmax > 384 && t32 > 1e-30f && t32 < INFINITY && !c->force_general &&
+               (size_t)8 * pl.nmax + 24 * 1024 <= c->max_lds && (unsigned long long)pl.ntot * c->direct_cap * 2ull <= 0xFFFFFFFFull;     // (byte offsets of the entries in 32 bits)
+    };
+    auto fixed_pool = [&]() { return direct_now() ? (unsigned long long)pl.ntot * c->direct_cap : 0ull; };
+    unsigned long long min_pool = fixed_pool() + (unsigned long long)pl.ntot * (direct_now() ? 1 : 32);
     const bool async = volume && c->async_enabled && c->pool_hint > 0;
     if (async) {
-        const unsigned long long want = std::max(min_pool, c->pool_hint + c->pool_hint / 2);
+        const unsigned long long dyn_hint = c->pool_hint > fixed_pool() ? c->pool_hint - fixed_pool() : 0ull;
+        const unsigned long long want = std::max(min_pool, fixed_pool() + dyn_hint + dyn_hint / 2);
         if (c->adj.cap < want * 2) HIPCHK(c, c->adj.reserve((size_t)want * 2 + 4096));
     } else {
         // the caller's host vectors must outlive the async copies; also pick up a failure latched by an
@@ -407,7 +420,10 @@ int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32, doub
         if (c->adj.cap < min_pool * 2) HIPCHK(c, c->adj.reserve((size_t)min_pool * 2 + 4096));
     }
 
-    for (int attempt = 0; attempt < 2; ++attempt) {
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        const bool direct = direct_now();
+        min_pool = fixed_pool() + (unsigned long long)pl.ntot * (direct ? 1 : 32);
+        if (!async && c->adj.cap < min_pool * 2) HIPCHK(c, c->adj.reserve((size_t)min_pool * 2 + 4096));
         HIPCHK(c, hipMemsetAsync(c->rowz.p, 0, (size_t)pl.ntot * 4, c->stream));
         HIPCHK(c, hipMemsetAsync(c->rowmeta.p, 0, (size_t)pl.ntot * 8, c->stream));
         HIPCHK(c, hipMemsetAsync(c->groupz.p, 0, G * 4, c->stream));
@@ -416,6 +432,10 @@ int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32, doub
             HIPCHK(c, hipMemsetAsync((char *)c->d_cnt + kPerBuildOff, 0, sizeof(Counters) - kPerBuildOff, c->stream));
         }
         else HIPCHK(c, hipMemsetAsync(c->d_cnt, 0, sizeof(Counters), c->stream));
+        c->direct_ntot = direct ? pl.ntot : 0;
+        c->direct_fixed = fixed_pool();
+        if (direct) hipLaunchKernelGGL(pool_start_kernel, dim3(1), dim3(1), 0, c->stream, &c->d_cnt->pool_used, fixed_pool());
+        const int pool_bits = async ? (kStPool | kStPoolAsync) : kStPool;
         const unsigned long long pool_cap = (c->adj.cap - 2048) / 2;     // (the packed walk reads up to 256 B past a list)
         // fast symmetric kernel for regular frames needs 0 < t32 < inf (exact divide-free test)
         // ... and the x1 index, whose sort must fit the LDS (8 B per box + tables)
@@ -453,7 +473,13 @@ int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32, doub
             uint64_t *bits_b = c->bits.as<uint64_t>();
             if (use_sym && bp.second > bp.first) {
                 StageTimer tm(c, ST_IOU_BITS);
-                if (c->wave_transpose)
+                if (direct)
+                    hipLaunchKernelGGL((iou_bits_sym_kernel<true, true>), dim3(bp.second - bp.first), dim3(256), 0, c->stream,
+                                       c->xbox.as<float4>(), c->groups.as<GroupDesc>(), c->gflags.as<uint32_t>(),
+                                       c->pairs.as<TilePair>() + bp.first, t32, one_minus_t, bits_b, c->rowz.as<uint32_t>(),
+                                       c->reachtab.as<float2>(), c->xord.as<uint16_t>(), c->adj.as<uint16_t>(), c->direct_cap,
+                                       &c->d_cnt->status, pool_bits | kStDirect);
+                else if (c->wave_transpose)
                     hipLaunchKernelGGL(iou_bits_sym_kernel<true>, dim3(bp.second - bp.first), dim3(256), 0, c->stream,
                                        c->xbox.as<float4>(), c->groups.as<GroupDesc>(), c->gflags.as<uint32_t>(),
                                        c->pairs.as<TilePair>() + bp.first, t32, one_minus_t, bits_b, c->rowz.as<uint32_t>(),
@@ -495,7 +521,15 @@ int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32, doub
                                    c->wmeta_built ? c->wmeta.as<WalkMeta>() : (WalkMeta *)nullptr,
                                    use_sym ? c->reachtab.as<float2>() : (const float2 *)nullptr, rows_path ? 1 : 0);
                 // regular groups of large frames: one workgroup per 64-row strip, half a wave per row (adjrows_kernels.hpp)
-                if (rows_path) {
+                if (rows_path && direct) {
+                    hipLaunchKernelGGL(adj_finish_kernel, dim3(nt), dim3(256), 0, c->stream, c->groups.as<GroupDesc>(),
+                                       c->tiles.as<TileDesc>() + bt.first, c->rowz.as<uint32_t>(), c->rowmeta.as<uint2>(),
+                                       c->adj.as<uint16_t>(), c->direct_cap, &c->d_cnt->status, c->gflags.as<uint32_t>(),
+                                       c->xbox.as<float4>(), c->xord.as<uint16_t>(), pool_bits | kStDirect,
+                                       c->wmeta_built ? c->wmeta.as<WalkMeta>() : (WalkMeta *)nullptr,
+                                       c->wmeta_built ? c->wmeta16.as<uint4>() : (uint4 *)nullptr);
+                    c->wmeta16_built = c->wmeta_built;
+                } else if (rows_path) {
                     // every strip's slab offset first (two small launches instead of an atomic per strip on one address)
                     HIPCHK(c, c->striptot.reserve((size_t)4 * nt * 4));
                     HIPCHK(c, c->stripoff.reserve((size_t)4 * nt * 8));
@@ -527,8 +561,12 @@ int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32, doub
             c->pool_hint = std::max(c->pool_hint, h.pool_used);
             return VDET_OK;
         }
+        if (h.status & kStDirect) {     // a row with more neighbours than a direct slot holds: through the bit matrix from now on
+            c->direct_lists = false;
+            continue;
+        }
         if (h.pool_used > 0xFFFFFFFFull) return fail(c, VDET_ENOMEM, "suppression graph has more than 2^32 edges");
-        if (attempt == 1) break;
+        if (attempt == 2) break;
         HIPCHK(c, c->adj.reserve((size_t)h.pool_used * 2 + 4096));
     }
     return fail(c, VDET_EHIP, "internal: adjacency pool overflow after regrow");
@@ -1089,6 +1127,8 @@ int vdet_create(vdet_ctx **out, int device)
     if (const char *e = getenv("VDET_NO_LAZY")) c->no_lazy = atoi(e) != 0;
     if (const char *e = getenv("VDET_NO_FUSED")) c->no_fused = atoi(e) != 0;
     if (const char *e = getenv("VDET_ADJ_ROWS")) c->adj_rows = atoi(e) != 0;
+    if (const char *e = getenv("VDET_DIRECT_LISTS")) c->direct_lists = atoi(e) != 0;
+    if (const char *e = getenv("VDET_DIRECT_CAP")) { const int v = atoi(e); if (v >= 8 && v <= 32760) c->direct_cap = (uint32_t)(v & ~7); }
     if (const char *e = getenv("VDET_BINSORT")) c->binsort = atoi(e) != 0;
     if (const char *e = getenv("VDET_SMALL_LISTS")) c->small_lists = atoi(e) != 0;
     {   // probe: do returning LDS atomics resolve same-address lanes in ascending lane order?
@@ -1279,6 +1319,19 @@ int vdet_sync(vdet_ctx *c)
         // since is invalid.  The pool is enlarged here, so running the same calls again succeeds.
         // (handled before a latched error of the same window is reported: the truncated graph must not be reused)
         c->graph_valid = c->lists_valid = c->nodes_valid = false;
+        if (h.status & kStDirect) {      // a direct slot overflowed: the bit-matrix path from now on, its pool sized from the cursors
+            c->direct_lists = false;
+            unsigned long long need = 0ull;
+            if (c->direct_ntot > 0 && c->striptot.reserve(8) == hipSuccess &&
+                hipMemsetAsync(c->striptot.p, 0, 8, c->stream) == hipSuccess) {
+                hipLaunchKernelGGL(deg_sum_kernel, dim3(1024), dim3(256), 0, c->stream, c->rowz.as<uint32_t>(), c->direct_ntot,
+                                   c->striptot.as<unsigned long long>());
+                if (hipMemcpyAsync(&need, c->striptot.p, 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess || host_sync(c) != hipSuccess) need = 0ull;
+            }
+            const unsigned long long dyn = h.pool_used > c->direct_fixed ? h.pool_used - c->direct_fixed : 0ull;
+            h.pool_used = need + dyn + 4096;
+            c->pool_hint = 0;            // (the hint of the direct builds counted the fixed slots)
+        }
         c->pool_hint = std::max(c->pool_hint, h.pool_used);
         if (h.pool_used <= 0xFFFFFFFFull) (void)c->adj.reserve((size_t)(h.pool_used + h.pool_used / 2) * 2 + 4096);
         if (l && l != VDET_EAGAIN) return l;
