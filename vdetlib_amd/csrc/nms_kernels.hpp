@@ -588,14 +588,23 @@ __global__ __launch_bounds__(256, DIRECT ? 6 : 1) void iou_bits_sym_kernel(
                                                            const float2 *__restrict__ reach_table,
                                                            const uint16_t *__restrict__ xord_all = nullptr,
                                                            uint16_t *__restrict__ adj = nullptr, uint32_t slot_cap = 0u,
-                                                           int *__restrict__ status = nullptr, int over_bits = 0)
+                                                           int *__restrict__ status = nullptr, int over_bits = 0, int npairs = 0)
 {
     static_assert(WT || !DIRECT, "the direct lists need the in-wave transpose");
     __shared__ float4 sbox[256];
     __shared__ float sarea[256];
     __shared__ uint16_t scord[DIRECT ? 256 : 1];      // DIRECT: box index of the tile's columns / of the tile's rows
     __shared__ uint16_t srord[DIRECT ? 256 : 1];
-    const TilePair tp = pairs[blockIdx.x];
+    // DIRECT: block b runs on XCD b % 8 (round-robin dispatch); give every XCD a CONTIGUOUS eighth of the pair list -- whole
+    // frames -- so that the partially written lines of a row's slot live in ONE L2 until the frame is done (with the frame's
+    // blocks spread over all XCDs every L2 held its own partial copy of every line: 4.3 x write amplification, PMC WRITE_SIZE)
+    int pidx = blockIdx.x;
+    if (DIRECT) {
+        const int per = gridDim.x >> 3;           // (the grid is the pair count rounded up to a multiple of 8)
+        pidx = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+        if (pidx >= npairs) return;
+    }
+    const TilePair tp = pairs[pidx];
     if (!(group_flags[tp.group] & kFlagRegular)) return;
     const GroupDesc gd = groups[tp.group];
     const int B = gd.nbox;

@@ -474,11 +474,11 @@ int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32, doub
             if (use_sym && bp.second > bp.first) {
                 StageTimer tm(c, ST_IOU_BITS);
                 if (direct)
-                    hipLaunchKernelGGL((iou_bits_sym_kernel<true, true>), dim3(bp.second - bp.first), dim3(256), 0, c->stream,
+                    hipLaunchKernelGGL((iou_bits_sym_kernel<true, true>), dim3((bp.second - bp.first + 7) & ~7), dim3(256), 0, c->stream,
                                        c->xbox.as<float4>(), c->groups.as<GroupDesc>(), c->gflags.as<uint32_t>(),
                                        c->pairs.as<TilePair>() + bp.first, t32, one_minus_t, bits_b, c->rowz.as<uint32_t>(),
                                        c->reachtab.as<float2>(), c->xord.as<uint16_t>(), c->adj.as<uint16_t>(), c->direct_cap,
-                                       &c->d_cnt->status, pool_bits | kStDirect);
+                                       &c->d_cnt->status, pool_bits | kStDirect, bp.second - bp.first);
                 else if (c->wave_transpose)
                     hipLaunchKernelGGL(iou_bits_sym_kernel<true>, dim3(bp.second - bp.first), dim3(256), 0, c->stream,
                                        c->xbox.as<float4>(), c->groups.as<GroupDesc>(), c->gflags.as<uint32_t>(),
