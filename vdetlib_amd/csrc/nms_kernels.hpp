@@ -567,44 +567,17 @@ __global__ __launch_bounds__(256) void reach_table_kernel(const float4 *__restri
 
 // (the 32-pair loops are unrolled 8 at a time: fully unrolled, the scheduler hoists the LDS reads of a dozen columns and
 //  ends at 158 registers, 3 waves per SIMD and 2.5 ms)
-// DIRECT (round 6, WT only): no bit matrix at all.  The wave that finishes a 64 x 64 block takes its words apart on the spot
-// and appends the entries to the rows' lists, which live in FIXED slots of slot_cap entries per row (slot of rank-row v of
-// the group at (box_off + v) * slot_cap): the row's degree counter doubles as the list's cursor -- one RETURNING atomicAdd per
-// (row, non-zero word) reserves the places, the entries (box indices, translated through LDS copies of the tile's xord) leave
-// as 2-byte stores.  The atomics of a block are issued when the block is done and their results are used one block later
-// (the next block's ~80 000 issue slots of pair tests hide the round trip).  adj_finish_kernel pads the lists and writes the
-// walk's records.  A row with more neighbours than a slot holds latches `over_bits` (its surplus entries are dropped): the host
-// rebuilds the graph through the bit matrix (adj_rows_kernel).  Entry order inside a list depends on the order of the atomics;
-// lists are sets to every consumer.
-// (6 blocks per CU asked for explicitly: the pending block's state takes the direct form to 82 registers otherwise -- 5 waves per
-//  SIMD, measured 3 % slower than 80 registers with two spills outside the pair loop)
-template <bool WT, bool DIRECT = false>
-__global__ __launch_bounds__(256, DIRECT ? 6 : 1) void iou_bits_sym_kernel(
-                                                           const float4 *__restrict__ xbox,
+template <bool WT>
+__global__ __launch_bounds__(256) void iou_bits_sym_kernel(const float4 *__restrict__ xbox,
                                                            const GroupDesc *__restrict__ groups,
                                                            const uint32_t *__restrict__ group_flags,
                                                            const TilePair *__restrict__ pairs, float t32, float one_minus_t,
                                                            uint64_t *__restrict__ bits, uint32_t *__restrict__ row_deg,
-                                                           const float2 *__restrict__ reach_table,
-                                                           const uint16_t *__restrict__ xord_all = nullptr,
-                                                           uint16_t *__restrict__ adj = nullptr, uint32_t slot_cap = 0u,
-                                                           int *__restrict__ status = nullptr, int over_bits = 0, int npairs = 0)
+                                                           const float2 *__restrict__ reach_table)
 {
-    static_assert(WT || !DIRECT, "the direct lists need the in-wave transpose");
     __shared__ float4 sbox[256];
     __shared__ float sarea[256];
-    __shared__ uint16_t scord[DIRECT ? 256 : 1];      // DIRECT: box index of the tile's columns / of the tile's rows
-    __shared__ uint16_t srord[DIRECT ? 256 : 1];
-    // DIRECT: block b runs on XCD b % 8 (round-robin dispatch); give every XCD a CONTIGUOUS eighth of the pair list -- whole
-    // frames -- so that the partially written lines of a row's slot live in ONE L2 until the frame is done (with the frame's
-    // blocks spread over all XCDs every L2 held its own partial copy of every line: 4.3 x write amplification, PMC WRITE_SIZE)
-    int pidx = blockIdx.x;
-    if (DIRECT) {
-        const int per = gridDim.x >> 3;           // (the grid is the pair count rounded up to a multiple of 8)
-        pidx = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-        if (pidx >= npairs) return;
-    }
-    const TilePair tp = pairs[pidx];
+    const TilePair tp = pairs[blockIdx.x];
     if (!(group_flags[tp.group] & kFlagRegular)) return;
     const GroupDesc gd = groups[tp.group];
     const int B = gd.nbox;
@@ -638,76 +611,10 @@ __global__ __launch_bounds__(256, DIRECT ? 6 : 1) void iou_bits_sym_kernel(
         sarea[tid] = box_area(bc);
         if (ints) { bc.z += 1.0f; bc.w += 1.0f; }
         sbox[tid] = bc;
-        if (DIRECT) {
-            scord[tid] = u < B ? xord_all[gd.box_off + u] : (uint16_t)0;
-            srord[tid] = v < B ? xord_all[gd.box_off + v] : (uint16_t)0;
-        }
     }
-    // (DIRECT: the blocks' reach entries are fetched before the loop -- a global load inside it would be waited for with
-    //  vmcnt(0), i.e. together with the atomics issued just before it, whose round trip the next block is meant to hide)
-    float first_c[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q)     // (wave-uniform: scalar registers)
-        first_c[q] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint((tp.ct * 4 + q < W) ? rtab[tp.ct * 4 + q].y : 3.0e38f)));
     __syncthreads();
     const int rows_left = B - r * 64;
     const unsigned long long rowvalid = rows_left >= 64 ? ~0ull : (rows_left > 0 ? ((1ull << rows_left) - 1ull) : 0ull);
-
-    // DIRECT: the block whose atomics are in flight (row word / transposed word, the returned cursors, its column block)
-    unsigned long long pm = 0ull, ptm = 0ull;
-    uint32_t pat = 0u, ptat = 0u;
-    int pq = -1;
-    // one 32-bit half of a word -> entries.  A wave's 64 lanes hold ~54 entries per half on average (config 2), seldom more than
-    // 4 in one lane: the first kSlots bits of every lane go out as STRAIGHT-LINE code -- all bit positions, then all translations
-    // (the LDS reads in flight together), then the stores under their own exec masks -- instead of a loop whose every turn is a
-    // ballot, three branches and an exposed LDS round trip (the loop form cost 0.42 ms per config-2 video); the rare lane with
-    // more bits finishes in the loop.  32-bit bit tricks, a byte OFFSET into the pool next to its scalar base.
-    constexpr int kSlots = 4;
-    auto emit_half = [&](uint32_t h, uint32_t boff, const uint16_t *ids) {
-        if (__ballot(h != 0u) == 0ull) return;                   // (wave-uniform)
-        uint32_t hk[kSlots];
-        uint16_t ek[kSlots];
-#pragma unroll
-        for (int k = 0; k < kSlots; ++k) { hk[k] = h; h &= h - 1u; }
-#pragma unroll
-        for (int k = 0; k < kSlots; ++k) ek[k] = ids[__builtin_ctz(hk[k]) & 31];      // (an empty slot reads ids[31]: in bounds, unused)
-#pragma unroll
-        for (int k = 0; k < kSlots; ++k) {
-            if (hk[k] != 0u) {
-                *reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(adj) + (boff + 2u * k)) = ek[k];
-            }
-        }
-        boff += 2u * kSlots;
-        while (__ballot(h != 0u) != 0ull) {
-            if (h != 0u) {
-                const uint16_t e = ids[__builtin_ctz(h)];
-                *reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(adj) + boff) = e;
-                boff += 2u;
-                h &= h - 1u;
-            }
-        }
-    };
-    auto emit_pending = [&]() {
-        if (!DIRECT || pq < 0) return;
-        const int pc = tp.ct * 4 + pq;
-        {   // my row's entries: the columns of block pc
-            unsigned long long m = pm;
-            const uint32_t cnt = (uint32_t)__popcll(m);
-            if (pat + cnt > slot_cap) { if (cnt) atomicOr(status, over_bits); m = 0ull; }
-            const uint32_t boff = ((uint32_t)(gd.box_off + v) * slot_cap + pat) * 2u;
-            emit_half((uint32_t)m, boff, scord + pq * 64);
-            emit_half((uint32_t)(m >> 32), boff + 2u * (uint32_t)__popc((uint32_t)m), scord + pq * 64 + 32);
-        }
-        if (pc > r) {   // the transposed block: entries of row pc * 64 + lane are rows of this wave
-            unsigned long long m = ptm;
-            const uint32_t cnt = (uint32_t)__popcll(m);
-            if (ptat + cnt > slot_cap) { if (cnt) atomicOr(status, over_bits); m = 0ull; }
-            const uint32_t boff = ((uint32_t)(gd.box_off + pc * 64 + lane) * slot_cap + ptat) * 2u;
-            emit_half((uint32_t)m, boff, srord + w * 64);
-            emit_half((uint32_t)(m >> 32), boff + 2u * (uint32_t)__popc((uint32_t)m), srord + w * 64 + 32);
-        }
-        pq = -1;
-    };
 
     uint32_t dsum = 0;
     for (int q = 0; q < 4; ++q) {
@@ -719,7 +626,7 @@ __global__ __launch_bounds__(256, DIRECT ? 6 : 1) void iou_bits_sym_kernel(
         uint32_t lo = 0, hi = 0, tlo = 0, thi = 0;
         // the reach test per 64 x 64 block (the columns of block c start at first[c]): a block out of reach is neither
         // evaluated nor written -- K2 applies the same test before it reads
-        if (rows_left <= 0 || (c > r && first_c[q] > my_reach)) continue;
+        if (rows_left <= 0 || (c > r && rtab[c].y > my_reach)) continue;
         {
             bool anyb = false;
             if (WT) {
@@ -798,19 +705,6 @@ __global__ __launch_bounds__(256, DIRECT ? 6 : 1) void iou_bits_sym_kernel(
         }
         unsigned long long m = (((unsigned long long)hi << 32) | lo) & colvalid;
         if (c == r) m &= ~(1ull << lane);        // no self edge
-        if (DIRECT) {
-            emit_pending();                      // the previous block's entries: its cursors have had a block's time to arrive
-            if (v >= B) m = 0ull;
-            unsigned long long tm = 0ull;
-            const int u = c * 64 + lane;
-            if (c > r && u < B) tm = (((unsigned long long)thi << 32) | tlo) & rowvalid;
-            const uint32_t cnt = (uint32_t)__popcll(m), tcnt = (uint32_t)__popcll(tm);
-            pat = 0u; ptat = 0u;
-            if (cnt) pat = atomicAdd(&row_deg[gd.box_off + v], cnt);
-            if (tcnt) ptat = atomicAdd(&row_deg[gd.box_off + u], tcnt);
-            pm = m; ptm = tm; pq = q;
-            continue;
-        }
         if (v < B) { bits[gd.bits_off + bit_word(B, v, c)] = m; dsum += (uint32_t)__popcll(m); }
         if (c > r) {
             const int u = c * 64 + lane;
@@ -822,7 +716,6 @@ __global__ __launch_bounds__(256, DIRECT ? 6 : 1) void iou_bits_sym_kernel(
             }
         }
     }
-    if (DIRECT) { emit_pending(); return; }
     // the rows' degrees (list lengths) come for free here; adj_build_kernel does not have to count them
     if (dsum) atomicAdd(&row_deg[gd.box_off + v], dsum);
 }

@@ -22,6 +22,7 @@
 #include "detnms_kernels.hpp"
 #include "fused_kernels.hpp"
 #include "adjrows_kernels.hpp"
+#include "graphlists_kernels.hpp"
 #include "temporal_kernels.hpp"
 #include "tubelet_kernels.hpp"
 #include "track_kernels.hpp"
@@ -86,6 +87,8 @@ struct NmsPlan {
     std::vector<TilePair> pairs;     // upper-triangle 256x256 tile pairs, ordered by batch
     std::vector<std::pair<int, int>> batch_tiles;  // [t0, t1) per batch
     std::vector<std::pair<int, int>> batch_pairs;  // [p0, p1) per batch
+    std::vector<ListItem> ditems;    // direct lists (graph_lists_kernel): one work item per (row tile, width quartile)
+    std::vector<std::pair<int, int>> batch_ditems;
     size_t bits_words_max = 0;       // largest batch
     int64_t ntot = 0;
     int nmax = 0;
@@ -105,7 +108,7 @@ struct vdet_ctx {
     int n_cu = 256;
     // scratch
     DevBuf boxes, scores, keys, excl, frames, groups, tiles, bits, rowz, rowmeta, groupz, adj, comp, origidx,
-        out64, trk_frames, trk_boxes, b1, b2, iou_out, order, ncand, keepidx, keepcnt, gflags, pairs, tkeys, tstate, visited, heads, xkeys, xord, wmeta, wmeta16, reachtab, striptot, stripoff, xncand, xbox, xbox16, xord16, xcum, xinfo, tmp[8];
+        out64, trk_frames, trk_boxes, b1, b2, iou_out, order, ncand, keepidx, keepcnt, gflags, pairs, tkeys, tstate, visited, heads, xkeys, xord, wmeta, wmeta16, reachtab, rowperm, qreach, ditems, striptot, stripoff, xncand, xbox, xbox16, xord16, xcum, xinfo, tmp[8];
     // timing
     bool timing = false;
     bool timing_accumulate = false;   // vdet_set_timing(ctx, 2): keep events across calls until read
@@ -265,7 +268,7 @@ int make_plan(vdet_ctx *c, NmsPlan &pl)
 {
     const size_t budget_words = std::max<size_t>(c->bits_budget / 8, 1);
     size_t cur = 0;
-    int t0 = 0, p0 = 0;
+    int t0 = 0, p0 = 0, d0 = 0;
     pl.nmax = 0;
     pl.ntot = 0;
     for (size_t g = 0; g < pl.groups.size(); ++g) {
@@ -277,8 +280,10 @@ int make_plan(vdet_ctx *c, NmsPlan &pl)
         if (cur && cur + words > budget_words) {
             pl.batch_tiles.push_back({t0, (int)pl.tiles.size()});
             pl.batch_pairs.push_back({p0, (int)pl.pairs.size()});
+            pl.batch_ditems.push_back({d0, (int)pl.ditems.size()});
             t0 = (int)pl.tiles.size();
             p0 = (int)pl.pairs.size();
+            d0 = (int)pl.ditems.size();
             pl.bits_words_max = std::max(pl.bits_words_max, cur);
             cur = 0;
         }
@@ -288,10 +293,14 @@ int make_plan(vdet_ctx *c, NmsPlan &pl)
         for (int rt = 0; rt < nrt; ++rt) pl.tiles.push_back({(int32_t)g, rt});
         for (int rt = 0; rt < nrt; ++rt)
             for (int ct = rt; ct < nrt; ++ct) pl.pairs.push_back({(int32_t)g, (int16_t)rt, (int16_t)ct});
+        // (the widest quartile of every tile first: its items run longest)
+        for (int q = 3; q >= 0; --q)
+            for (int rt = 0; rt < nrt; ++rt) pl.ditems.push_back({(int32_t)g, (int32_t)(4 * rt + q)});
     }
     if ((int)pl.tiles.size() > t0) {
         pl.batch_tiles.push_back({t0, (int)pl.tiles.size()});
         pl.batch_pairs.push_back({p0, (int)pl.pairs.size()});
+        pl.batch_ditems.push_back({d0, (int)pl.ditems.size()});
     }
     pl.bits_words_max = std::max(pl.bits_words_max, cur);
     (void)c;
@@ -386,9 +395,13 @@ int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32, doub
     HIPCHK(c, c->groupz.reserve(G * 4));
     HIPCHK(c, c->gflags.reserve(G * 4));
     HIPCHK(c, c->pairs.reserve(std::max<size_t>(pl.pairs.size(), 1) * sizeof(TilePair)));
+    HIPCHK(c, c->ditems.reserve(std::max<size_t>(pl.ditems.size(), 1) * sizeof(ListItem)));
     if (!(volume && c->vplan_valid)) {
         if (!pl.pairs.empty())
             HIPCHK(c, hipMemcpyAsync(c->pairs.p, pl.pairs.data(), pl.pairs.size() * sizeof(TilePair),
+                                     hipMemcpyHostToDevice, c->stream));
+        if (!pl.ditems.empty())
+            HIPCHK(c, hipMemcpyAsync(c->ditems.p, pl.ditems.data(), pl.ditems.size() * sizeof(ListItem),
                                      hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->groups.p, pl.groups.data(), G * sizeof(GroupDesc), hipMemcpyHostToDevice, c->stream));
         if (!pl.tiles.empty())
@@ -461,9 +474,28 @@ int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32, doub
                 StageTimer tm(c, ST_OTHER);
                 hipLaunchKernelGGL(reach_table_kernel, dim3((unsigned)G), dim3(256), 0, c->stream, c->xbox.as<float4>(),
                                    c->groups.as<GroupDesc>(), c->gflags.as<uint32_t>(), one_minus_t, c->reachtab.as<float2>());
+                if (direct) {      // the tiles' rows by width: one quartile per wave of the predicate kernel
+                    HIPCHK(c, c->rowperm.reserve((size_t)pl.ntot * 2 + 1024));
+                    HIPCHK(c, c->qreach.reserve((size_t)(pl.ntot / 256 + (int64_t)G + 2) * 4 * sizeof(float)));
+                    hipLaunchKernelGGL(row_classes_kernel, dim3((unsigned)G, (unsigned)((pl.nmax + 255) / 256)), dim3(256), 0, c->stream,
+                                       c->xbox.as<float4>(), c->groups.as<GroupDesc>(), c->gflags.as<uint32_t>(), one_minus_t,
+                                       c->rowperm.as<uint16_t>(), c->qreach.as<float>());
+                }
             }
         } else {
             c->index_valid = false;      // gflags / the x-index describe some earlier boxes
+        }
+        if (direct && !pl.ditems.empty()) {
+            // ONE launch for every regular frame of the plan (no bit matrix: nothing ties the launch to the batches below): a
+            // work item is a wave that runs 90-250 us, and four launches of two rounds of items each were a quarter tail
+            StageTimer tm(c, ST_IOU_BITS);
+            GraphListsParams gp;
+            gp.xbox = c->xbox.as<float4>(); gp.xord = c->xord.as<uint16_t>(); gp.groups = c->groups.as<GroupDesc>();
+            gp.group_flags = c->gflags.as<uint32_t>(); gp.items = c->ditems.as<ListItem>(); gp.nitems = (int)pl.ditems.size();
+            gp.t32 = t32; gp.one_minus_t = one_minus_t; gp.row_deg = c->rowz.as<uint32_t>(); gp.reach_table = c->reachtab.as<float2>();
+            gp.rowperm = c->rowperm.as<uint16_t>(); gp.qreach = c->qreach.as<float>(); gp.adj = c->adj.as<uint16_t>();
+            gp.slot_cap = c->direct_cap; gp.status = &c->d_cnt->status; gp.over_bits = pool_bits | kStDirect;
+            hipLaunchKernelGGL(graph_lists_kernel, dim3((gp.nitems + 7) & ~7), dim3(64), 0, c->stream, gp);
         }
         for (size_t bi = 0; bi < pl.batch_tiles.size(); ++bi) {
             const auto bt = pl.batch_tiles[bi];
@@ -471,15 +503,9 @@ int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32, doub
             const int nt = bt.second - bt.first;
             if (nt <= 0) continue;
             uint64_t *bits_b = c->bits.as<uint64_t>();
-            if (use_sym && bp.second > bp.first) {
+            if (use_sym && !direct && bp.second > bp.first) {       // (the direct lists: one launch for all frames, above)
                 StageTimer tm(c, ST_IOU_BITS);
-                if (direct)
-                    hipLaunchKernelGGL((iou_bits_sym_kernel<true, true>), dim3((bp.second - bp.first + 7) & ~7), dim3(256), 0, c->stream,
-                                       c->xbox.as<float4>(), c->groups.as<GroupDesc>(), c->gflags.as<uint32_t>(),
-                                       c->pairs.as<TilePair>() + bp.first, t32, one_minus_t, bits_b, c->rowz.as<uint32_t>(),
-                                       c->reachtab.as<float2>(), c->xord.as<uint16_t>(), c->adj.as<uint16_t>(), c->direct_cap,
-                                       &c->d_cnt->status, pool_bits | kStDirect, bp.second - bp.first);
-                else if (c->wave_transpose)
+                if (c->wave_transpose)
                     hipLaunchKernelGGL(iou_bits_sym_kernel<true>, dim3(bp.second - bp.first), dim3(256), 0, c->stream,
                                        c->xbox.as<float4>(), c->groups.as<GroupDesc>(), c->gflags.as<uint32_t>(),
                                        c->pairs.as<TilePair>() + bp.first, t32, one_minus_t, bits_b, c->rowz.as<uint32_t>(),
@@ -1201,7 +1227,7 @@ int vdet_destroy(vdet_ctx *c)
                       &c->rowz, &c->rowmeta, &c->groupz, &c->adj, &c->comp, &c->origidx, &c->out64,
                       &c->trk_frames, &c->trk_boxes, &c->b1, &c->b2, &c->iou_out, &c->order, &c->ncand, &c->keepidx,
                       &c->keepcnt, &c->gflags, &c->pairs, &c->tkeys, &c->tstate, &c->visited, &c->heads, &c->xkeys, &c->xord, &c->xncand, &c->linkmemo, &c->linkstats, &c->linkwarm, &c->linkorder, &c->linkchains, &c->linknodes, &c->tracknode, &c->rtodo,
-                      &c->xbox, &c->xbox16, &c->xord16, &c->xcum, &c->xinfo, &c->wmeta, &c->wmeta16, &c->reachtab, &c->striptot, &c->stripoff, &c->sortctl, &c->segtab, &c->vidtab, &c->nover, &c->ordncand};
+                      &c->xbox, &c->xbox16, &c->xord16, &c->xcum, &c->xinfo, &c->wmeta, &c->wmeta16, &c->reachtab, &c->rowperm, &c->qreach, &c->ditems, &c->striptot, &c->stripoff, &c->sortctl, &c->segtab, &c->vidtab, &c->nover, &c->ordncand};
     for (DevBuf *b : bufs) b->release();
     for (DevBuf &b : c->tmp) b.release();
     for (auto &e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
