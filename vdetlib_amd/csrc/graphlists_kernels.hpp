@@ -87,30 +87,63 @@ struct GraphListsParams {
     uint32_t slot_cap;
     int *status;
     int over_bits;
+    uint32_t trash_off;              // byte offset of >= 256 unused bytes of the pool (where the entries of an overflowing list go)
 };
 
-// one 32-bit half of a word -> entries at byte offset boff of the pool
-__device__ __forceinline__ void emit_half(uint16_t *__restrict__ adj, uint32_t h, uint32_t boff, const uint16_t *ids)
+// One 32-bit half of a row word -> BOTH entries of every edge: the column's box goes to the row's list (byte offset boff of the
+// pool, consecutive places), the row's own box (myid) to the column's list -- at the byte offset kept in lpos[column], which a
+// returning LDS add hands out and advances.  The columns' entries need no second pass over the transposed word that way (the
+// two enumerations cost ~55 issue slots per half each; the extra add + store per edge ~4).
+__device__ __forceinline__ void emit_half(uint16_t *__restrict__ adj, uint32_t h, uint32_t boff, const uint16_t *ids, uint32_t *lpos,
+                                          const uint16_t myid)
 {
     constexpr int kSlots = 4;
     if (__ballot(h != 0u) == 0ull) return;                   // (wave-uniform)
     uint32_t hk[kSlots];
     uint16_t ek[kSlots];
+    int bk[kSlots];
 #pragma unroll
-    for (int k = 0; k < kSlots; ++k) { hk[k] = h; h &= h - 1u; }
+    for (int k = 0; k < kSlots; ++k) { hk[k] = h; bk[k] = __builtin_ctz(h) & 31; h &= h - 1u; }      // (an empty slot: bit 31, unused)
 #pragma unroll
-    for (int k = 0; k < kSlots; ++k) ek[k] = ids[__builtin_ctz(hk[k]) & 31];      // (an empty slot reads ids[31]: in bounds, unused)
+    for (int k = 0; k < kSlots; ++k) ek[k] = ids[bk[k]];
 #pragma unroll
-    for (int k = 0; k < kSlots; ++k)
-        if (hk[k] != 0u) *reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(adj) + (boff + 2u * k)) = ek[k];
+    for (int k = 0; k < kSlots; ++k) {
+        if (hk[k] != 0u) {
+            *reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(adj) + (boff + 2u * k)) = ek[k];
+            const uint32_t o = __hip_atomic_fetch_add(&lpos[bk[k]], 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            *reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(adj) + o) = myid;
+        }
+    }
     boff += 2u * kSlots;
     while (__ballot(h != 0u) != 0ull) {
         if (h != 0u) {
-            *reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(adj) + boff) = ids[__builtin_ctz(h)];
+            const int b = __builtin_ctz(h);
+            *reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(adj) + boff) = ids[b];
+            const uint32_t o = __hip_atomic_fetch_add(&lpos[b], 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            *reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(adj) + o) = myid;
             boff += 2u;
             h &= h - 1u;
         }
     }
+}
+
+// The entries of one evaluated block (m = my row's word over the block's 64 columns, tcnt = entries of column `lane`, pat / ptat =
+// the places the two cursors returned).  A list that would outgrow its slot latches over_bits; its entries
+// land in the pool's spare slot: the host rebuilds the graph through the bit matrix.
+__device__ __forceinline__ void emit_block(const uint32_t slot_cap, uint16_t *__restrict__ adj, int *__restrict__ status, const int over_bits,
+                                           const uint32_t trash_off, unsigned long long m, const uint32_t tcnt, const uint32_t pat,
+                                           const uint32_t ptat, const uint32_t row_slot, const uint32_t col_slot, const uint16_t *cids,
+                                           const uint16_t myid, uint32_t *lpos, const int lane)
+{
+    // (an overflowing row still hands its box to its columns' lists -- those rows are not to blame and their lists must come out
+    //  whole: the walk of an asynchronous step reads them before the host sees the flag)
+    const uint32_t cnt = (uint32_t)__popcll(m);
+    const bool rover = pat + cnt > slot_cap, cover = ptat + tcnt > slot_cap;
+    if ((rover && cnt) || (cover && tcnt)) atomicOr(status, over_bits);
+    lpos[lane] = cover ? trash_off : (col_slot * slot_cap + ptat) * 2u;
+    const uint32_t boff = rover ? trash_off : (row_slot * slot_cap + pat) * 2u;
+    emit_half(adj, (uint32_t)m, boff, cids, lpos, myid);
+    emit_half(adj, (uint32_t)(m >> 32), boff + 2u * (uint32_t)__popc((uint32_t)m), cids + 32, lpos + 32, myid);
 }
 
 // the 64 margins pairs of one block: complement of the sign words = predicate bits, anyb = some pair in the half-ulp band
@@ -148,7 +181,7 @@ __global__ __launch_bounds__(64, 6) void graph_lists_kernel(const GraphListsPara
     __shared__ float4 sbox[2][64];
     __shared__ float sarea[2][64];
     __shared__ uint16_t scord[2][64];
-    __shared__ uint16_t srord[64];
+    __shared__ uint32_t lpos[64];
     // block b runs on XCD b % 8: a contiguous eighth of the items (whole frames) per XCD
     const int per = gridDim.x >> 3;               // (the grid is the item count rounded up to a multiple of 8)
     const int idx = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
@@ -176,7 +209,8 @@ __global__ __launch_bounds__(64, 6) void graph_lists_kernel(const GraphListsPara
     uint16_t *adj = prm.adj;
 
     float4 br = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (v < B) { br = xb[v]; srord[lane] = xo[v]; } else srord[lane] = 0;
+    uint16_t myid = 0;
+    if (v < B) { br = xb[v]; myid = xo[v]; }
     const float rarea = box_area(br);
     float4 brx = br;
     if (ints) { brx.z += 1.0f; brx.w += 1.0f; }
@@ -193,8 +227,8 @@ __global__ __launch_bounds__(64, 6) void graph_lists_kernel(const GraphListsPara
         sbox[0][lane] = bc; scord[0][lane] = oc;
     }
     // the block whose atomics are in flight (row word / transposed word, the returned cursors, its column block and buffer)
-    unsigned long long pm = 0ull, ptm = 0ull;
-    uint32_t pat = 0u, ptat = 0u;
+    unsigned long long pm = 0ull;
+    uint32_t pat = 0u, ptat = 0u, ptcnt = 0u;
     int pc = -1;
     // (where the next block starts is fetched ONE BLOCK AHEAD: a load that is looked at right away is waited for with vmcnt(0),
     //  i.e. together with the atomics issued just before it, whose round trip the block's pair tests are meant to hide)
@@ -240,24 +274,9 @@ __global__ __launch_bounds__(64, 6) void graph_lists_kernel(const GraphListsPara
         uint32_t tlo = (uint32_t)m, thi = (uint32_t)(m >> 32);
         wave_transpose64(tlo, thi, tcs);          // (of the MASKED words)
         // the previous block's entries: its cursors have had this block's time to arrive
-        if (pc >= 0) {
-            {
-                unsigned long long mm = pm;
-                const uint32_t cnt = (uint32_t)__popcll(mm);
-                if (pat + cnt > slot_cap) { if (cnt) atomicOr(prm.status, prm.over_bits); mm = 0ull; }
-                const uint32_t boff = ((uint32_t)(gd.box_off + v) * slot_cap + pat) * 2u;
-                emit_half(adj, (uint32_t)mm, boff, scord[buf ^ 1]);
-                emit_half(adj, (uint32_t)(mm >> 32), boff + 2u * (uint32_t)__popc((uint32_t)mm), scord[buf ^ 1] + 32);
-            }
-            {
-                unsigned long long mm = ptm;
-                const uint32_t cnt = (uint32_t)__popcll(mm);
-                if (ptat + cnt > slot_cap) { if (cnt) atomicOr(prm.status, prm.over_bits); mm = 0ull; }
-                const uint32_t boff = ((uint32_t)(gd.box_off + pc * 64 + lane) * slot_cap + ptat) * 2u;
-                emit_half(adj, (uint32_t)mm, boff, srord);
-                emit_half(adj, (uint32_t)(mm >> 32), boff + 2u * (uint32_t)__popc((uint32_t)mm), srord + 32);
-            }
-        }
+        if (pc >= 0)
+            emit_block(slot_cap, adj, prm.status, prm.over_bits, prm.trash_off, pm, ptcnt, pat, ptat, (uint32_t)(gd.box_off + v),
+                       (uint32_t)(gd.box_off + pc * 64 + lane), scord[buf ^ 1], myid, lpos, lane);
         // this block's reservations
         {
             unsigned long long tm = 0ull;
@@ -267,7 +286,7 @@ __global__ __launch_bounds__(64, 6) void graph_lists_kernel(const GraphListsPara
             pat = 0u; ptat = 0u;
             if (cnt) pat = atomicAdd(&prm.row_deg[gd.box_off + v], cnt);
             if (tcnt) ptat = atomicAdd(&prm.row_deg[gd.box_off + u], tcnt);
-            pm = m; ptm = tm; pc = c;
+            pm = m; ptcnt = tcnt; pc = c;
         }
         if (!more) break;
         // stage the next block (the previous block's translations in that buffer have just been used)
@@ -276,25 +295,9 @@ __global__ __launch_bounds__(64, 6) void graph_lists_kernel(const GraphListsPara
         sbox[buf ^ 1][lane] = bn; scord[buf ^ 1][lane] = on;
     }
     // the last block's entries (its translations sit in the buffer it was evaluated from)
-    if (pc >= 0) {
-        const int buf = (pc - mt * 4) & 1;
-        {
-            unsigned long long mm = pm;
-            const uint32_t cnt = (uint32_t)__popcll(mm);
-            if (pat + cnt > slot_cap) { if (cnt) atomicOr(prm.status, prm.over_bits); mm = 0ull; }
-            const uint32_t boff = ((uint32_t)(gd.box_off + v) * slot_cap + pat) * 2u;
-            emit_half(adj, (uint32_t)mm, boff, scord[buf]);
-            emit_half(adj, (uint32_t)(mm >> 32), boff + 2u * (uint32_t)__popc((uint32_t)mm), scord[buf] + 32);
-        }
-        {
-            unsigned long long mm = ptm;
-            const uint32_t cnt = (uint32_t)__popcll(mm);
-            if (ptat + cnt > slot_cap) { if (cnt) atomicOr(prm.status, prm.over_bits); mm = 0ull; }
-            const uint32_t boff = ((uint32_t)(gd.box_off + pc * 64 + lane) * slot_cap + ptat) * 2u;
-            emit_half(adj, (uint32_t)mm, boff, srord);
-            emit_half(adj, (uint32_t)(mm >> 32), boff + 2u * (uint32_t)__popc((uint32_t)mm), srord + 32);
-        }
-    }
+    if (pc >= 0)
+        emit_block(slot_cap, adj, prm.status, prm.over_bits, prm.trash_off, pm, ptcnt, pat, ptat, (uint32_t)(gd.box_off + v),
+                   (uint32_t)(gd.box_off + pc * 64 + lane), scord[(pc - mt * 4) & 1], myid, lpos, lane);
 }
 
 }  // namespace vdet

@@ -1424,7 +1424,10 @@ __global__ __launch_bounds__(256) void rescore_adj_kernel(const float *__restric
                                                           int32_t *__restrict__ todo, unsigned int *__restrict__ todo_cnt)
 {
     const int l = threadIdx.x & 15;
-    const int64_t wv = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    // block b runs on XCD b % 8: a contiguous eighth of the tubelet boxes (wv is frame-major: whole frames) per XCD, so that a
+    // frame's boxes, lists and score rows are fetched into ONE L2 instead of eight (the grid is a multiple of 8 blocks)
+    const int64_t per = gridDim.x >> 3;
+    const int64_t wv = ((int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3)) * 16 + (threadIdx.x >> 4);
     if (wv >= (int64_t)F * C * T) return;
     if (!rescore_adj_one(wv, l, tracks, ntracks, boxes, scores, F, B, C, T, thres, out_score, out_box, group_flags, nodes, row_meta, adj,
                          min_self_iou) && l == 0)

@@ -413,9 +413,10 @@ int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32, doub
     // the pool, the dynamic part (irregular frames) follows
     auto direct_now = [&]() {
         return c->direct_lists && c->adj_rows && c->wave_transpose && pl.nmax > 384 && t32 > 1e-30f && t32 < INFINITY && !c->force_general &&
-               (size_t)8 * pl.nmax + 24 * 1024 <= c->max_lds && (unsigned long long)pl.ntot * c->direct_cap * 2ull <= 0xFFFFFFFFull;     // (byte offsets of the entries in 32 bits)
+               (size_t)8 * pl.nmax + 24 * 1024 <= c->max_lds && ((unsigned long long)pl.ntot + 1ull) * c->direct_cap * 2ull + 512ull <= 0xFFFFFFFFull;     // (byte offsets of the entries in 32 bits)
     };
-    auto fixed_pool = [&]() { return direct_now() ? (unsigned long long)pl.ntot * c->direct_cap : 0ull; };
+    // (one slot more than rows: where the entries of a column that outgrew its slot are dumped)
+    auto fixed_pool = [&]() { return direct_now() ? (unsigned long long)pl.ntot * c->direct_cap + std::max<unsigned long long>(c->direct_cap, 128) : 0ull; };
     unsigned long long min_pool = fixed_pool() + (unsigned long long)pl.ntot * (direct_now() ? 1 : 32);
     const bool async = volume && c->async_enabled && c->pool_hint > 0;
     if (async) {
@@ -495,6 +496,7 @@ int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32, doub
             gp.t32 = t32; gp.one_minus_t = one_minus_t; gp.row_deg = c->rowz.as<uint32_t>(); gp.reach_table = c->reachtab.as<float2>();
             gp.rowperm = c->rowperm.as<uint16_t>(); gp.qreach = c->qreach.as<float>(); gp.adj = c->adj.as<uint16_t>();
             gp.slot_cap = c->direct_cap; gp.status = &c->d_cnt->status; gp.over_bits = pool_bits | kStDirect;
+            gp.trash_off = (uint32_t)((unsigned long long)pl.ntot * c->direct_cap * 2ull);      // (the spare slot behind the rows')
             hipLaunchKernelGGL(graph_lists_kernel, dim3((gp.nitems + 7) & ~7), dim3(64), 0, c->stream, gp);
         }
         for (size_t bi = 0; bi < pl.batch_tiles.size(); ++bi) {
@@ -2167,7 +2169,7 @@ int vdet_rescore_tracks(vdet_ctx *c, const float *d_tracks, const int32_t *d_ntr
             HIPCHK(c, c->rtodo.reserve((size_t)nb * 4 + 16));
             unsigned int *cnt = reinterpret_cast<unsigned int *>(c->rtodo.as<char>() + (size_t)nb * 4);
             HIPCHK(c, hipMemsetAsync(cnt, 0, 4, c->stream));
-            hipLaunchKernelGGL(rescore_adj_kernel, dim3((unsigned)((nb + 15) / 16)), dim3(256), 0, c->stream, d_tracks, d_ntracks,
+            hipLaunchKernelGGL(rescore_adj_kernel, dim3((unsigned)((((nb + 15) / 16) + 7) & ~(int64_t)7)), dim3(256), 0, c->stream, d_tracks, d_ntracks,
                                reinterpret_cast<const float4 *>(d_boxes), d_scores, (int)F, (int)B, (int)C, max_tracks,
                                overlap_thres, d_det_score, d_boxes_out, flags, c->tracknode.as<int32_t>(), c->rowmeta.as<uint2>(),
                                c->adj.as<uint16_t>(), min_self, c->rtodo.as<int32_t>(), cnt);
