@@ -847,7 +847,7 @@ def main():
             except Exception:
                 traffic = None
         # what bounds each stage (VALU ceiling measured by devtools/valu_bench, profiles/)
-        BOUND = {"iou_bits": "valu", "adj_build": "hbm (reads the 2.1 GB bit matrix) + bit loops", "sort": "valu issue + lds (equalised counting sort)", "walk": "valu 47% / salu 46% / lds 49% busy, no pipe saturated (profiles/r06_pmc_sq*.csv)", "temporal": "hbm",
+        BOUND = {"iou_bits": "valu (pair tests + list entries, graph_lists_kernel)", "adj_build": "latency (adj_finish_kernel: pads + records; the lists themselves come out of the iou_bits stage = graph_lists_kernel)", "sort": "valu issue + lds (equalised counting sort)", "walk": "valu 47% / salu 46% / lds 49% busy, no pipe saturated (profiles/r06_pmc_sq*.csv)", "temporal": "hbm",
                  "transpose_keys": "hbm", "track_link": "latency (serial chain)", "track_pick": "latency", "rescore_spatial": "l2/valu",
                  "rescore_series": "latency", "track_suppress": "valu-issue", "iou_bits_general": "valu", "other": "latency"}
         for k, v in stages.items():
