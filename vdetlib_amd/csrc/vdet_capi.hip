@@ -550,8 +550,10 @@ int build_graph(vdet_ctx *c, const float4 *d_boxes, NmsPlan &pl, float t32, doub
                                    use_sym ? c->reachtab.as<float2>() : (const float2 *)nullptr, rows_path ? 1 : 0);
                 // regular groups of large frames: one workgroup per 64-row strip, half a wave per row (adjrows_kernels.hpp)
                 if (rows_path && direct) {
-                    hipLaunchKernelGGL(adj_finish_kernel, dim3(nt), dim3(256), 0, c->stream, c->groups.as<GroupDesc>(),
-                                       c->tiles.as<TileDesc>() + bt.first, c->rowz.as<uint32_t>(), c->rowmeta.as<uint2>(),
+                    // (one launch for all tiles, behind the first batch: the lists of every regular frame are complete by then)
+                    if (bi == 0)
+                    hipLaunchKernelGGL(adj_finish_kernel, dim3((unsigned)pl.tiles.size()), dim3(256), 0, c->stream, c->groups.as<GroupDesc>(),
+                                       c->tiles.as<TileDesc>(), c->rowz.as<uint32_t>(), c->rowmeta.as<uint2>(),
                                        c->adj.as<uint16_t>(), c->direct_cap, &c->d_cnt->status, c->gflags.as<uint32_t>(),
                                        c->xbox.as<float4>(), c->xord.as<uint16_t>(), pool_bits | kStDirect,
                                        c->wmeta_built ? c->wmeta.as<WalkMeta>() : (WalkMeta *)nullptr,
