@@ -130,6 +130,9 @@ int vdet_set_async(vdet_ctx *ctx, int enable);
  *   VDET_NO_FUSED=1       h_* calls of <= 640 rows through the general kernel chain (what larger inputs take)
  *   VDET_BINSORT=0        the LSD radix sort for every column (what tied / thresholded columns take)
  *   VDET_SMALL_LISTS=0    frames of <= 384 boxes through the large-list sort and walk
+ *   VDET_DIRECT_LISTS=0   the suppression graph of regular frames of > 384 boxes through the bit matrix (what a context takes for
+ *                         good once a row had more neighbours than a direct list slot holds); VDET_DIRECT_CAP=n entries per slot
+ *   VDET_ADJ_ROWS=0       (bit-matrix path) the lane-per-row adjacency kernel on every frame (what irregular / small frames take)
  *   VDET_ATOMIC_RANK=0 / VDET_WAVE_TRANSPOSE=0   the variants selected when the start-up hardware probes fail
  *   VDET_BITS_BUDGET_MB=n bytes of bit-matrix scratch per graph-build batch (default 1024) */
 int vdet_query(vdet_ctx *ctx, int what);
