@@ -1530,15 +1530,19 @@ __device__ __forceinline__ void walk_ring_drain(const WalkParams &prm, lds_mask_
         const int ng = min(8, qn);
         const int s = ring_wrap(qh + k);
         const bool vk = k < ng;
-        const int cm = vk ? (int)ring[8 * s] : 0;
+        // (the slot's four meta words -- candidate, list offset, length, area -- in ONE 16-byte LDS read; the areas were formed
+        //  once when the candidate was queued instead of twice per lane and group here)
+        const int sj = ring_wrap(qh + sub);
+        const lds_f4v mi = ringb[2 * s];
+        const int cm = vk ? (int)__float_as_uint(mi.x) : 0;
         // who survives: alive when the group starts, and not suppressed by an earlier surviving member (boxes from the ring)
-        const lds_f4v vi = ringb[2 * s + 1], vj = ringb[2 * ring_wrap(qh + sub) + 1];
+        const lds_f4v vi = ringb[2 * s + 1], vj = ringb[2 * sj + 1];
         const float4 bi = make_float4(vi.x, vi.y, vi.z, vi.w), bj = make_float4(vj.x, vj.y, vj.z, vj.w);
         const bool live = vk && !((mask[cm >> 5] >> (cm & 31)) & 1u);
         const unsigned long long lm = __ballot(live);
         // the graph's own edge rule without the division (regular frames only get here): the sign of fma(-t32, union, inter)
         // decides, the band just below the threshold falls back to the IEEE quotient (pred_regular, as in iou_bits_sym_kernel)
-        const float ai = box_area(bi), aj = box_area(bj);
+        const float ai = mi.w, aj = __uint_as_float(ring[8 * sj + 3]);
         bool border;
         bool hit = pred_regular(bi, ai, bj, aj, t32, t32 * 4.76837158203125e-7f, border);
         if (__ballot(border) != 0ull) {
@@ -1563,8 +1567,8 @@ __device__ __forceinline__ void walk_ring_drain(const WalkParams &prm, lds_mask_
             // the survivors' lists: lane `sub` owns entries [8 sub, 8 sub + 8) and [64 + 8 sub, 64 + 8 sub + 8) -- 8 lanes
             // read 128 contiguous, aligned bytes per load; a lane whose share lies past the list's end re-reads the
             // list's first 16 bytes (no extra cache line, no divergent load); only entries that exist go to the LDS
-            const uint32_t off = surv ? ring[8 * s + 1] : 0u;
-            const int deg = surv ? (int)ring[8 * s + 2] : 0;
+            const uint32_t off = surv ? __float_as_uint(mi.y) : 0u;
+            const int deg = surv ? (int)__float_as_uint(mi.z) : 0;
             const AdjVec *pa = reinterpret_cast<const AdjVec *>(prm.adj + off);
             const AdjVec a0 = pa[8 * sub < deg ? sub : 0];
             const AdjVec a1 = pa[64 + 8 * sub < deg ? 8 + sub : 0];
@@ -1676,6 +1680,7 @@ __device__ __forceinline__ void walk_list_packed(const WalkParams &prm, lds_mask
                 bv.x = bb[CUR].x; bv.y = bb[CUR].y; bv.z = bb[CUR].z; bv.w = bb[CUR].w;                                              \
             }                                                                                                                        \
             ringb[2 * s + 1] = bv;                                                                                                   \
+            ring[8 * s + 3] = __float_as_uint(box_area(make_float4(bv.x, bv.y, bv.z, bv.w)));                                        \
         }                                                                                                                            \
         qn += __popcll(am);                                                                                                          \
         walk_ring_drain(prm, mask, ring, ringb, lane, t32, q0_ + 64 >= ncand, qh, qn, nk, out, cap);                                 \
