@@ -1401,6 +1401,7 @@ struct WalkParams {
     int packed;               // regular frames take walk_list_packed (eight candidates per pass)
     const WalkMeta *wmeta;    // per box: coordinates + list (adj_build_kernel), and the graph's threshold: the packed walk
     float t32;                // tests the members of a group against each other geometrically
+    int adj32;                // the adjacency pool is smaller than 4 GB (byte offsets of its lists fit 32 bits)
     const uint4 *wmeta16;     // frames of integer coordinates (kFlagU16) whose records adj_rows_kernel wrote: the same record in 16
                               // bytes {x1 | y1 << 16, x2 | y2 << 16, list offset, degree} (null: none)
 };
@@ -1569,9 +1570,19 @@ __device__ __forceinline__ void walk_ring_drain(const WalkParams &prm, lds_mask_
             // list's first 16 bytes (no extra cache line, no divergent load); only entries that exist go to the LDS
             const uint32_t off = surv ? __float_as_uint(mi.y) : 0u;
             const int deg = surv ? (int)__float_as_uint(mi.z) : 0;
-            const AdjVec *pa = reinterpret_cast<const AdjVec *>(prm.adj + off);
-            const AdjVec a0 = pa[8 * sub < deg ? sub : 0];
-            const AdjVec a1 = pa[64 + 8 * sub < deg ? 8 + sub : 0];
+            AdjVec a0, a1;
+            if (prm.adj32) {
+                // (a pool of < 4 GB: 32-bit byte offsets next to the scalar base -- two 64-bit address computations less per
+                //  lane and group; A/B on one box: 2.79 -> 2.745 ms)
+                const uint32_t bo = off * 2u;
+                const char *ab = reinterpret_cast<const char *>(prm.adj);
+                a0 = *reinterpret_cast<const AdjVec *>(ab + (bo + (8 * sub < deg ? 16u * (uint32_t)sub : 0u)));
+                a1 = *reinterpret_cast<const AdjVec *>(ab + (bo + (64 + 8 * sub < deg ? 128u + 16u * (uint32_t)sub : 0u)));
+            } else {
+                const AdjVec *pa = reinterpret_cast<const AdjVec *>(prm.adj + off);
+                a0 = pa[8 * sub < deg ? sub : 0];
+                a1 = pa[64 + 8 * sub < deg ? 8 + sub : 0];
+            }
             // (a piece that starts inside the list is applied whole: K2 pads every list to a multiple of 8 entries with
             //  copies of its last entry -- one guard per piece instead of one per entry)
             const bool has0 = 8 * sub < deg, has1 = 64 + 8 * sub < deg;

@@ -794,6 +794,7 @@ int launch_sort_walk(vdet_ctx *c, const SortWalkArgs &a, int nmax, int64_t order
     wp.wmeta = c->wmeta.as<WalkMeta>();
     wp.t32 = c->gt32;
     wp.wmeta16 = (wp.packed && c->wmeta16_built) ? c->wmeta16.as<uint4>() : nullptr;
+    wp.adj32 = c->adj.cap <= 0xFFFFFF00ull ? 1 : 0;
     // frames of at most 384 boxes: one LANE per list, the frames' rows in LDS (small_kernels.hpp); the lists of irregular frames
     // are left to the general walk (walk_rest_kernel: normally nothing)
     const bool small_walk = c->small_lists && a.mode != 2 && nmax <= kSmallMax && wp.group_flags && a.C > 0 && a.P % a.C == 0;
