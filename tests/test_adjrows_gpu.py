@@ -133,3 +133,21 @@ def test_direct_lists_slot_sizes_and_the_fallback(slot, oracle, monkeypatch):
     idx, cnt = ops.nms_volume(tb, ts, 0.3, cap=B, ctx=cx)      # sync=True: repeats the enqueue by itself after a RetryError
     assert np.array_equal(cnt.cpu().numpy(), wcnt) and np.array_equal(idx.cpu().numpy(), widx)
     cx.close()
+
+
+def test_direct_lists_on_groups_of_mixed_sizes(oracle):
+    """vid_nms (utils/nms.pyx:71-125) through the drop-in module: ONE plan whose frames hold 1 / 3 / 64 / 385 / 500 / 1 300 detections
+    (the largest takes the plan to the direct lists; the small groups and the singleton ride along: partial tiles, tiles with one
+    valid quartile, a group without a graph), fractional and integer boxes, against the oracle's kept list."""
+    from vdetlib_amd.utils import cython_nms as cnms
+    rng = np.random.RandomState(20)
+    for integer in (True, False):
+        rows = []
+        for frame, n in enumerate([1, 3, 64, 385, 500, 1300, 2]):
+            b = _boxes(rng, n, 900, 700, 260, 260)
+            if not integer:
+                b = b + rng.rand(n, 4).astype(np.float32) * 0.5
+            rows.append(np.hstack([np.full((n, 1), frame + 1, np.float32), b, rng.rand(n, 1).astype(np.float32)]))
+        d = np.vstack(rows).astype(np.float32)
+        d = d[rng.permutation(len(d))]
+        assert cnms.vid_nms(d, 0.3) == oracle.vid_nms(d, 0.3)
